@@ -1,0 +1,326 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the reference's own Python modules.
+
+Runs ONLY in the build container (needs /root/reference).  Nothing from the
+reference is copied: this script imports its modules in place, feeds them
+seeded synthetic inputs and stores inputs + outputs as data fixtures.
+
+The reference imports two third-party native packages that are absent from the
+image (and from /root/reference): `ssw` (ssw-py) and `editdistance`.  They are
+replaced in sys.modules by the pure-Python restatements below (independent of
+oracle/badger_oracle.c, so the fixtures cross-check the C oracle as well):
+  - editdistance.eval: textbook unit-cost Levenshtein DP (uniquely defined).
+  - ssw.AlignmentMgr:  Smith-Waterman with the SSW library's published
+    end/begin tie rules.  Score is uniquely defined; the COORDINATE tie rules
+    are restated from the SSW algorithm and are NOT pinned against ssw-py.
+Every Python-level decision in the fixtures (branch order, slicing, strict vs
+non-strict comparisons, row formatting, chunk headers, q-gram filter, edge
+lists, clustering) is therefore the reference's own.
+`pysam`, `Bio`, `igraph`, `edlib`, `Levenshtein` are only imported by the
+reference's CLI/statistics modules, never called on the paths exercised here;
+they are satisfied by empty modules.
+"""
+import gzip
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+# ---------------------------------------------------------------- shims
+def lev(a, b):
+    prev = list(range(len(b) + 1))
+    for i in range(1, len(a) + 1):
+        cur = [i] + [0] * len(b)
+        for j in range(1, len(b) + 1):
+            cur[j] = min(prev[j - 1] + (a[i - 1] != b[j - 1]), prev[j] + 1, cur[j - 1] + 1)
+        prev = cur
+    return prev[len(b)]
+
+
+def _sw_scan(read, ref, order, terminate):
+    """SSW sw_sse2_byte semantics: returns (max, end_ref, end_read)."""
+    m = len(read)
+    hprev = [0] * m
+    best_col = [0] * m
+    mx, end_ref = 0, -1
+    for j in order:
+        rc = ref[j]
+        cur = [0] * m
+        for i in range(m):
+            pc = read[i]
+            s = 0 if (pc == "N" or rc == "N") else (1 if pc == rc else -1)
+            h = max(0, (hprev[i - 1] if i > 0 else 0) + s, (cur[i - 1] if i > 0 else 0) - 1, hprev[i] - 1)
+            cur[i] = h
+        cm = max(cur)
+        if cm > mx:
+            mx, end_ref, best_col = cm, j, cur
+        hprev = cur
+        if terminate and cm == terminate:
+            break
+    end_read = m - 1
+    for i in range(m):
+        if best_col[i] == mx and i < end_read:
+            end_read = i
+    return mx, end_ref, end_read
+
+
+class _Alignment:
+    pass
+
+
+class AlignmentMgr:
+    def __init__(self, match_score=2, mismatch_penalty=2):
+        assert (match_score, mismatch_penalty) in ((1, 1), (2, 2), (3, 3))
+        self.ms, self.mp = match_score, mismatch_penalty
+
+    def set_read(self, read):
+        self.read = read
+
+    def set_reference(self, ref):
+        self.ref = ref
+
+    def align(self, gap_open=3, gap_extension=1):
+        assert (self.ms, self.mp, gap_open, gap_extension) == (1, 1, 1, 1), "only the hot-path scoring is restated"
+        read, ref = self.read, self.ref
+        score, ref_end, read_end = _sw_scan(read, ref, range(len(ref)), 0)
+        a = _Alignment()
+        a.optimal_score = score
+        a.reference_end, a.read_end = ref_end, read_end
+        a.reference_start = a.read_start = -1
+        if score > 0:
+            rread = read[:read_end + 1][::-1]
+            _, rb, rr = _sw_scan(rread, ref, range(ref_end, -1, -1), score)
+            a.reference_start, a.read_start = rb, read_end - rr
+        return a
+
+
+def install_shims():
+    ssw = types.ModuleType("ssw")
+    ssw.AlignmentMgr = AlignmentMgr
+    sys.modules["ssw"] = ssw
+    ed = types.ModuleType("editdistance")
+    ed.eval = lev
+    sys.modules["editdistance"] = ed
+    for name in ("pysam", "Bio", "igraph", "edlib", "Levenshtein"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["Levenshtein"].distance = lev     # stats.py:20 imports the name; never called here
+    seqio = types.ModuleType("Bio.SeqIO")
+    sys.modules["Bio"].SeqIO = seqio
+    sys.modules["Bio.SeqIO"] = seqio
+    sys.path.insert(0, REF)
+
+
+# ---------------------------------------------------------------- inputs
+def edge_case_reads(rng):
+    """Hand-made reads around every branch of barcode_callers.py:181-229."""
+    R1 = "CTACACGACGCTCTTCCGATCT"
+    rnd = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))
+    bc, umi = "AAACCCAAGAAACACT", "ACGTTGCAACGG"
+    clean = rnd(12) + R1 + bc + umi + "T" * 30 + rnd(300)
+    reads = [
+        ("clean_fwd", clean),
+        ("clean_rev", rc(clean)),
+        ("random", rnd(500)),
+        ("short15", rnd(15)),
+        ("short16", rnd(16)),
+        ("short5", "ACGTA"),
+        ("empty", ""),
+        ("only_T", "T" * 40),
+        ("no_polyT_strict", rnd(20) + R1 + bc + umi + rnd(200)),
+        ("no_polyT_strict_rev", rc(rnd(20) + R1 + bc + umi + rnd(200))),
+        ("polyT_too_close", rnd(10) + R1 + "ACGTAC" + "T" * 30 + rnd(100)),
+        ("polyT_far", rnd(10) + R1 + bc + umi + rnd(30) + "T" * 30 + rnd(100)),
+        ("polyT_far_with_local_T5", rnd(10) + R1 + bc + umi + "TTTTTGACGACGAACGAGC" + "T" * 30 + rnd(80)),
+        ("r1_at_start", R1 + bc + umi + "T" * 30 + rnd(100)),
+        ("r1_truncated_start", R1[5:] + bc + umi + "T" * 30 + rnd(100)),
+        ("r1_truncated_end3", rnd(15) + R1[:-3] + bc + umi + "T" * 30 + rnd(100)),
+        ("r1_truncated_end5", rnd(15) + R1[:-5] + bc + umi + "T" * 30 + rnd(100)),
+        ("read_ends_in_barcode", rnd(30) + R1 + bc[:9]),
+        ("read_ends_after_r1", rnd(30) + R1),
+        ("read_ends_in_umi", rnd(30) + R1 + bc + umi[:4]),
+        ("double_r1", rnd(5) + R1 + rnd(40) + R1 + bc + umi + "T" * 30 + rnd(60)),
+        ("r1_concatemer", R1 * 4 + bc + umi + "T" * 30 + rnd(60)),
+        ("both_strands", rnd(8) + R1 + bc + umi + "T" * 30 + rnd(50) + rc(rnd(8) + R1 + bc + umi + "T" * 30)),
+        ("polyT_at_end", rnd(10) + R1 + bc + umi + "T" * 16),
+        ("polyT_at_end17", rnd(10) + R1 + bc + umi + "T" * 17),
+        ("with_N", rnd(10) + R1[:10] + "N" + R1[11:] + bc[:5] + "N" + bc[6:] + umi + "T" * 30 + rnd(50) + "NNN" + rnd(20)),
+        ("short_umi", rnd(10) + R1 + bc + "ACG" + "T" * 30 + rnd(50)),
+        ("long_umi", rnd(10) + R1 + bc + rnd(20) + "T" * 30 + rnd(50)),
+        ("mismatch_r1", rnd(10) + "CTACACGACGGTCTTCCGATCT" + bc + umi + "T" * 30 + rnd(50)),
+        ("indel_r1", rnd(10) + "CTACACGACGCTTTCCGATCT" + bc + umi + "T" * 30 + rnd(50)),
+        ("ins_r1", rnd(10) + "CTACACGACGCTCATTCCGATCT" + bc + umi + "T" * 30 + rnd(50)),
+        ("sparse_T", rnd(10) + R1 + bc + umi + "TTTATTTCTTTGTTTATTTT" + rnd(50)),
+    ]
+    return reads
+
+
+def main():
+    install_shims()
+    os.makedirs(OUT, exist_ok=True)
+    from badger_amd import synth
+
+    from barcode_extraction import barcode_callers, common as bx_common, kmer_indexer
+    import common as ref_common
+    import index as ref_index
+    import barcode_graph as ref_graph
+    import extract_raw_barcodes as ref_extract
+
+    rng = np.random.default_rng(12345)
+
+    # ---- 1. primitives (KATs) --------------------------------------
+    prim = {"find_polyt_start": [], "find_polyt_start_w5": [], "reverese_complement": [],
+            "get_occurrences": [], "align_pattern_ssw": [], "detect_exact_positions": [],
+            "rank": [], "qgram_threshold": [], "editdistance": []}
+    seqs = [s for _, s in edge_case_reads(rng)]
+    for _ in range(60):
+        n = int(rng.integers(0, 120))
+        p = rng.random()
+        alpha = "ACGT" if p < 0.5 else "TTTA" if p < 0.8 else "TTTTTTC"
+        seqs.append("".join(alpha[i] for i in rng.integers(0, len(alpha), n)))
+    idx = kmer_indexer.KmerIndexer([barcode_callers.TenXBarcodeExtractor.R1], kmer_size=6)
+    R1 = barcode_callers.TenXBarcodeExtractor.R1
+    for s in seqs:
+        prim["find_polyt_start"].append([s, bx_common.find_polyt_start(s)])
+        prim["find_polyt_start_w5"].append([s[:14], bx_common.find_polyt_start(s[:14], window_size=5, polya_fraction=1.0)])
+        if "N" not in s or True:
+            prim["reverese_complement"].append([s, bx_common.reverese_complement(s)])
+        occ = idx.get_occurrences(s)
+        prim["get_occurrences"].append([s, occ[R1][2] if occ else []])
+        if occ:
+            for (ms, sd, ed_) in ((9, -1, 4), (17, 1, 1), (0, -1, -1)):
+                r = bx_common.detect_exact_positions(s, 0, len(s), 6, R1, occ, min_score=ms, start_delta=sd, end_delta=ed_)
+                prim["detect_exact_positions"].append([s, 0, len(s), occ[R1][2], ms, sd, ed_, list(r)])
+    for _ in range(300):
+        n = int(rng.integers(6, 40))
+        w = "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+        if rng.random() < 0.7:      # plant a mutated piece of R1
+            a = int(rng.integers(0, 12)); b = int(rng.integers(a + 6, 23))
+            piece = list(R1[a:b])
+            for k in range(len(piece)):
+                u = rng.random()
+                if u < 0.08: piece[k] = "ACGT"[int(rng.integers(0, 4))]
+                elif u < 0.12: piece[k] = ""
+                elif u < 0.16: piece[k] = piece[k] + "ACGT"[int(rng.integers(0, 4))]
+            piece = "".join(piece)
+            at = int(rng.integers(0, max(1, n - len(piece))))
+            w = (w[:at] + piece + w[at + len(piece):])[:39]
+        prim["align_pattern_ssw"].append([w, list(bx_common.align_pattern_ssw(w, 0, len(w), R1, 0))])
+    for _ in range(50):
+        s = "".join("ACGT"[i] for i in rng.integers(0, 4, 16))
+        rk = ref_common.rank(s, 16)
+        assert ref_common.unrank(rk, 16) == s
+        prim["rank"].append([s, rk])
+    for t in (0, 1, 2, 3):
+        import contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            prim["qgram_threshold"].append([t, ref_index.QGramIndex(t, 16, 6).threshold])
+    for _ in range(200):
+        la, lb = int(rng.integers(0, 17)), int(rng.integers(0, 17))
+        a = "".join("ACGT"[i] for i in rng.integers(0, 4, la))
+        b = list(a[:lb]) if rng.random() < 0.6 else ["ACGT"[i] for i in rng.integers(0, 4, lb)]
+        for k in range(len(b)):
+            if rng.random() < 0.15: b[k] = "ACGT"[int(rng.integers(0, 4))]
+        b = "".join(b)
+        prim["editdistance"].append([a, b, lev(a, b)])
+    json.dump(prim, open(os.path.join(OUT, "primitives.json"), "w"))
+
+    # ---- 2. per-read extraction rows (both protocol versions) ------
+    wl = synth.make_whitelist(1000)
+    bases, off = synth.make_reads(300, wl, seed=7)
+    reads = edge_case_reads(rng) + [("syn_%d" % i, s) for i, s in enumerate(synth.reads_to_list(bases, off))]
+    bases0, off0 = synth.make_reads(40, wl, seed=8, p_sub=0.0, p_ins=0.0, p_del=0.0)
+    reads += [("clean_%d" % i, s) for i, s in enumerate(synth.reads_to_list(bases0, off0))]
+    ext = {"header": barcode_callers.TenXBarcodeDetectionResult.header(), "reads": []}
+    d3, d2 = barcode_callers.TenXBarcodeExtractorV3(), barcode_callers.TenXBarcodeExtractorV2()
+    for rid, s in reads:
+        r3, r2 = d3.find_barcode_umi(rid, s), d2.find_barcode_umi(rid, s)
+        ext["reads"].append({"id": rid, "seq": s, "row_v3": str(r3), "row_v2": str(r2),
+                             "r1_score_v3": r3.r1_score, "r1_score_v2": r2.r1_score})
+    json.dump(ext, open(os.path.join(OUT, "extract_rows.json"), "w"))
+
+    # ---- 3. config 1: 1K reads through BarcodeCaller.process_chunk --
+    bases, off = synth.make_reads(1000, wl, seed=1)
+    c1 = synth.reads_to_list(bases, off)
+    with gzip.open(os.path.join(OUT, "c1_reads.fa.gz"), "wt", compresslevel=9) as f:
+        for i, s in enumerate(c1):
+            f.write(">read_%d\n%s\n" % (i, s))
+    np.save(os.path.join(OUT, "c1_whitelist.npy"), wl)
+    tsv = os.path.join(OUT, "c1_expected.tsv")
+    handler = ref_extract.FileReadHandler(tsv)
+    caller = ref_extract.BarcodeCaller(barcode_callers.TenXBarcodeExtractorV3(), handler)
+    caller.process_chunk([("read_%d" % i, s) for i, s in enumerate(c1)])
+    handler.dump_stats(caller.read_stat)            # -> c1_expected.tsv.stats
+    handler.output_file.close()
+
+    # ---- 4. graph: counts / edges / dists / q-gram candidates ------
+    graph = {}
+    rows = [l.rstrip("\n").split("\t") for l in open(tsv) if not l.startswith("#")]
+    c1_barcodes = [r[1] for r in rows if r[1] != "*"]
+    cells = [synth.rank_to_str(x) for x in wl[:60]]
+    obs = []
+    g7 = np.random.default_rng(7)
+    for _ in range(1333):
+        s = list(cells[int(g7.integers(0, 60))])
+        k = 0
+        while k < len(s):
+            u = g7.random()
+            if u < 0.04: s[k] = "ACGT"[int(g7.integers(0, 4))]
+            elif u < 0.06: del s[k]; continue
+            elif u < 0.08: s.insert(k, "ACGT"[int(g7.integers(0, 4))]); k += 1
+            k += 1
+        s = "".join(s)
+        if len(s) >= 16:
+            s = s[:16] if g7.random() < 0.8 else s[:17]      # 17-char inputs are trimmed (barcode_graph.py:196-197)
+        obs.append(s)
+    for name, bcs in (("c1", c1_barcodes), ("cells60", obs)):
+        for thr in (1, 2):
+            import contextlib
+            with contextlib.redirect_stdout(io.StringIO()):
+                g = ref_graph.BarcodeGraph(thr)
+                g.graph_construction(bcs, 16, 1)
+            edges = sorted((a, b, g.dists[(a, b)]) for a in g.edges for b in g.edges[a] if a < b)
+            assert all(g.dists[(b, a)] == d for a, b, d in edges)
+            assert len(edges) == len(set(edges))
+            graph["%s_thr%d" % (name, thr)] = {
+                "barcodes": bcs, "counts": [[int(k), int(v)] for k, v in g.counts.items()],
+                "qgram_T": g.index.threshold, "edges": [[int(a), int(b), int(d)] for a, b, d in edges]}
+            if name == "cells60" and thr == 1:
+                ranks = list(g.counts.keys())[:40]
+                cl = []
+                for rk in ranks:
+                    cl.append([int(rk), sorted(int(x) for x in g.index.get_close(ref_common.unrank(rk, 16), rk))])
+                graph["cells60_get_close_thr1"] = cl
+    json.dump(graph, open(os.path.join(OUT, "graph.json"), "w"))
+
+    # ---- 5. stage 2 end to end: badger.py main on the c1 TSV -------
+    import contextlib
+    import badger as ref_badger
+    wl_file = os.path.join(OUT, "c1_whitelist.txt")
+    # whitelist for stage 2: the cells that actually occur, so cluster centers exist
+    with open(wl_file, "w") as f:
+        f.write("\n".join(synth.rank_to_str(x) for x in wl))
+    for hs in (False, True):
+        prefix = os.path.join(OUT, "c1_stage2%s" % ("_hs" if hs else ""))
+        argv = ["-r", tsv, "-d", "tenX_v3", "-l", wl_file, "-c", "50", "-o", prefix]
+        if hs:
+            argv.append("-hs")
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ref_badger.main(argv)
+        open(prefix + "_stdout_tail.txt", "w").write(buf.getvalue().strip().split("\n")[-1] + "\n")
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
