@@ -1,0 +1,205 @@
+"""ctypes binding of libbadger_hip.so (include/badger_hip.h).
+
+The product path: there is NO CPU fallback.  If the HIP library is missing, or no
+MI355X is visible, every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbadger_hip.so")
+
+REC_DTYPE = np.dtype([
+    ("polyT", "<i4"), ("r1_end", "<i4"), ("bc_start", "<i4"), ("umi_start", "<i4"),
+    ("umi_end", "<i4"), ("bc_rank", "<u4"), ("r1_score", "i1"), ("strand", "i1"),
+    ("valid", "u1"), ("flags", "u1"), ("reserved", "<u4")])
+EDGE_DTYPE = np.dtype([("a", "<u4"), ("b", "<u4"), ("dist", "<u4")])
+FLAG_REV = 1
+FLAG_RANK_OK = 2
+NONE_IDX = 0xFFFFFFFF
+
+E_ARG, E_HIP, E_NOMEM, E_CAPACITY, E_BADBASE = -1, -2, -3, -4, -5
+
+EXPORTS = [
+    "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_set_stream", "bdg_synchronize",
+    "bdg_profile_enable", "bdg_profile_reset", "bdg_profile_read",
+    "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status",
+    "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_set_algo",
+    "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_set_algo",
+]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+class BadgerHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libbadger_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_LIB = None
+
+
+def load():
+    """dlopen the in-tree HIP library and declare its prototypes.  No GPU needed for this."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `make -C badger_amd/csrc` "
+                          "(or `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    L.bdg_init.argtypes = [C.c_int, C.POINTER(vp)]
+    L.bdg_free.argtypes = [vp]
+    L.bdg_free.restype = None
+    L.bdg_last_error.argtypes = [vp]
+    L.bdg_last_error.restype = C.c_char_p
+    L.bdg_version.restype = C.c_char_p
+    L.bdg_set_stream.argtypes = [vp, vp]
+    L.bdg_synchronize.argtypes = [vp]
+    L.bdg_profile_enable.argtypes = [vp, C.c_int]
+    L.bdg_profile_reset.argtypes = [vp]
+    L.bdg_profile_read.argtypes = [vp, C.POINTER(KernelTime), C.c_int]
+    L.bdg_extract_batch.argtypes = [vp, vp, vp, u32, u32, vp]
+    L.bdg_extract_batch_dev.argtypes = [vp, vp, vp, u32, u64, u32, vp]
+    L.bdg_extract_status.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.bdg_nearest16.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp, vp]
+    L.bdg_whitelist_load.argtypes = [vp, vp, u32]
+    L.bdg_nearest16_dev.argtypes = [vp, vp, u32, u32, vp, vp, vp]
+    L.bdg_nearest16_set_algo.argtypes = [vp, C.c_int]
+    L.bdg_graph_edges.argtypes = [vp, vp, u32, u32, i32, vp, u64, C.POINTER(u64)]
+    L.bdg_graph_edges_dev.argtypes = [vp, vp, u32, u32, i32, vp, u64, vp]
+    L.bdg_graph_set_algo.argtypes = [vp, C.c_int]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("bdg_free",):
+            fn.restype = C.c_int
+    _LIB = L
+    return L
+
+
+class Context:
+    """One bdg_ctx = one GPU.  Host-buffer calls take numpy arrays; *_dev calls take torch tensors
+    that already live on the context's device."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.bdg_init(int(device), C.byref(h))
+        if rc != 0:
+            raise BadgerHipError(rc, self.lib.bdg_last_error(None).decode())
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bdg_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise BadgerHipError(rc, self.lib.bdg_last_error(self.h).decode())
+        return rc
+
+    # -- plumbing ----------------------------------------------------------
+    def set_stream(self, hip_stream_handle):
+        self._check(self.lib.bdg_set_stream(self.h, C.c_void_p(hip_stream_handle or 0)))
+
+    def synchronize(self):
+        self._check(self.lib.bdg_synchronize(self.h))
+
+    def profile(self, on=True):
+        self._check(self.lib.bdg_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.bdg_profile_reset(self.h))
+
+    def profile_read(self):
+        buf = (KernelTime * 32)()
+        n = self._check(self.lib.bdg_profile_read(self.h, buf, 32))
+        return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(min(n, 32))}
+
+    # -- extraction ----------------------------------------------------------
+    def extract_batch(self, bases, off, umi_len=12):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        out = np.zeros(max(n, 0), dtype=REC_DTYPE)
+        if n <= 0:
+            return out
+        self._check(self.lib.bdg_extract_batch(self.h, bases.ctypes.data, off.ctypes.data, n, umi_len, out.ctypes.data))
+        return out
+
+    def extract_batch_dev(self, d_bases, d_off, n, total_bytes, umi_len, d_out):
+        self._check(self.lib.bdg_extract_batch_dev(self.h, d_bases.data_ptr(), d_off.data_ptr(), n, total_bytes,
+                                                   umi_len, d_out.data_ptr()))
+
+    def extract_status(self):
+        bad, nwin = C.c_uint64(), C.c_uint64()
+        rc = self.lib.bdg_extract_status(self.h, C.byref(bad), C.byref(nwin))
+        return rc, bad.value, nwin.value
+
+    # -- nearest ---------------------------------------------------------------
+    def nearest16(self, q, wl, max_ed=2):
+        q = np.ascontiguousarray(q, dtype=np.uint32)
+        wl = np.ascontiguousarray(wl, dtype=np.uint32)
+        idx = np.zeros(len(q), np.uint32)
+        ed = np.zeros(len(q), np.uint8)
+        ties = np.zeros(len(q), np.uint16)
+        self._check(self.lib.bdg_nearest16(self.h, q.ctypes.data, len(q), wl.ctypes.data, len(wl), max_ed,
+                                           idx.ctypes.data, ed.ctypes.data, ties.ctypes.data))
+        return idx, ed, ties
+
+    def whitelist_load(self, wl):
+        wl = np.ascontiguousarray(wl, dtype=np.uint32)
+        self._check(self.lib.bdg_whitelist_load(self.h, wl.ctypes.data, len(wl)))
+
+    def nearest16_dev(self, d_q, nq, max_ed, d_idx, d_ed, d_ties):
+        self._check(self.lib.bdg_nearest16_dev(self.h, d_q.data_ptr(), nq, max_ed, d_idx.data_ptr(),
+                                               d_ed.data_ptr(), d_ties.data_ptr()))
+
+    def nearest16_set_algo(self, algo):
+        self._check(self.lib.bdg_nearest16_set_algo(self.h, algo))
+
+    # -- graph -----------------------------------------------------------------
+    def graph_edges(self, ranks, thr, qgram_T):
+        ranks = np.ascontiguousarray(ranks, dtype=np.uint32)
+        cap = max(1024, 4 * len(ranks))
+        while True:
+            out = np.zeros(cap, dtype=EDGE_DTYPE)
+            tot = C.c_uint64()
+            rc = self.lib.bdg_graph_edges(self.h, ranks.ctypes.data, len(ranks), thr, qgram_T,
+                                          out.ctypes.data, cap, C.byref(tot))
+            if rc == E_CAPACITY and tot.value > cap:
+                cap = int(tot.value)
+                continue
+            self._check(rc)
+            return out[:tot.value]
+
+    def graph_edges_dev(self, d_ranks, n, thr, qgram_T, d_out, cap, d_n_edges):
+        self._check(self.lib.bdg_graph_edges_dev(self.h, d_ranks.data_ptr(), n, thr, qgram_T,
+                                                 d_out.data_ptr(), cap, d_n_edges.data_ptr()))
+
+    def graph_set_algo(self, algo):
+        self._check(self.lib.bdg_graph_set_algo(self.h, algo))
+
+
+_DEFAULT = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (created on first use; raises without a GPU)."""
+    if device not in _DEFAULT:
+        _DEFAULT[device] = Context(device)
+    return _DEFAULT[device]

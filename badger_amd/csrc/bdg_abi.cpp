@@ -1,0 +1,328 @@
+// C ABI of libbadger_hip.so (include/badger_hip.h): context management, host-buffer
+// wrappers (H2D, launch, D2H) and the device-resident entry points.
+#include "bdg_common.hpp"
+
+#include <algorithm>
+#include <mutex>
+
+// launchers in the kernel translation units
+int bdg_extract_launch(bdg_ctx*, const uint8_t*, const uint64_t*, uint32_t, uint64_t, uint32_t, bdg_extract_rec*);
+int bdg_extract_status_impl(bdg_ctx*, uint64_t*, uint64_t*);
+int bdg_whitelist_load_impl(bdg_ctx*, const uint32_t*, uint32_t);
+int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
+int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*);
+
+static thread_local std::string g_err_noctx;
+
+int bdg_reserve(bdg_ctx* ctx, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.bytes && b.p) return BDG_OK;
+    if (bytes < 256) bytes = 256;
+    if (b.p) {
+        // the buffer may still be in use by queued work
+        BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        BDG_HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr; b.bytes = 0;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->err = "hipMalloc(" + std::to_string(bytes) + " bytes): " + hipGetErrorString(e);
+        return BDG_E_NOMEM;
+    }
+    b.p = p; b.bytes = bytes;
+    return BDG_OK;
+}
+
+int bdg_timer_id(bdg_ctx* ctx, const char* name)
+{
+    for (size_t i = 0; i < ctx->timers.size(); ++i) if (ctx->timers[i].name == name) return (int)i;
+    ctx->timers.emplace_back();
+    ctx->timers.back().name = name;
+    return (int)ctx->timers.size() - 1;
+}
+
+static hipEvent_t take_event(bdg_ctx* ctx)
+{
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void bdg_timer_begin(bdg_ctx* ctx, int id)
+{
+    hipEvent_t a = take_event(ctx), b = take_event(ctx);
+    (void)hipEventRecord(a, ctx->stream);
+    ctx->timers[id].pending.emplace_back(a, b);
+}
+
+void bdg_timer_end(bdg_ctx* ctx, int id)
+{
+    (void)hipEventRecord(ctx->timers[id].pending.back().second, ctx->stream);
+    ctx->timers[id].launches++;
+}
+
+static int collect_timers(bdg_ctx* ctx)
+{
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& t : ctx->timers) {
+        for (auto& pr : t.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) t.total_ms += ms;
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        t.pending.clear();
+    }
+    return BDG_OK;
+}
+
+extern "C" {
+
+const char* bdg_version(void) { return "badger_hip 0.1 (gfx950)"; }
+
+int bdg_init(int device_id, bdg_ctx** out)
+{
+    if (!out) return BDG_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { g_err_noctx = "no HIP device available"; return BDG_E_HIP; }
+    if (device_id < 0 || device_id >= ndev) { g_err_noctx = "device_id out of range"; return BDG_E_ARG; }
+    if (hipSetDevice(device_id) != hipSuccess) { g_err_noctx = "hipSetDevice failed"; return BDG_E_HIP; }
+    bdg_ctx* ctx = new bdg_ctx();
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx; g_err_noctx = "hipStreamCreate failed"; return BDG_E_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return BDG_OK;
+}
+
+void bdg_free(bdg_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = { &ctx->x_lut, &ctx->x_polyt, &ctx->x_keys, &ctx->x_hits, &ctx->x_counters, &ctx->s_in0,
+                       &ctx->s_in1, &ctx->s_out0, &ctx->w_sorted, &ctx->w_orig, &ctx->w_prefix, &ctx->w_bitmap,
+                       &ctx->n_list, &ctx->n_counters, &ctx->g_sig, &ctx->g_tmp0, &ctx->g_tmp1, &ctx->g_cnt };
+    for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    for (auto& t : ctx->timers) for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* bdg_last_error(bdg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err_noctx.c_str(); }
+
+int bdg_set_stream(bdg_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return BDG_E_ARG;
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return BDG_OK;
+}
+
+int bdg_synchronize(bdg_ctx* ctx)
+{
+    if (!ctx) return BDG_E_ARG;
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDG_OK;
+}
+
+int bdg_profile_enable(bdg_ctx* ctx, int on) { if (!ctx) return BDG_E_ARG; ctx->profiling = on != 0; return BDG_OK; }
+
+int bdg_profile_reset(bdg_ctx* ctx)
+{
+    if (!ctx) return BDG_E_ARG;
+    int rc = collect_timers(ctx);
+    for (auto& t : ctx->timers) { t.launches = 0; t.total_ms = 0.0; }
+    return rc;
+}
+
+int bdg_profile_read(bdg_ctx* ctx, bdg_kernel_time* out, int cap)
+{
+    if (!ctx) return BDG_E_ARG;
+    int rc = collect_timers(ctx);
+    if (rc) return rc;
+    int n = (int)ctx->timers.size();
+    for (int i = 0; i < n && i < cap && out; ++i) {
+        memset(&out[i], 0, sizeof(out[i]));
+        strncpy(out[i].name, ctx->timers[i].name.c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = ctx->timers[i].launches;
+        out[i].total_ms = ctx->timers[i].total_ms;
+    }
+    return n;
+}
+
+// ---- extraction -----------------------------------------------------------
+int bdg_extract_batch_dev(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_off, uint32_t n,
+                          uint64_t total_bytes, uint32_t umi_len, bdg_extract_rec* d_out)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (n && (!d_bases || !d_off || !d_out)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    if (umi_len == 0 || umi_len > 64) return bdg_fail(ctx, BDG_E_ARG, "umi_len out of range");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bdg_extract_launch(ctx, d_bases, d_off, n, total_bytes, umi_len, d_out);
+}
+
+int bdg_extract_status(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_windows)
+{
+    if (!ctx) return BDG_E_ARG;
+    return bdg_extract_status_impl(ctx, bad_read, n_windows);
+}
+
+int bdg_extract_batch(bdg_ctx* ctx, const uint8_t* bases, const uint64_t* off, uint32_t n,
+                      uint32_t umi_len, bdg_extract_rec* out)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (n == 0) return BDG_OK;
+    if (!bases || !off || !out) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    if (umi_len == 0 || umi_len > 64) return bdg_fail(ctx, BDG_E_ARG, "umi_len out of range");
+    for (uint32_t i = 0; i < n; ++i)
+        if (off[i + 1] < off[i]) return bdg_fail(ctx, BDG_E_ARG, "offsets must be non-decreasing");
+    for (uint32_t i = 0; i < n; ++i)
+        if (off[i + 1] - off[i] >= (1ull << 30)) return bdg_fail(ctx, BDG_E_ARG, "read longer than 2^30 bases");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // ship only the byte range the offsets reference, rebased to 0
+    const uint64_t lo = off[0], hi = off[n], total = hi - lo;
+    int rc;
+    if ((rc = bdg_reserve(ctx, ctx->s_in0, total + 64))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->s_in1, sizeof(uint64_t) * ((size_t)n + 1)))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->s_out0, sizeof(bdg_extract_rec) * (size_t)n))) return rc;
+    std::vector<uint64_t> rel((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; ++i) rel[i] = off[i] - lo;
+    hipStream_t st = ctx->stream;
+    if (total) BDG_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_in0.p, bases + lo, total, hipMemcpyHostToDevice, st));
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_in1.p, rel.data(), sizeof(uint64_t) * rel.size(), hipMemcpyHostToDevice, st));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        rc = bdg_extract_launch(ctx, static_cast<const uint8_t*>(ctx->s_in0.p), static_cast<const uint64_t*>(ctx->s_in1.p),
+                                n, total, umi_len, static_cast<bdg_extract_rec*>(ctx->s_out0.p));
+        if (rc) return rc;
+        uint64_t bad = 0, nwin = 0;
+        rc = bdg_extract_status_impl(ctx, &bad, &nwin);
+        if (rc != BDG_E_CAPACITY) break;          // queue overflow: workspace grown, run again
+    }
+    if (rc) return rc;
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->s_out0.p, sizeof(bdg_extract_rec) * (size_t)n, hipMemcpyDeviceToHost, st));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return BDG_OK;
+}
+
+// ---- nearest ----------------------------------------------------------------
+int bdg_whitelist_load(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (nw && !wl) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bdg_whitelist_load_impl(ctx, wl, nw);
+}
+
+int bdg_nearest16_set_algo(bdg_ctx* ctx, int algo)
+{
+    if (!ctx || algo < 0 || algo > 2) return BDG_E_ARG;
+    ctx->n16_algo = algo;
+    return BDG_OK;
+}
+
+int bdg_nearest16_dev(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t max_ed,
+                      uint32_t* d_best_idx, uint8_t* d_best_ed, uint16_t* d_n_ties)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (nq && (!d_q || !d_best_idx || !d_best_ed || !d_n_ties)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bdg_nearest16_launch(ctx, d_q, nq, max_ed, d_best_idx, d_best_ed, d_n_ties);
+}
+
+int bdg_nearest16(bdg_ctx* ctx, const uint32_t* q, uint32_t nq, const uint32_t* wl, uint32_t nw,
+                  uint32_t max_ed, uint32_t* best_idx, uint8_t* best_ed, uint16_t* n_ties)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (nq == 0) return BDG_OK;
+    if (!q || !best_idx || !best_ed || !n_ties || (nw && !wl)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (nw == 0) {
+        for (uint32_t i = 0; i < nq; ++i) { best_idx[i] = 0xFFFFFFFFu; best_ed[i] = 0xFF; n_ties[i] = 0; }
+        return BDG_OK;
+    }
+    int rc = bdg_whitelist_load_impl(ctx, wl, nw);
+    if (rc) return rc;
+    const size_t bq = sizeof(uint32_t) * (size_t)nq;
+    if ((rc = bdg_reserve(ctx, ctx->s_in0, bq))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->s_out0, bq * 2 + 64))) return rc;     // idx u32 | ties u16 | ed u8
+    hipStream_t st = ctx->stream;
+    auto* d_idx = static_cast<uint32_t*>(ctx->s_out0.p);
+    auto* d_ties = reinterpret_cast<uint16_t*>(d_idx + nq);
+    auto* d_ed = reinterpret_cast<uint8_t*>(d_ties + nq);
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_in0.p, q, bq, hipMemcpyHostToDevice, st));
+    rc = bdg_nearest16_launch(ctx, static_cast<const uint32_t*>(ctx->s_in0.p), nq, max_ed, d_idx, d_ed, d_ties);
+    if (rc) return rc;
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(best_idx, d_idx, bq, hipMemcpyDeviceToHost, st));
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(n_ties, d_ties, sizeof(uint16_t) * (size_t)nq, hipMemcpyDeviceToHost, st));
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(best_ed, d_ed, (size_t)nq, hipMemcpyDeviceToHost, st));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return BDG_OK;
+}
+
+// ---- graph --------------------------------------------------------------------
+int bdg_graph_set_algo(bdg_ctx* ctx, int algo)
+{
+    if (!ctx || algo < 0 || algo > 2) return BDG_E_ARG;
+    ctx->graph_algo = algo;
+    return BDG_OK;
+}
+
+int bdg_graph_edges_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
+                        bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (!d_n_edges || (n && !d_ranks) || (cap && !d_out)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bdg_graph_launch(ctx, d_ranks, n, thr, qgram_T, d_out, cap, d_n_edges);
+}
+
+int bdg_graph_edges(bdg_ctx* ctx, const uint32_t* ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
+                    bdg_edge* out, uint64_t cap, uint64_t* n_edges)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (!n_edges || (n && !ranks) || (cap && !out)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    *n_edges = 0;
+    if (n < 2) return BDG_OK;
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> srt(ranks, ranks + n);
+    std::sort(srt.begin(), srt.end());
+    for (uint32_t i = 1; i < n; ++i)
+        if (srt[i] == srt[i - 1]) return bdg_fail(ctx, BDG_E_ARG, "ranks must be distinct");
+    int rc;
+    hipStream_t st = ctx->stream;
+    if ((rc = bdg_reserve(ctx, ctx->g_tmp0, sizeof(uint32_t) * (size_t)n))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->g_cnt, 64))) return rc;
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(ctx->g_tmp0.p, srt.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+    uint64_t dcap = std::max<uint64_t>(cap, 4ull * n + 1024);
+    std::vector<bdg_edge> all;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = bdg_reserve(ctx, ctx->g_tmp1, sizeof(bdg_edge) * dcap))) return rc;
+        rc = bdg_graph_launch(ctx, static_cast<const uint32_t*>(ctx->g_tmp0.p), n, thr, qgram_T,
+                              static_cast<bdg_edge*>(ctx->g_tmp1.p), dcap, static_cast<uint64_t*>(ctx->g_cnt.p));
+        if (rc) return rc;
+        uint64_t total = 0;
+        BDG_HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->g_cnt.p, 8, hipMemcpyDeviceToHost, st));
+        BDG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (total > dcap) { dcap = total; continue; }
+        all.resize(total);
+        if (total) BDG_HIP_TRY(ctx, hipMemcpy(all.data(), ctx->g_tmp1.p, sizeof(bdg_edge) * total, hipMemcpyDeviceToHost));
+        *n_edges = total;
+        break;
+    }
+    std::sort(all.begin(), all.end(), [](const bdg_edge& x, const bdg_edge& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+    const uint64_t w = std::min<uint64_t>(cap, all.size());
+    if (w) memcpy(out, all.data(), sizeof(bdg_edge) * w);
+    if (all.size() > cap) return bdg_fail(ctx, BDG_E_CAPACITY, "edge capacity too small");
+    return BDG_OK;
+}
+
+}  // extern "C"

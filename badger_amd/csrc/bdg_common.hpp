@@ -1,0 +1,95 @@
+// Shared host-side plumbing of libbadger_hip.so: context, error handling,
+// per-kernel HIP-event timing, grow-only device workspaces.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/badger_hip.h"
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t bytes = 0;
+};
+
+struct KTimer {
+    std::string name;
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct bdg_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool profiling = false;
+    std::vector<KTimer> timers;
+    std::vector<hipEvent_t> event_pool;
+
+    // ---- extraction workspace (extract_kernels.hip)
+    DevBuf x_lut;        // k-mer LUT (1 KiB) + byte-class table (2 KiB)
+    DevBuf x_polyt;      // int32 [2n]
+    DevBuf x_keys;       // uint64 [4n]  relaxed[2n] | strict[2n]
+    DevBuf x_hits;       // uint64 [hits_cap]
+    DevBuf x_counters;   // uint64 [8]
+    uint64_t x_hits_cap = 0;
+    void* x_counters_host = nullptr;   // pinned mirror
+    // host-buffer staging
+    DevBuf s_in0, s_in1, s_out0;
+
+    // ---- whitelist index (nearest_kernels.hip)
+    DevBuf w_sorted;     // uint32 [nw] ranks ascending
+    DevBuf w_orig;       // uint32 [nw] caller index of sorted entry
+    DevBuf w_prefix;     // uint32 [2^pbits + 1] offsets by top bits
+    DevBuf w_bitmap;     // uint32 [2^bbits / 32] membership of top bbits
+    uint32_t w_n = 0;
+    int w_pbits = 0, w_bbits = 0;
+    bool w_identity = false;
+    int n16_algo = 0;
+    DevBuf n_list;       // uint32 [nq] level-2 query list
+    DevBuf n_counters;   // uint32 [4]
+
+    // ---- graph workspace (graph_kernels.hip)
+    int graph_algo = 0;
+    DevBuf g_sig;        // uint32 [n] letter-count signatures
+    DevBuf g_tmp0, g_tmp1, g_cnt;
+};
+
+#define BDG_HIP_TRY(ctx, expr)                                                           \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+            return e_ == hipErrorOutOfMemory ? BDG_E_NOMEM : BDG_E_HIP;                  \
+        }                                                                                \
+    } while (0)
+
+// Grow-only device buffer.
+int bdg_reserve(bdg_ctx* ctx, DevBuf& b, size_t bytes);
+
+// Event-bracketed launch bookkeeping.
+int  bdg_timer_id(bdg_ctx* ctx, const char* name);
+void bdg_timer_begin(bdg_ctx* ctx, int id);
+void bdg_timer_end(bdg_ctx* ctx, int id);
+
+struct ScopedKernelTimer {
+    bdg_ctx* ctx; int id;
+    ScopedKernelTimer(bdg_ctx* c, const char* name) : ctx(c), id(-1) {
+        if (c->profiling) { id = bdg_timer_id(c, name); bdg_timer_begin(c, id); }
+    }
+    ~ScopedKernelTimer() { if (id >= 0) bdg_timer_end(ctx, id); }
+};
+
+static inline int bdg_fail(bdg_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}

@@ -1,0 +1,594 @@
+// K1: per-read barcode extraction on gfx950.
+//
+// Replaces TenXBarcodeExtractor.find_barcode_umi (reference barcode_callers.py:165-229)
+// and everything under it: find_polyt_start (barcode_extraction/common.py:10-31),
+// reverese_complement (:34-39), KmerIndexer.get_occurrences over [R1]
+// (kmer_indexer.py:49-75), detect_exact_positions (:85-114) and the SSW local
+// alignment behind align_pattern_ssw (:42-51).
+//
+// Three launches per batch, no host round trip in between:
+//   k_scan_reads     one wave per read, 16 B/lane coalesced loads straight from the
+//                    ASCII buffer: polyT start of both strands (the reverse strand is
+//                    derived from the same bytes: T-windows of the reverse complement
+//                    are A-windows of the read) and every R1 6-mer hit of both strands
+//                    (4096-entry 2-bit LUT in LDS), appended to a window queue with one
+//                    wave-aggregated atomic per kilobase.
+//   k_sw_windows     one lane per queued window: 22 x <=39 Smith-Waterman in registers
+//                    (22 row registers, the pattern is a compile-time constant so a
+//                    column costs one 22-bit equality mask), SSW's end-cell tie rule
+//                    folded into a single running max over packed (score,col,row) keys;
+//                    per read-strand winner by 64-bit atomicMax on (score, first hit).
+//   k_finalize_reads one lane per read: delta checks, reverse pass for strict hits,
+//                    polyT re-search, barcode/UMI slicing, strand choice, 32-byte record.
+//
+// Integer-only; bit-exact to oracle/badger_oracle.c.
+#include "bdg_common.hpp"
+
+namespace {
+
+constexpr int R1_LEN = 22;
+constexpr char R1[R1_LEN + 1] = "CTACACGACGCTCTTCCGATCT";   // barcode_callers.py:154
+constexpr int KMER = 6;
+constexpr int BC_LEN = 16;
+
+// internal base code = (ascii >> 1) & 3 : A0 C1 T2 G3 ; complement = code ^ 2
+constexpr uint32_t icode(char c) { return (uint32_t(c) >> 1) & 3u; }
+constexpr uint32_t eq_mask(uint32_t code)
+{
+    uint32_t m = 0;
+    for (int i = 0; i < R1_LEN; ++i) if (icode(R1[i]) == code) m |= 1u << i;
+    return m;
+}
+constexpr uint32_t EQ0 = eq_mask(0), EQ1 = eq_mask(1), EQ2 = eq_mask(2), EQ3 = eq_mask(3);
+
+constexpr int KEY_SHIFT = 11;                 // score | (63-col) << 5 | (31-row)
+constexpr int32_t ONE = 1 << KEY_SHIFT;
+
+enum { C_NHITS = 0, C_BADREAD = 1, C_NWINDOWS = 2 };
+
+constexpr int READS_PER_BLOCK = 32;
+
+__device__ __forceinline__ uint32_t range_mask16(int64_t lo, int64_t hi)
+{
+    int l = lo < 0 ? 0 : (lo > 16 ? 16 : (int)lo);
+    int h = hi < 0 ? 0 : (hi > 16 ? 16 : (int)hi);
+    return h > l ? (((1u << h) - 1u) & ~((1u << l) - 1u)) : 0u;
+}
+
+// ---------------------------------------------------------------------------
+// k_scan_reads
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
+                  const uint64_t* __restrict__ off, uint32_t n,
+                  const uint32_t* __restrict__ tables,
+                  int32_t* __restrict__ polyt,
+                  uint64_t* __restrict__ hits, uint64_t hits_cap,
+                  unsigned long long* __restrict__ counters)
+{
+    __shared__ uint32_t s_kmer[256];     // 4096 x 2 bits: bit0 R1 6-mer, bit1 reverse-complement of one
+    __shared__ uint2 s_cls[256];         // byte -> {isT | isA<<16, isN | bad<<16}
+    const int tid = threadIdx.x;
+    s_kmer[tid] = tables[tid];
+    s_cls[tid] = reinterpret_cast<const uint2*>(tables + 256)[tid];
+    __syncthreads();
+
+    const int lane = tid & 63, wv = tid >> 6;
+    const uint64_t r_begin = (uint64_t)blockIdx.x * READS_PER_BLOCK;
+    const uint64_t r_end = r_begin + READS_PER_BLOCK < n ? r_begin + READS_PER_BLOCK : n;
+
+    for (uint64_t r = r_begin + wv; r < r_end; r += 4) {
+        const uint64_t s = off[r];
+        const int64_t L = (int64_t)(off[r + 1] - s);
+        const uint64_t base_al = s & ~15ull;
+        const int64_t span = (int64_t)(s - base_al) + L;
+        const int niter = L > 0 ? (int)((span + 1007) / 1008) : 0;
+        int32_t ptF = -1, ptR = -1;
+        bool foundF = false;
+
+        for (int t = 0; t < niter; ++t) {
+            const uint64_t g0 = base_al + (uint64_t)(t * 63 + lane) * 16ull;
+            const int64_t p0 = (int64_t)g0 - (int64_t)s;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (g0 < total_rounded && p0 < L) v = *reinterpret_cast<const uint4*>(bases + g0);
+            const uint32_t words[4] = { v.x, v.y, v.z, v.w };
+            uint32_t ta = 0, nb = 0, codes = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t b = (words[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                const uint2 c = s_cls[b];
+                ta |= c.x << k;
+                nb |= c.y << k;
+                codes |= ((b >> 1) & 3u) << (2 * k);
+            }
+            const uint32_t rm = range_mask16(-p0, L - p0);
+            const uint32_t T = ta & 0xFFFFu & rm;
+            const uint32_t A = (ta >> 16) & rm;
+            const uint32_t N = ((nb & 0xFFFFu) | ~rm) & 0xFFFFu;    // out-of-read behaves like N
+            const uint32_t bad = (nb >> 16) & rm;
+
+            const uint32_t TA1 = __shfl_down(T | (A << 16), 1);
+            const uint32_t N1 = __shfl_down(N, 1);
+            const uint32_t codes1 = __shfl_down(codes, 1);
+            const uint32_t T32 = T | (TA1 << 16);
+            const uint32_t A32 = A | (TA1 & 0xFFFF0000u);
+            const uint32_t N32 = N | (N1 << 16);
+            const bool worker = lane < 63;       // lane 63 only feeds lane 62; its bytes are lane 0 of the next step
+
+            uint32_t qT = 0, qA = 0, hitF = 0, hitR = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t cT = __popc((T32 >> k) & 0xFFFFu);
+                const uint32_t cA = __popc((A32 >> k) & 0xFFFFu);
+                qT |= (cT >= 12u ? 1u : 0u) << k;              // int(16 * 0.75), common.py:11
+                qA |= (cA >= 12u ? 1u : 0u) << k;
+                const uint32_t key = __builtin_amdgcn_alignbit(codes1, codes, 2 * k) & 0xFFFu;
+                uint32_t f = (s_kmer[key >> 4] >> ((key & 15u) * 2u)) & 3u;
+                f = ((N32 >> k) & 0x3Fu) == 0u ? f : 0u;
+                hitF |= (f & 1u) << k;
+                hitR |= (f >> 1) << k;
+            }
+            // window starts allowed by the loop bounds of common.py:17,28
+            qT &= range_mask16(-p0, L - 16 - p0);              // 0 <= p < L-16
+            qA &= range_mask16(1 - p0, L - 16 - p0 + 1);       // reverse strand: 0 <= L-16-p < L-16
+            if (!worker) { qT = 0; qA = 0; hitF = 0; hitR = 0; }
+
+            if (!foundF) {
+                const unsigned long long bal = __ballot(qT != 0);
+                if (bal) {
+                    const int src = __builtin_ctzll(bal);
+                    int32_t val = 0;
+                    if (lane == src) {
+                        const int k = __builtin_ctz(qT);
+                        const uint32_t tt = (T32 & (T32 >> 1) & (T32 >> 2)) >> k;     // 'TTT' starts, common.py:31
+                        val = (int32_t)(p0 + k + (tt ? __builtin_ctz(tt) : 0));
+                    }
+                    ptF = __shfl(val, src);
+                    foundF = true;
+                }
+            }
+            {
+                const unsigned long long bal = __ballot(qA != 0);
+                if (bal) {
+                    const int src = 63 - __builtin_clzll(bal);
+                    int32_t val = 0;
+                    if (lane == src) {
+                        const int k = 31 - __builtin_clz(qA);
+                        const uint32_t aa = A32 & (A32 >> 1) & (A32 >> 2);
+                        const uint32_t m = aa & ((1u << (k + 14)) - 1u);
+                        const int j = m ? 31 - __builtin_clz(m) : k + 13;
+                        val = (int32_t)((L - 16 - (p0 + k)) + (k + 13 - j));
+                    }
+                    ptR = __shfl(val, src);
+                }
+            }
+            if (__ballot(bad != 0 && worker)) {
+                if (bad != 0 && worker) atomicMin(&counters[C_BADREAD], (unsigned long long)r);
+            }
+            // append the hits of this step to the window queue
+            const uint32_t cnt = __popc(hitF) + __popc(hitR);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            if (total) {
+                unsigned long long base = 0;
+                if (lane == 63) base = atomicAdd(&counters[C_NHITS], (unsigned long long)total);
+                base = __shfl(base, 63);
+                unsigned long long idx = base + incl - cnt;
+                uint32_t m = hitF;
+                while (m) {
+                    const int k = __builtin_ctz(m); m &= m - 1;
+                    const uint64_t pos = (uint64_t)(p0 + k);
+                    if (idx < hits_cap) hits[idx] = r | ((pos << 1) << 32);
+                    ++idx;
+                }
+                m = hitR;
+                while (m) {
+                    const int k = __builtin_ctz(m); m &= m - 1;
+                    const uint64_t pos = (uint64_t)(L - KMER - (p0 + k));
+                    if (idx < hits_cap) hits[idx] = r | (((pos << 1) | 1ull) << 32);
+                    ++idx;
+                }
+            }
+        }
+        if (lane == 0) { polyt[2 * r] = ptF; polyt[2 * r + 1] = ptR; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Window loader: 40 characters of strand `strand` starting at strand position x0,
+// walking in direction dir, as raw forward bytes (char k = byte k of w[]).
+// Characters outside the read are garbage; the caller masks them (k >= n).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_block(const uint8_t* __restrict__ bases, uint64_t total_rounded,
+                                           uint64_t rs, int64_t L, int strand, int64_t x0, int dir,
+                                           uint32_t (&w)[10])
+{
+    const int64_t f0 = strand ? (L - 1 - x0) : x0;
+    const bool asc = (dir > 0) != (strand != 0);
+    const int64_t a = (int64_t)rs + (asc ? f0 : f0 - 39);
+    const int64_t a_al = a & ~3ll;
+    const uint32_t sh = (uint32_t)(a - a_al);
+    uint32_t t[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int64_t idx = a_al + 4 * i;
+        t[i] = (idx >= 0 && (uint64_t)idx + 4 <= total_rounded)
+                   ? *reinterpret_cast<const uint32_t*>(bases + idx) : 0u;
+    }
+    uint32_t u[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) u[i] = __builtin_amdgcn_alignbyte(t[i + 1], t[i], sh);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) w[i] = asc ? u[i] : __builtin_bswap32(u[9 - i]);
+}
+
+__device__ __forceinline__ bool block_has_N(const uint32_t (&w)[10])
+{
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t x = w[i] ^ 0x4E4E4E4Eu;
+        any |= (x - 0x01010101u) & ~x & 0x80808080u;
+    }
+    return any != 0;
+}
+
+// ---------------------------------------------------------------------------
+// Smith-Waterman of R1 (rows) against the first n characters of the block
+// (columns), +1/-1/-1 linear gaps, N scores 0.  Returns the maximum over all cells of
+//   (H << 11) | (63 - col) << 5 | (31 - row)
+// i.e. the best score, its first column, and the smallest row in that column --
+// the end cell SSW reports (see oracle/badger_oracle.c, sw_scan).
+// REV: rows are pattern[end_read - r] (reverse pass of ssw_align).
+// ---------------------------------------------------------------------------
+template <bool WITH_N, bool REV>
+__device__ __forceinline__ uint32_t sw_block(uint32_t (&w)[10], int n, uint32_t comp, int end_read)
+{
+    int32_t hs[R1_LEN];
+#pragma unroll
+    for (int i = 0; i < R1_LEN; ++i) hs[i] = 0;
+    int32_t acc = 0;
+#pragma nounroll
+    for (int d = 0; d < 10; ++d) {
+        const uint32_t cur = w[0];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = d * 4 + b;
+            const uint32_t c = (cur >> (8 * b)) & 0xFFu;
+            const uint32_t code = ((c >> 1) & 3u) ^ (comp << 1);
+            uint32_t e = (code & 2u) ? ((code & 1u) ? EQ3 : EQ2) : ((code & 1u) ? EQ1 : EQ0);
+            const bool live = j < n;
+            const bool isN = WITH_N && (c == (uint32_t)'N');
+            e = (live && !isN) ? e : 0u;
+            if (REV) e = __brev(e) >> (31 - end_read);
+            const int32_t dN = (WITH_N && isN && live) ? ONE : 0;
+            const int32_t cj = (63 - j) << 5;
+            int32_t diag_t = -ONE;       // H(-1, j-1) - 1
+            int32_t up = 0;              // H(i-1, j)
+            int32_t keyprev = 0;
+#pragma unroll
+            for (int i = 0; i < R1_LEN; ++i) {
+                const int32_t tl = hs[i] - ONE;                                  // H(i, j-1) - 1
+                int32_t dg = (int32_t)(((e >> i) & 1u) << (KEY_SHIFT + 1)) + diag_t;   // H(i-1,j-1) +/- 1
+                if (WITH_N) dg += dN;
+                const int32_t tu = up - ONE;                                     // H(i-1, j) - 1
+                int32_t h = max(max(dg, tl), tu);
+                h = max(h, 0);
+                diag_t = tl;
+                hs[i] = h;
+                up = h;
+                const int32_t key = h | cj | (31 - i);
+                if (i & 1) acc = max(max(acc, keyprev), key);
+                else keyprev = key;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w[i] = w[i + 1];
+    }
+    return (uint32_t)acc;
+}
+
+__device__ __forceinline__ uint32_t sw_window(uint32_t (&w)[10], int n, uint32_t comp, bool anyN)
+{
+    return anyN ? sw_block<true, false>(w, n, comp, 0) : sw_block<false, false>(w, n, comp, 0);
+}
+
+__device__ __forceinline__ uint64_t make_key(uint32_t acc, uint32_t pos)
+{
+    const uint64_t score = acc >> KEY_SHIFT;
+    const uint64_t end_ref = 63u - ((acc >> 5) & 63u);
+    const uint64_t end_read = 31u - (acc & 31u);
+    return (score << 43) | ((uint64_t)(0xFFFFFFFFu - pos) << 11) | (end_ref << 5) | end_read;
+}
+
+// ---------------------------------------------------------------------------
+// k_sw_windows: one lane per queued hit (detect_exact_positions loop body,
+// barcode_extraction/common.py:91-103, for the relaxed and the strict search at once).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_sw_windows(const uint8_t* __restrict__ bases, uint64_t total_rounded,
+                  const uint64_t* __restrict__ off, uint32_t n_reads,
+                  const int32_t* __restrict__ polyt,
+                  const uint64_t* __restrict__ hits, uint64_t hits_cap,
+                  unsigned long long* __restrict__ counters,
+                  unsigned long long* __restrict__ keys)
+{
+    unsigned long long nh = counters[C_NHITS];
+    if (nh > hits_cap) nh = hits_cap;
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
+    uint32_t nwin = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256ull + (threadIdx.x & ~63); base < nh; base += stride) {
+        const uint64_t g = base + lane;
+        const bool active = g < nh;
+        uint64_t rs = 0; int64_t L = 0; uint32_t r = 0, strand = 0; int64_t pos = 0; int32_t pt = -1;
+        if (active) {
+            const uint64_t ent = hits[g];
+            r = (uint32_t)ent;
+            const uint32_t ps = (uint32_t)(ent >> 32);
+            strand = ps & 1u; pos = ps >> 1;
+            rs = off[r]; L = (int64_t)(off[r + 1] - rs);
+            pt = polyt[2 * (uint64_t)r + strand];
+        }
+        const int64_t ws = pos - (R1_LEN - KMER) > 0 ? pos - (R1_LEN - KMER) : 0;       // common.py:96-97
+        const int64_t we = pos + R1_LEN + 1 < L ? pos + R1_LEN + 1 : L;                 // :98-99 (strict: end = len)
+        const int nfull = active ? (int)(we - ws) : 0;
+        uint32_t w[10];
+        load_block(bases, total_rounded, rs, L, (int)strand, ws, +1, w);
+        const bool anyN = __ballot(active && block_has_N(w)) != 0;
+        uint32_t w2[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) w2[i] = w[i];
+        const uint32_t acc = sw_window(w, nfull, strand, anyN);
+        const uint32_t score = acc >> KEY_SHIFT;
+        const uint64_t key = make_key(acc, (uint32_t)pos);
+        nwin += active ? 1u : 0u;
+        if (active && score >= 17u)                                                      // barcode_callers.py:200
+            atomicMax(&keys[2ull * n_reads + 2ull * r + strand], (unsigned long long)key);
+        // relaxed search (barcode_callers.py:186-192): hits inside sequence[0:polyT+1], end = polyT+1
+        const bool relaxed = active && pt >= 0 && pos + KMER <= (int64_t)pt + 1;
+        const int64_t we_r = pos + R1_LEN + 1 < (int64_t)pt + 1 ? pos + R1_LEN + 1 : (int64_t)pt + 1;
+        const bool clipped = relaxed && we_r < we;
+        uint64_t key_r = key; uint32_t score_r = score;
+        if (__ballot(clipped)) {
+            const uint32_t acc2 = sw_window(w2, clipped ? (int)(we_r - ws) : 0, strand, anyN);
+            if (clipped) { key_r = make_key(acc2, (uint32_t)pos); score_r = acc2 >> KEY_SHIFT; nwin += 1u; }
+        }
+        if (relaxed && score_r >= 9u)                                                    // barcode_callers.py:191
+            atomicMax(&keys[2ull * r + strand], (unsigned long long)key_r);
+    }
+    // window count (statistics only)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nwin += __shfl_xor(nwin, d);
+    if (lane == 0 && nwin) atomicAdd(&counters[C_NWINDOWS], (unsigned long long)nwin);
+}
+
+// ---------------------------------------------------------------------------
+// k_finalize_reads
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t strand_byte(const uint8_t* __restrict__ rd, int64_t L, int strand, int64_t x)
+{
+    // character x of the strand, returned as the FORWARD byte (complement applied by the caller's test)
+    return rd[strand ? (L - 1 - x) : x];
+}
+
+struct StrandRes { int32_t valid, polyT, r1, score, bc_start, umi_start, umi_end; };
+
+__device__ StrandRes finalize_strand(const uint8_t* __restrict__ bases, uint64_t total_rounded,
+                                     uint64_t rs, int64_t L, int strand, int32_t pt,
+                                     uint64_t kr, uint64_t ks, int umi_len, bool active)
+{
+    StrandRes res = { 0, pt, -1, 0, -1, -1, -1 };
+    bool found = false;
+    int64_t r1_end = 0; int32_t r1_score = 0;
+    if (active && pt != -1 && kr != 0) {                       // relaxed: min_score 9, end_delta 4
+        const int64_t pos = (int64_t)(0xFFFFFFFFu - (uint32_t)(kr >> 11));
+        const int end_ref = (int)((kr >> 5) & 63), end_read = (int)(kr & 31);
+        const int64_t ws = pos - (R1_LEN - KMER) > 0 ? pos - (R1_LEN - KMER) : 0;
+        const int leftover = R1_LEN - end_read - 1;            // common.py:113
+        if (leftover <= 4) { found = true; r1_end = ws + end_ref + leftover; r1_score = (int32_t)(kr >> 43); }
+    }
+    // strict: min_score 17, start_delta 1, end_delta 1 -> needs read_start (reverse pass)
+    int end_ref_s = 0, end_read_s = 0; int64_t ws_s = 0;
+    bool need_rev = false;
+    if (active && !found && ks != 0) {
+        const int64_t pos = (int64_t)(0xFFFFFFFFu - (uint32_t)(ks >> 11));
+        end_ref_s = (int)((ks >> 5) & 63); end_read_s = (int)(ks & 31);
+        ws_s = pos - (R1_LEN - KMER) > 0 ? pos - (R1_LEN - KMER) : 0;
+        need_rev = (R1_LEN - end_read_s - 1) <= 1;             // common.py:110-111
+    }
+    if (__ballot(need_rev)) {
+        uint32_t w[10];
+        load_block(bases, total_rounded, rs, L, strand, ws_s + end_ref_s, -1, w);
+        const bool anyN = __ballot(need_rev && block_has_N(w)) != 0;
+        const int ncol = need_rev ? end_ref_s + 1 : 0;
+        const uint32_t acc = anyN ? sw_block<true, true>(w, ncol, (uint32_t)strand, end_read_s)
+                                  : sw_block<false, true>(w, ncol, (uint32_t)strand, end_read_s);
+        if (need_rev) {
+            const int rr = 31 - (int)(acc & 31u);
+            const int read_begin = end_read_s - rr;
+            if (read_begin <= 1) {                             // common.py:108-109
+                found = true;
+                r1_end = ws_s + end_ref_s + (R1_LEN - end_read_s - 1);
+                r1_score = (int32_t)(ks >> 43);
+            }
+        }
+    }
+    if (!found) return res;                                                        // barcode_callers.py:204-205
+    if (pt != -1 && (int64_t)pt - r1_end < BC_LEN) return res;                     // :208-209
+    const uint8_t* rd = bases + rs;
+    int64_t polyt = pt;
+    if (pt == -1 || (int64_t)pt - r1_end > BC_LEN + umi_len + 10) {                // :211-218
+        const int64_t presumable = r1_end + BC_LEN + umi_len;
+        const int64_t ss = presumable - 4;
+        const int64_t se = presumable + 10 < L ? presumable + 10 : L;
+        const int64_t sl = (ss < L && se > ss) ? se - ss : 0;
+        polyt = -1;
+        const uint32_t tchar = strand ? (uint32_t)'A' : (uint32_t)'T';
+        int run = 0;
+        for (int64_t x = 0; x < sl; ++x) {          // first all-T window of 5 starting at i < sl-5
+            run = strand_byte(rd, L, strand, ss + x) == tchar ? run + 1 : 0;
+            const int64_t i = x - 4;
+            if (run >= 5 && i < sl - 5) { polyt = ss + i; break; }
+        }
+    }
+    const int64_t barcode_start = r1_end + 1;
+    const int64_t umi_start = r1_end + BC_LEN + 1;
+    int64_t umi_end = polyt - 1;
+    if (umi_end - umi_start <= 5) umi_end = umi_start + umi_len - 1;               // :226-227
+    res.valid = 1; res.polyT = (int32_t)polyt; res.r1 = (int32_t)r1_end; res.score = r1_score;
+    res.bc_start = (int32_t)barcode_start; res.umi_start = (int32_t)umi_start; res.umi_end = (int32_t)(umi_end + 1);
+    return res;
+}
+
+__global__ __launch_bounds__(256)
+void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
+                      const uint64_t* __restrict__ off, uint32_t n,
+                      const int32_t* __restrict__ polyt,
+                      const unsigned long long* __restrict__ keys,
+                      uint32_t umi_len, bdg_extract_rec* __restrict__ out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256ull + threadIdx.x;
+    const bool active = r < n;
+    uint64_t rs = 0; int64_t L = 0;
+    int32_t ptF = -1, ptR = -1; uint64_t krF = 0, krR = 0, ksF = 0, ksR = 0;
+    if (active) {
+        rs = off[r]; L = (int64_t)(off[r + 1] - rs);
+        ptF = polyt[2 * r]; ptR = polyt[2 * r + 1];
+        krF = keys[2 * r]; krR = keys[2 * r + 1];
+        ksF = keys[2ull * n + 2 * r]; ksR = keys[2ull * n + 2 * r + 1];
+    }
+    const StrandRes f = finalize_strand(bases, total_rounded, rs, L, 0, ptF, krF, ksF, (int)umi_len, active);
+    const StrandRes v = finalize_strand(bases, total_rounded, rs, L, 1, ptR, krR, ksR, (int)umi_len, active);
+    if (!active) return;
+    bool use_rev;
+    if (v.valid && f.valid) use_rev = !(f.score > v.score);          // barcode_callers.py:175-176
+    else use_rev = v.valid != 0;                                     // :177-179
+    const StrandRes c = use_rev ? v : f;
+    bdg_extract_rec rec;
+    rec.polyT = c.polyT; rec.r1_end = c.r1; rec.bc_start = c.bc_start;
+    rec.umi_start = c.umi_start; rec.umi_end = c.umi_end;
+    rec.bc_rank = 0;
+    rec.r1_score = (int8_t)c.score;
+    rec.strand = c.polyT != -1 ? (use_rev ? -1 : 1) : 0;             // :167-168,172-173
+    rec.valid = (uint8_t)c.valid;
+    rec.flags = use_rev ? BDG_FLAG_REV : 0;
+    rec.reserved = 0;
+    if (c.valid && (int64_t)c.bc_start + BC_LEN <= L) {
+        const uint8_t* rd = bases + rs;
+        uint32_t rk = 0; bool ok = true;
+        for (int i = 0; i < BC_LEN; ++i) {
+            const uint32_t b = strand_byte(rd, L, use_rev ? 1 : 0, (int64_t)c.bc_start + i);
+            uint32_t cd;
+            switch (b) {                                             // rank codes A0 C1 G2 T3 (common.py:11-14)
+            case 'A': cd = 0; break; case 'C': cd = 1; break;
+            case 'G': cd = 2; break; case 'T': cd = 3; break;
+            default: cd = 0; ok = false;
+            }
+            if (use_rev) cd = 3u - cd;
+            rk |= cd << (2 * i);
+        }
+        if (ok) { rec.bc_rank = rk; rec.flags |= BDG_FLAG_RANK_OK; }
+    }
+    out[r] = rec;
+}
+
+// host-side tables -------------------------------------------------------------
+void build_tables(uint32_t* t /* 256 + 512 words */)
+{
+    memset(t, 0, sizeof(uint32_t) * 768);
+    auto comp = [](char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; };
+    for (int q = 0; q + KMER <= R1_LEN; ++q) {
+        uint32_t kf = 0, kr = 0;
+        for (int u = 0; u < KMER; ++u) {
+            kf |= icode(R1[q + u]) << (2 * u);
+            kr |= icode(comp(R1[q + KMER - 1 - u])) << (2 * u);
+        }
+        t[kf >> 4] |= 1u << ((kf & 15u) * 2u);
+        t[kr >> 4] |= 2u << ((kr & 15u) * 2u);
+    }
+    for (int b = 0; b < 256; ++b) {
+        const bool isA = b == 'A', isC = b == 'C', isG = b == 'G', isT = b == 'T', isN = b == 'N';
+        const bool badb = !(isA || isC || isG || isT || isN);
+        t[256 + 2 * b] = (isT ? 1u : 0u) | (isA ? 1u << 16 : 0u);
+        t[256 + 2 * b + 1] = (isN ? 1u : 0u) | (badb ? 1u << 16 : 0u);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host entry (called from bdg_abi.cpp)
+// ---------------------------------------------------------------------------
+int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_off, uint32_t n,
+                       uint64_t total_bytes, uint32_t umi_len, bdg_extract_rec* d_out)
+{
+    if (n == 0) return BDG_OK;
+    if (reinterpret_cast<uintptr_t>(d_bases) & 15u) return bdg_fail(ctx, BDG_E_ARG, "d_bases must be 16-byte aligned");
+    if (total_bytes >= (1ull << 62)) return bdg_fail(ctx, BDG_E_ARG, "total_bytes too large");
+    int rc;
+    if (!ctx->x_lut.p) {
+        uint32_t t[768];
+        build_tables(t);
+        if ((rc = bdg_reserve(ctx, ctx->x_lut, sizeof(t)))) return rc;
+        BDG_HIP_TRY(ctx, hipMemcpy(ctx->x_lut.p, t, sizeof(t), hipMemcpyHostToDevice));
+    }
+    if ((rc = bdg_reserve(ctx, ctx->x_polyt, sizeof(int32_t) * 2ull * n))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->x_keys, sizeof(uint64_t) * 4ull * n))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->x_counters, 64))) return rc;
+    uint64_t want = total_bytes / 16 + 4096;
+    if (want < ctx->x_hits_cap) want = ctx->x_hits_cap;
+    if ((rc = bdg_reserve(ctx, ctx->x_hits, sizeof(uint64_t) * want))) return rc;
+    ctx->x_hits_cap = ctx->x_hits.bytes / sizeof(uint64_t);
+
+    hipStream_t st = ctx->stream;
+    const uint64_t total_rounded = (total_bytes + 15ull) & ~15ull;
+    auto* counters = static_cast<unsigned long long*>(ctx->x_counters.p);
+    BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, st));
+    BDG_HIP_TRY(ctx, hipMemsetAsync(counters + C_BADREAD, 0xFF, 8, st));
+    BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->x_keys.p, 0, sizeof(uint64_t) * 4ull * n, st));
+    {
+        ScopedKernelTimer tm(ctx, "k_scan_reads");
+        const uint32_t grid = (n + READS_PER_BLOCK - 1) / READS_PER_BLOCK;
+        hipLaunchKernelGGL(k_scan_reads, dim3(grid), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
+                           static_cast<const uint32_t*>(ctx->x_lut.p), static_cast<int32_t*>(ctx->x_polyt.p),
+                           static_cast<uint64_t*>(ctx->x_hits.p), ctx->x_hits_cap, counters);
+    }
+    {
+        ScopedKernelTimer tm(ctx, "k_sw_windows");
+        hipLaunchKernelGGL(k_sw_windows, dim3(256 * 8), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
+                           static_cast<const int32_t*>(ctx->x_polyt.p), static_cast<const uint64_t*>(ctx->x_hits.p),
+                           ctx->x_hits_cap, counters, static_cast<unsigned long long*>(ctx->x_keys.p));
+    }
+    {
+        ScopedKernelTimer tm(ctx, "k_finalize_reads");
+        hipLaunchKernelGGL(k_finalize_reads, dim3((n + 255) / 256), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
+                           static_cast<const int32_t*>(ctx->x_polyt.p),
+                           static_cast<const unsigned long long*>(ctx->x_keys.p), umi_len, d_out);
+    }
+    BDG_HIP_TRY(ctx, hipGetLastError());
+    return BDG_OK;
+}
+
+int bdg_extract_status_impl(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_windows)
+{
+    if (!ctx->x_counters.p) { if (bad_read) *bad_read = ~0ull; if (n_windows) *n_windows = 0; return BDG_OK; }
+    uint64_t c[8];
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(c, ctx->x_counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad_read) *bad_read = c[C_BADREAD];
+    if (n_windows) *n_windows = c[C_NWINDOWS];
+    if (c[C_NHITS] > ctx->x_hits_cap) {
+        const uint64_t want = c[C_NHITS] + 4096;
+        ctx->x_hits_cap = want;            // next launch reserves this much
+        return bdg_fail(ctx, BDG_E_CAPACITY, "window queue overflow: rerun the batch (workspace grown)");
+    }
+    if (c[C_BADREAD] != ~0ull)
+        return bdg_fail(ctx, BDG_E_BADBASE, "read " + std::to_string(c[C_BADREAD]) + " holds a byte outside 'ACGTN'");
+    return BDG_OK;
+}

@@ -1,0 +1,298 @@
+// K2: nearest whitelist barcode under Levenshtein distance (operator form of the loop
+// body of BarcodeGraph.postprocessing, reference barcode_graph.py:376-384, whose
+// distance is editdistance.eval on 16-character strings).
+//
+// Two device paths with identical results (ties -> lowest caller index, tie count):
+//   scan   k_nearest_scan: exhaustive.  One query per lane (its four 16-bit match
+//          vectors live in registers), whitelist tiles staged in LDS and broadcast to
+//          the wave, Myers/Hyyro bit-vector distance per pair.  Any max_ed.
+//   probe  k_nearest_l01 + k_nearest_l2: for max_ed <= 2 the candidates are enumerated
+//          instead of the whitelist: the query itself, its 48 substitution neighbours,
+//          and -- one wave per still-unmatched query -- the 1080 double substitutions
+//          and 1024 delete+insert variants, each looked up in the sorted whitelist
+//          through an L2-resident prefix directory behind a membership bitmap.
+//          Equal-length strings at distance 1 differ by one substitution; at distance 2
+//          by two substitutions or one deletion plus one insertion, so the enumeration
+//          is exhaustive.
+#include "bdg_common.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+namespace {
+
+constexpr uint32_t NONE_IDX = 0xFFFFFFFFu;
+
+struct WlIndex {
+    const uint32_t* sorted;
+    const uint32_t* orig;
+    const uint32_t* prefix;
+    const uint32_t* bitmap;
+    uint32_t n;
+    int pshift;     // 32 - pbits
+    int bshift;     // 32 - bbits
+};
+
+__device__ __forceinline__ bool wl_lookup(const WlIndex& ix, uint32_t key, uint32_t& orig)
+{
+    const uint32_t b = key >> ix.bshift;
+    if (!((ix.bitmap[b >> 5] >> (b & 31u)) & 1u)) return false;
+    const uint32_t p = key >> ix.pshift;
+    const uint32_t lo = ix.prefix[p], hi = ix.prefix[p + 1];
+    for (uint32_t k = lo; k < hi; ++k) {
+        const uint32_t v = ix.sorted[k];
+        if (v == key) { orig = ix.orig[k]; return true; }
+        if (v > key) break;
+    }
+    return false;
+}
+
+// ---- exhaustive scan -------------------------------------------------------
+constexpr int SCAN_TILE = 4096;
+
+__global__ __launch_bounds__(256)
+void k_nearest_scan(const uint32_t* __restrict__ q, const uint32_t* __restrict__ qlist, uint32_t nq_host,
+                    const uint32_t* __restrict__ d_nq,
+                    const uint32_t* __restrict__ wl_sorted, const uint32_t* __restrict__ wl_orig, uint32_t nw,
+                    uint32_t max_ed, uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed,
+                    uint16_t* __restrict__ n_ties)
+{
+    __shared__ uint32_t s_rank[SCAN_TILE];
+    __shared__ uint32_t s_orig[SCAN_TILE];
+    const uint32_t nq = d_nq ? *d_nq : nq_host;          // list length may live on the device (overflow list)
+  for (uint32_t slot0 = blockIdx.x * 256u; slot0 < nq; slot0 += gridDim.x * 256u) {
+    const uint32_t slot = slot0 + threadIdx.x;
+    const bool active = slot < nq;
+    const uint32_t qi = active ? (qlist ? qlist[slot] : slot) : 0u;
+    const uint32_t qq = active ? q[qi] : 0u;
+    uint32_t peq[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t c = (qq >> (2 * i)) & 3u;
+        peq[0] |= (c == 0u ? 1u : 0u) << i; peq[1] |= (c == 1u ? 1u : 0u) << i;
+        peq[2] |= (c == 2u ? 1u : 0u) << i; peq[3] |= (c == 3u ? 1u : 0u) << i;
+    }
+    uint32_t best = 255u, bidx = NONE_IDX, ties = 0u;
+    for (uint32_t t0 = 0; t0 < nw; t0 += SCAN_TILE) {
+        const uint32_t tn = nw - t0 < (uint32_t)SCAN_TILE ? nw - t0 : (uint32_t)SCAN_TILE;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < tn; k += 256u) { s_rank[k] = wl_sorted[t0 + k]; s_orig[k] = wl_orig[t0 + k]; }
+        __syncthreads();
+        for (uint32_t k = 0; k < tn; ++k) {
+            const uint32_t t = __builtin_amdgcn_readfirstlane(s_rank[k]);
+            const uint32_t o = __builtin_amdgcn_readfirstlane(s_orig[k]);
+            uint32_t pv = 0xFFFFu, mv = 0u, score = 16u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t c = (t >> (2 * j)) & 3u;
+                const uint32_t eq = (c & 2u) ? ((c & 1u) ? peq[3] : peq[2]) : ((c & 1u) ? peq[1] : peq[0]);
+                const uint32_t xv = eq | mv;
+                const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+                uint32_t ph = mv | ~(xh | pv);
+                uint32_t mh = pv & xh;
+                score += (ph >> 15) & 1u;
+                score -= (mh >> 15) & 1u;
+                ph = (ph << 1) | 1u;
+                mh = mh << 1;
+                pv = mh | ~(xv | ph);
+                mv = ph & xv;
+            }
+            const bool better = score < best, same = score == best;
+            bidx = better ? o : ((same && o < bidx) ? o : bidx);
+            ties = better ? 1u : (same ? ties + 1u : ties);
+            best = better ? score : best;
+        }
+    }
+    if (active) {
+        if (best > max_ed) { best = 255u; bidx = NONE_IDX; ties = 0u; }
+        best_idx[qi] = bidx; best_ed[qi] = (uint8_t)best; n_ties[qi] = (uint16_t)(ties > 0xFFFFu ? 0xFFFFu : ties);
+    }
+  }
+}
+
+// ---- probe path, levels 0 and 1: one query per lane ---------------------------
+__global__ __launch_bounds__(256)
+void k_nearest_l01(const uint32_t* __restrict__ q, uint32_t nq, WlIndex ix, uint32_t max_ed,
+                   uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
+                   uint32_t* __restrict__ list2, uint32_t* __restrict__ counters)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nq) return;
+    const uint32_t qq = q[i];
+    uint32_t o = 0;
+    if (wl_lookup(ix, qq, o)) { best_idx[i] = o; best_ed[i] = 0; n_ties[i] = 1; return; }
+    if (max_ed >= 1u) {
+        uint32_t bidx = NONE_IDX, ties = 0;
+        for (int pos = 0; pos < 16; ++pos) {
+#pragma unroll
+            for (uint32_t x = 1; x < 4; ++x) {
+                if (wl_lookup(ix, qq ^ (x << (2 * pos)), o)) { ++ties; bidx = o < bidx ? o : bidx; }
+            }
+        }
+        if (ties) { best_idx[i] = bidx; best_ed[i] = 1; n_ties[i] = (uint16_t)ties; return; }
+    }
+    if (max_ed >= 2u) { list2[atomicAdd(&counters[0], 1u)] = i; return; }
+    best_idx[i] = NONE_IDX; best_ed[i] = 255; n_ties[i] = 0;
+}
+
+// ---- probe path, level 2: one wave per unmatched query ------------------------
+__device__ __forceinline__ uint32_t low_mask(int bases) { return bases >= 16 ? 0xFFFFFFFFu : ((1u << (2 * bases)) - 1u); }
+
+__global__ __launch_bounds__(256)
+void k_nearest_l2(const uint32_t* __restrict__ q, const uint32_t* __restrict__ list2,
+                  const uint32_t* counters, WlIndex ix,
+                  uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
+                  uint32_t* __restrict__ list3, uint32_t* counters_out)
+{
+    const uint32_t n2 = counters[0];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * 4u;
+    for (uint32_t s = wave; s < n2; s += nwaves) {
+        const uint32_t qi = list2[s];
+        const uint32_t qq = q[qi];
+        uint32_t found[4] = { 0, 0, 0, 0 }; int nf = 0; bool overflow = false;
+        auto probe = [&](uint32_t cand) {
+            uint32_t o;
+            if (wl_lookup(ix, cand, o)) {
+                bool dup = false;
+                for (int k = 0; k < 4; ++k) dup |= (k < nf && found[k] == o);
+                if (!dup) { if (nf < 4) { found[0] = nf == 0 ? o : found[0]; found[1] = nf == 1 ? o : found[1];
+                                          found[2] = nf == 2 ? o : found[2]; found[3] = nf == 3 ? o : found[3]; ++nf; }
+                            else overflow = true; }
+            }
+        };
+        // (a) two substitutions: 120 position pairs x 9 letter pairs
+        for (int t = lane; t < 1080; t += 64) {
+            const int pi = t / 9, xy = t - pi * 9;
+            // unrank pair index -> (i<j): rows of decreasing length 15,14,...,1
+            int i = 0, rem = pi;
+            while (rem >= 15 - i) { rem -= 15 - i; ++i; }
+            const int j = i + 1 + rem;
+            const uint32_t x = 1u + (uint32_t)(xy / 3), y = 1u + (uint32_t)(xy % 3);
+            probe(qq ^ (x << (2 * i)) ^ (y << (2 * j)));
+        }
+        // (b) delete base i, insert letter c at slot sl of the 15-mer
+        for (int t = lane; t < 1024; t += 64) {
+            const int i = t >> 6, sl = (t >> 2) & 15; const uint32_t c = (uint32_t)t & 3u;
+            const uint32_t lm = low_mask(i);
+            const uint32_t d = (qq & lm) | ((qq >> 2) & ~lm);           // 15 bases (top slot is garbage-free: zero)
+            const uint32_t sm = low_mask(sl);
+            const uint32_t r = (d & sm) | (c << (2 * sl)) | ((d & ~sm) << 2);
+            // r == q or one substitution away cannot be in the whitelist here (levels 0/1 found nothing)
+            probe(r);
+        }
+        // wave merge: distinct hits, lowest caller index
+        uint32_t bidx = NONE_IDX, ties = 0;
+        const bool any_over = __ballot(overflow) != 0;
+        int pending = nf;
+        while (true) {
+            const unsigned long long bal = __ballot(pending > 0);
+            if (!bal) break;
+            const int src = __builtin_ctzll(bal);
+            const uint32_t v = __shfl(found[0], src);
+            ++ties; bidx = v < bidx ? v : bidx;
+            // drop v everywhere (a lane's list holds distinct values: at most one match)
+            const bool h0 = pending > 0 && found[0] == v, h1 = pending > 1 && found[1] == v;
+            const bool h2 = pending > 2 && found[2] == v, h3 = pending > 3 && found[3] == v;
+            if (h0) { found[0] = found[1]; found[1] = found[2]; found[2] = found[3]; }
+            else if (h1) { found[1] = found[2]; found[2] = found[3]; }
+            else if (h2) { found[2] = found[3]; }
+            if (h0 || h1 || h2 || h3) --pending;
+        }
+        if (lane == 0) {
+            if (any_over) { list3[atomicAdd(&counters_out[1], 1u)] = qi; }
+            else if (ties) { best_idx[qi] = bidx; best_ed[qi] = 2; n_ties[qi] = (uint16_t)ties; }
+            else { best_idx[qi] = NONE_IDX; best_ed[qi] = 255; n_ties[qi] = 0; }
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
+{
+    if (nw == 0) { ctx->w_n = 0; return BDG_OK; }
+    std::vector<uint32_t> order(nw);
+    std::iota(order.begin(), order.end(), 0u);
+    bool sorted_in = true;
+    for (uint32_t i = 1; i < nw; ++i) if (wl[i - 1] >= wl[i]) { sorted_in = false; break; }
+    if (!sorted_in) std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return wl[a] < wl[b] || (wl[a] == wl[b] && a < b); });
+    std::vector<uint32_t> srt(nw);
+    for (uint32_t i = 0; i < nw; ++i) srt[i] = wl[order[i]];
+    for (uint32_t i = 1; i < nw; ++i)
+        if (srt[i] == srt[i - 1]) return bdg_fail(ctx, BDG_E_ARG, "whitelist entries must be distinct");
+    int pbits = 8;
+    while (pbits < 20 && (1u << pbits) < nw) ++pbits;
+    const int bbits = pbits + 4 > 24 ? 24 : pbits + 4;
+    std::vector<uint32_t> prefix((size_t(1) << pbits) + 1, 0u), bitmap(size_t(1) << (bbits - 5), 0u);
+    for (uint32_t i = 0; i < nw; ++i) {
+        prefix[(srt[i] >> (32 - pbits)) + 1]++;
+        const uint32_t b = srt[i] >> (32 - bbits);
+        bitmap[b >> 5] |= 1u << (b & 31u);
+    }
+    for (size_t p = 0; p < (size_t(1) << pbits); ++p) prefix[p + 1] += prefix[p];
+    int rc;
+    if ((rc = bdg_reserve(ctx, ctx->w_sorted, sizeof(uint32_t) * nw))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->w_orig, sizeof(uint32_t) * nw))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->w_prefix, sizeof(uint32_t) * prefix.size()))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->w_bitmap, sizeof(uint32_t) * bitmap.size()))) return rc;
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_sorted.p, srt.data(), sizeof(uint32_t) * nw, hipMemcpyHostToDevice));
+    BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_orig.p, order.data(), sizeof(uint32_t) * nw, hipMemcpyHostToDevice));
+    BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_prefix.p, prefix.data(), sizeof(uint32_t) * prefix.size(), hipMemcpyHostToDevice));
+    BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_bitmap.p, bitmap.data(), sizeof(uint32_t) * bitmap.size(), hipMemcpyHostToDevice));
+    ctx->w_n = nw; ctx->w_pbits = pbits; ctx->w_bbits = bbits;
+    return BDG_OK;
+}
+
+int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t max_ed,
+                         uint32_t* d_best_idx, uint8_t* d_best_ed, uint16_t* d_n_ties)
+{
+    if (nq == 0) return BDG_OK;
+    if (ctx->w_n == 0) return bdg_fail(ctx, BDG_E_ARG, "no whitelist loaded (bdg_whitelist_load)");
+    hipStream_t st = ctx->stream;
+    const auto* srt = static_cast<const uint32_t*>(ctx->w_sorted.p);
+    const auto* org = static_cast<const uint32_t*>(ctx->w_orig.p);
+    const bool probe = ctx->n16_algo == 2 || (ctx->n16_algo == 0 && max_ed <= 2);
+    if (ctx->n16_algo == 2 && max_ed > 2) return bdg_fail(ctx, BDG_E_ARG, "probe path needs max_ed <= 2");
+    if (!probe) {
+        ScopedKernelTimer tm(ctx, "k_nearest_scan");
+        hipLaunchKernelGGL(k_nearest_scan, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, (const uint32_t*)nullptr, nq,
+                           (const uint32_t*)nullptr, srt, org, ctx->w_n, max_ed, d_best_idx, d_best_ed, d_n_ties);
+        BDG_HIP_TRY(ctx, hipGetLastError());
+        return BDG_OK;
+    }
+    int rc;
+    if ((rc = bdg_reserve(ctx, ctx->n_list, sizeof(uint32_t) * 2ull * nq))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->n_counters, 16))) return rc;
+    auto* list2 = static_cast<uint32_t*>(ctx->n_list.p);
+    auto* list3 = list2 + nq;
+    auto* counters = static_cast<uint32_t*>(ctx->n_counters.p);
+    BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 16, st));
+    WlIndex ix{ srt, org, static_cast<const uint32_t*>(ctx->w_prefix.p), static_cast<const uint32_t*>(ctx->w_bitmap.p),
+                ctx->w_n, 32 - ctx->w_pbits, 32 - ctx->w_bbits };
+    {
+        ScopedKernelTimer tm(ctx, "k_nearest_l01");
+        hipLaunchKernelGGL(k_nearest_l01, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, nq, ix, max_ed,
+                           d_best_idx, d_best_ed, d_n_ties, list2, counters);
+    }
+    if (max_ed >= 2) {
+        {
+            ScopedKernelTimer tm(ctx, "k_nearest_l2");
+            const uint32_t grid = std::min<uint32_t>((nq + 3) / 4, 256u * 8u);
+            hipLaunchKernelGGL(k_nearest_l2, dim3(grid), dim3(256), 0, st, d_q, list2, counters, ix,
+                               d_best_idx, d_best_ed, d_n_ties, list3, counters);
+        }
+        // queries whose hit list overflowed (one lane found more than 4 distinct entries): exhaustive
+        // scan of just those; the list length stays on the device, so no host round trip
+        {
+            ScopedKernelTimer tm(ctx, "k_nearest_scan_overflow");
+            hipLaunchKernelGGL(k_nearest_scan, dim3(64), dim3(256), 0, st, d_q, list3, 0u, counters + 1,
+                               srt, org, ctx->w_n, max_ed, d_best_idx, d_best_ed, d_n_ties);
+        }
+    }
+    BDG_HIP_TRY(ctx, hipGetLastError());
+    return BDG_OK;
+}

@@ -1,0 +1,148 @@
+/*
+ * badger_hip.h -- C ABI of libbadger_hip.so, the MI355X (gfx950) drop-in for the
+ * data-parallel hot path of algbio/Badger.
+ *
+ * The reference is pure Python and has no FFI of its own; each entry point below
+ * replaces a Python call site (reference-relative file:line) and is what a ctypes
+ * binding inside the reference would call (INTEGRATION.md shows the stubs):
+ *
+ *   bdg_extract_batch*   BarcodeCaller.process_chunk -> TenXBarcodeExtractor.find_barcode_umi
+ *                        extract_raw_barcodes.py:120-128, barcode_callers.py:165-229,
+ *                        barcode_extraction/common.py:10-51,85-114, kmer_indexer.py:49-75
+ *   bdg_graph_edges*     BarcodeGraph.graph_construction / compare_chunk
+ *                        barcode_graph.py:75-111,207-249, index.py:29-35,77-93
+ *   bdg_nearest16*       loop body of BarcodeGraph.postprocessing
+ *                        barcode_graph.py:376-384 (argmin editdistance.eval over the centers)
+ *
+ * Conventions: plain pointers and sizes, little-endian integers, no exceptions
+ * cross the boundary.  Return 0 = OK, <0 = error (BDG_E_*); bdg_last_error()
+ * gives a message.  One bdg_ctx per device, used by one host thread at a time;
+ * different contexts are independent (one per GPU, no collectives).
+ * The library never keeps a caller pointer past the call.
+ *
+ * Two families:
+ *   host-buffer calls   (bdg_extract_batch, bdg_nearest16, bdg_graph_edges):
+ *       pointers are host memory; the call copies in, runs, copies out, returns
+ *       when the results are in the caller's buffers.
+ *   device-resident calls (*_dev): pointers are device memory on the context's
+ *       device; kernels are enqueued on the context's stream (bdg_set_stream)
+ *       and the call returns without synchronising unless stated.
+ */
+#ifndef BADGER_HIP_H
+#define BADGER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDG_OK            0
+#define BDG_E_ARG        -1   /* bad argument */
+#define BDG_E_HIP        -2   /* HIP runtime error */
+#define BDG_E_NOMEM      -3   /* device allocation failed */
+#define BDG_E_CAPACITY   -4   /* output capacity too small (graph edges: see *n_edges) */
+#define BDG_E_BADBASE    -5   /* a read holds a byte outside "ACGTN" (reference: KeyError,
+                                 barcode_extraction/common.py:34-38) */
+
+typedef struct bdg_ctx bdg_ctx;
+
+/* One record per read: everything BarcodeCaller needs to print the TSV row
+ * (barcode_callers.py:40-42,91-93) without string data leaving the device.
+ * Coordinates are in the coordinates of the strand the result was taken from
+ * (flags & BDG_FLAG_REV: the reverse complement of the read). */
+typedef struct bdg_extract_rec {
+    int32_t  polyT;      /* polyT_start column, -1 = none                          */
+    int32_t  r1_end;     /* R1_end column, -1 = none                               */
+    int32_t  bc_start;   /* barcode = strand_seq[bc_start : bc_start+16] (Python slice) */
+    int32_t  umi_start;  /* UMI     = strand_seq[umi_start : umi_end]              */
+    int32_t  umi_end;
+    uint32_t bc_rank;    /* rank() of the barcode (common.py:21-25) if BDG_FLAG_RANK_OK */
+    int8_t   r1_score;   /* Smith-Waterman score of the accepted R1 alignment, else 0 */
+    int8_t   strand;     /* printed strand column: +1 '+', -1 '-', 0 '.'           */
+    uint8_t  valid;      /* 1: barcode detected (is_valid()), 0: row prints "*"    */
+    uint8_t  flags;      /* BDG_FLAG_*                                             */
+    uint32_t reserved;
+} bdg_extract_rec;       /* 32 bytes */
+
+#define BDG_FLAG_REV      1u  /* result comes from reverese_complement(read)          */
+#define BDG_FLAG_RANK_OK  2u  /* bc_rank is valid: 16 in-range ACGT bases             */
+
+typedef struct bdg_edge {
+    uint32_t a;          /* rank, a < b */
+    uint32_t b;
+    uint32_t dist;       /* min(ed(a,b), ed(a[:-1],b), ed(a,b[:-1]))  barcode_graph.py:243 */
+} bdg_edge;              /* 12 bytes */
+
+/* Per-kernel device time, collected with HIP events on the context's stream when
+ * profiling is enabled (bdg_profile_enable). */
+typedef struct bdg_kernel_time {
+    char     name[48];
+    uint64_t launches;
+    double   total_ms;
+} bdg_kernel_time;
+
+/* ---- context ---------------------------------------------------------- */
+int  bdg_init(int device_id, bdg_ctx** out);
+void bdg_free(bdg_ctx* ctx);
+const char* bdg_last_error(bdg_ctx* ctx);     /* ctx-local, valid until the next call; ctx may be NULL */
+const char* bdg_version(void);
+/* Use `hip_stream` (a hipStream_t) for all later work of this context; NULL = the
+ * context's own stream.  Lets the caller time with its own events/stream. */
+int  bdg_set_stream(bdg_ctx* ctx, void* hip_stream);
+int  bdg_synchronize(bdg_ctx* ctx);
+int  bdg_profile_enable(bdg_ctx* ctx, int on);
+int  bdg_profile_reset(bdg_ctx* ctx);
+/* Synchronises, then writes up to cap entries; returns the number of kernels known. */
+int  bdg_profile_read(bdg_ctx* ctx, bdg_kernel_time* out, int cap);
+
+/* ---- B-E: barcode extraction ------------------------------------------ */
+/* n reads as one concatenated ASCII buffer + n+1 offsets (off[0]=0 not required,
+ * off non-decreasing).  umi_len 10 (tenX_v2) or 12 (tenX_v3), barcode_callers.py:156. */
+int  bdg_extract_batch(bdg_ctx* ctx, const uint8_t* bases, const uint64_t* off, uint32_t n,
+                       uint32_t umi_len, bdg_extract_rec* out);
+/* Device-resident form.  d_bases must be 16-byte aligned and readable up to
+ * total_bytes rounded up to 16 (any hipMalloc/torch allocation is).  Asynchronous;
+ * a bad base is reported by the next bdg_extract_status(). */
+int  bdg_extract_batch_dev(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_off, uint32_t n,
+                           uint64_t total_bytes, uint32_t umi_len, bdg_extract_rec* d_out);
+/* Synchronises and returns BDG_OK, BDG_E_BADBASE (read index in *bad_read) or
+ * BDG_E_CAPACITY if the internal window queue overflowed (the host-buffer call
+ * retries by itself; device callers call bdg_extract_batch_dev again, the
+ * workspace has been grown). n_windows: Smith-Waterman windows evaluated. */
+int  bdg_extract_status(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_windows);
+
+/* ---- B-N: nearest whitelist barcode ----------------------------------- */
+/* Per query: the whitelist entry with the smallest Levenshtein distance (ties ->
+ * lowest whitelist index), that distance, and how many entries share it.  If the
+ * distance exceeds max_ed: best_idx 0xFFFFFFFF, best_ed 0xFF, n_ties 0.
+ * Queries and whitelist are rank-packed 16-mers (common.py:21-25). */
+int  bdg_nearest16(bdg_ctx* ctx, const uint32_t* q, uint32_t nq, const uint32_t* wl, uint32_t nw,
+                   uint32_t max_ed, uint32_t* best_idx, uint8_t* best_ed, uint16_t* n_ties);
+/* Copy a whitelist (host memory, any order, distinct) to the device and build its
+ * lookup index; kept in the context until replaced.  Indices reported later refer
+ * to the caller's order. */
+int  bdg_whitelist_load(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw);
+int  bdg_nearest16_dev(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t max_ed,
+                       uint32_t* d_best_idx, uint8_t* d_best_ed, uint16_t* d_n_ties);
+/* algorithm: 0 = automatic, 1 = force the exhaustive Myers scan, 2 = force the
+ * neighbourhood-probe path (max_ed <= 2 only). Results are identical. */
+int  bdg_nearest16_set_algo(bdg_ctx* ctx, int algo);
+
+/* ---- B-G: edit-distance graph ----------------------------------------- */
+/* ranks: distinct rank-packed 16-mers, any order.  Writes up to cap edges (a<b)
+ * with S(a,b) >= qgram_T (index.py:77-93) and dist <= thr, sorted by (a,b); the
+ * total found goes to *n_edges.  Returns BDG_E_CAPACITY if *n_edges > cap (the
+ * first cap edges in sorted order are still written). */
+int  bdg_graph_edges(bdg_ctx* ctx, const uint32_t* ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
+                     bdg_edge* out, uint64_t cap, uint64_t* n_edges);
+/* Device-resident form: d_ranks sorted ascending and distinct; edges are written
+ * unsorted; *d_n_edges (device, 8 bytes) receives the total.  Asynchronous. */
+int  bdg_graph_edges_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
+                         bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges);
+int  bdg_graph_set_algo(bdg_ctx* ctx, int algo);   /* 0 auto, 1 all-pairs scan, 2 neighbourhood probes (thr=1) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,253 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
+Bit-exact: every quantity is an integer.  Needs a real MI355X: `pytest -m gpu`."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from badger_amd import _native, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def _row(rid, seq, rec, orc):
+    s = orc.revcomp(seq) if rec["flags"] & 1 else seq
+    if rec["valid"]:
+        bc, umi, score = s[rec["bc_start"]:rec["bc_start"] + 16], s[rec["umi_start"]:rec["umi_end"]], 0
+    else:
+        bc, umi, score = "*", "*", -1
+    strand = {1: "+", -1: "-", 0: "."}[int(rec["strand"])]
+    return "%s\t%s\t%s\t%d\t%s\t%s\t%d\t%d" % (rid, bc, umi, score, False, strand, rec["polyT"], rec["r1_end"])
+
+
+def _diff(got, want):
+    bad = np.nonzero(got != want)[0]
+    return "first mismatch at %d: got %s want %s (%d total)" % (bad[0], got[bad[0]], want[bad[0]], len(bad)) if len(bad) else ""
+
+
+# --------------------------------------------------------------------------- extraction
+def test_extract_golden_rows(ctx, orc, golden_dir):
+    ext = json.load(open(os.path.join(golden_dir, "extract_rows.json")))
+    seqs = [r["seq"] for r in ext["reads"]]
+    bases, off = synth.list_to_reads(seqs)
+    for umi_len, key, skey in ((12, "row_v3", "r1_score_v3"), (10, "row_v2", "r1_score_v2")):
+        recs = ctx.extract_batch(bases, off, umi_len)
+        for r, rec in zip(ext["reads"], recs):
+            assert _row(r["id"], r["seq"], rec, orc) == r[key], r["id"]
+            assert int(rec["r1_score"]) == r[skey], r["id"]
+        want = orc.extract_batch(bases, off, umi_len, threads=4)
+        assert (recs == want).all(), _diff(recs, want)
+
+
+def test_extract_config1_tsv(ctx, orc, golden_dir):
+    seqs, ids = [], []
+    with gzip.open(os.path.join(golden_dir, "c1_reads.fa.gz"), "rt") as f:
+        for line in f:
+            (ids if line.startswith(">") else seqs).append(line[1:].strip() if line.startswith(">") else line.strip())
+    bases, off = synth.list_to_reads(seqs)
+    recs = ctx.extract_batch(bases, off, 12)
+    want = open(os.path.join(golden_dir, "c1_expected.tsv")).read().split("\n")
+    rows = [_row(i, s, r, orc) for i, s, r in zip(ids, seqs, recs)]
+    assert rows == want[1:1 + len(rows)]
+
+
+@pytest.mark.parametrize("n,seed,errs", [(5000, 3, (0.03, 0.02, 0.03)), (3000, 4, (0.0, 0.0, 0.0)), (3000, 5, (0.10, 0.05, 0.05))])
+def test_extract_vs_oracle_synthetic(ctx, orc, n, seed, errs):
+    wl = synth.make_whitelist(1000)
+    bases, off = synth.make_reads(n, wl, seed=seed, p_sub=errs[0], p_ins=errs[1], p_del=errs[2])
+    b, o = bases.numpy(), off.numpy().astype(np.uint64)
+    got = ctx.extract_batch(b, o, 12)
+    want = orc.extract_batch(b, o, 12, threads=8)
+    assert (got == want).all(), _diff(got, want)
+
+
+def test_extract_adversarial(ctx, orc):
+    rng = np.random.default_rng(99)
+    R1 = "CTACACGACGCTCTTCCGATCT"
+    rnd = lambda k: "".join("ACGT"[i] for i in rng.integers(0, 4, k))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))
+    seqs = ["", "A", "ACGTA", "T" * 16, "T" * 17, "A" * 16, "A" * 17, "T" * 5000, "A" * 5000, R1, rc(R1), R1 * 50, rc(R1 * 50),
+            "N" * 100, rnd(1007), rnd(1008), rnd(1009), rnd(2016), rnd(2017), rnd(8000), rnd(70000)]
+    for k in range(200):    # reads with R1 / polyT planted at every alignment relative to the 16-byte vectors
+        pre = rnd(int(rng.integers(0, 70)))
+        mid = R1 if rng.random() < 0.8 else R1[:int(rng.integers(8, 22))]
+        tail = "T" * int(rng.integers(10, 40)) if rng.random() < 0.8 else rnd(5)
+        s = pre + mid + rnd(int(rng.integers(0, 45))) + tail + rnd(int(rng.integers(0, 1200)))
+        if rng.random() < 0.2:
+            p = int(rng.integers(0, len(s)))
+            s = s[:p] + "N" + s[p + 1:]
+        seqs.append(s if rng.random() < 0.5 else rc(s))
+    for k in range(100):    # short reads around every length threshold
+        seqs.append(rnd(int(rng.integers(0, 80))))
+    bases, off = synth.list_to_reads(seqs)
+    for umi_len in (10, 12):
+        got = ctx.extract_batch(bases, off, umi_len)
+        want = orc.extract_batch(bases, off, umi_len, threads=8)
+        assert (got == want).all(), _diff(got, want)
+    # a sub-range of the buffer (off[0] != 0) gives the same records
+    got2 = ctx.extract_batch(bases, off[20:], 12)
+    assert (got2 == orc.extract_batch(bases, off, 12, threads=8)[20:]).all()
+
+
+def test_extract_empty_and_errors(ctx):
+    assert len(ctx.extract_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))) == 0
+    bases, off = synth.list_to_reads(["ACGT" * 30, "ACGTacgt" * 10, "ACGT" * 5])
+    with pytest.raises(_native.BadgerHipError) as e:
+        ctx.extract_batch(bases, off, 12)
+    assert e.value.code == _native.E_BADBASE and "read 1" in str(e.value)
+    with pytest.raises(_native.BadgerHipError):
+        ctx.extract_batch(bases, np.array([0, 10, 5, 20], np.uint64), 12)
+
+
+def test_extract_partition_invariance(ctx, orc):
+    """Sharding reads across GPUs = running contiguous sub-batches: records must not depend on the split."""
+    wl = synth.make_whitelist(1000)
+    bases, off = synth.make_reads(4000, wl, seed=21)
+    b, o = bases.numpy(), off.numpy().astype(np.uint64)
+    whole = ctx.extract_batch(b, o, 12)
+    parts = [ctx.extract_batch(b, o[s:e + 1], 12) for s, e in ((0, 1000), (1000, 1001), (1001, 2500), (2500, 4000))]
+    assert (np.concatenate(parts) == whole).all()
+
+
+# --------------------------------------------------------------------------- nearest16
+def _near_queries(wl, rng, n):
+    q = []
+    for _ in range(n):
+        w = int(wl[int(rng.integers(0, len(wl)))])
+        u = rng.random()
+        if u < 0.2:
+            pass
+        elif u < 0.5:
+            w ^= int(rng.integers(1, 4)) << (2 * int(rng.integers(0, 16)))
+        elif u < 0.7:
+            w ^= int(rng.integers(1, 4)) << (2 * int(rng.integers(0, 16)))
+            w ^= int(rng.integers(1, 4)) << (2 * int(rng.integers(0, 16)))
+        elif u < 0.9:      # delete one base, insert one elsewhere
+            s = list(synth.rank_to_str(w))
+            del s[int(rng.integers(0, 16))]
+            s.insert(int(rng.integers(0, 16)), "ACGT"[int(rng.integers(0, 4))])
+            w = synth.str_to_rank("".join(s))
+        else:
+            w = int(rng.integers(0, 1 << 32))
+        q.append(w)
+    return np.array(q, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("max_ed", [0, 1, 2])
+def test_nearest16_vs_oracle(ctx, orc, algo, max_ed):
+    rng = np.random.default_rng(17)
+    wl = synth.make_whitelist(3000)
+    # a dense cluster so that ties and multi-hit neighbourhoods occur
+    base = int(wl[0])
+    cluster = {base ^ (x << (2 * p)) for p in range(16) for x in (1, 2, 3)} | {base ^ (1 << 2) ^ (2 << 10), base ^ (3 << 6) ^ (1 << 20)}
+    wl = np.unique(np.concatenate([wl, np.array(sorted(cluster), dtype=np.uint32)]))
+    rng.shuffle(wl)                      # caller order != rank order: indices must refer to the caller's order
+    q = np.concatenate([_near_queries(wl, rng, 1500), np.array([base, base ^ 3, base ^ (1 << 30)], dtype=np.uint32)])
+    ctx.nearest16_set_algo(algo)
+    gi, ge, gt = ctx.nearest16(q, wl, max_ed)
+    wi, we, wt = orc.nearest16(q, wl, max_ed, threads=8)
+    assert (ge == we).all(), _diff(ge, we)
+    assert (gi == wi).all(), _diff(gi, wi)
+    assert (gt == wt).all(), _diff(gt, wt)
+    ctx.nearest16_set_algo(0)
+
+
+def test_nearest16_scan_large_max_ed(ctx, orc):
+    rng = np.random.default_rng(5)
+    wl = synth.make_whitelist(5000)
+    q = rng.integers(0, 1 << 32, 300, dtype=np.uint64).astype(np.uint32)
+    gi, ge, gt = ctx.nearest16(q, wl, 16)
+    wi, we, wt = orc.nearest16(q, wl, 16, threads=8)
+    assert (ge == we).all() and (gi == wi).all() and (gt == wt).all()
+
+
+def test_nearest16_edge_cases(ctx):
+    wl = synth.make_whitelist(10)
+    gi, ge, gt = ctx.nearest16(np.zeros(0, np.uint32), wl, 2)
+    assert len(gi) == 0
+    gi, ge, gt = ctx.nearest16(wl[:3], np.zeros(0, np.uint32), 2)
+    assert (gi == 0xFFFFFFFF).all() and (ge == 255).all() and (gt == 0).all()
+    with pytest.raises(_native.BadgerHipError):
+        ctx.nearest16(wl[:3], np.array([5, 5, 7], np.uint32), 2)      # whitelist must be distinct
+
+
+# --------------------------------------------------------------------------- graph
+def _ranks_of(barcodes):
+    out = []
+    for s in barcodes:
+        if len(s) == 17:
+            s = s[:-1]
+        if len(s) == 16:
+            out.append(synth.str_to_rank(s))
+    return np.unique(np.array(out, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_graph_golden(ctx, golden_dir, algo):
+    g = json.load(open(os.path.join(golden_dir, "graph.json")))
+    for key in ("c1_thr1", "c1_thr2", "cells60_thr1", "cells60_thr2"):
+        thr = int(key[-1])
+        if algo == 2 and thr != 1:
+            continue
+        ctx.graph_set_algo(algo)
+        case = g[key]
+        e = ctx.graph_edges(_ranks_of(case["barcodes"]), thr, case["qgram_T"])
+        got = [[int(x["a"]), int(x["b"]), int(x["dist"])] for x in e]
+        assert got == case["edges"], key
+    ctx.graph_set_algo(0)
+
+
+def _observed_barcodes(n_cells, n_obs, seed):
+    rng = np.random.default_rng(seed)
+    cells = rng.integers(0, 1 << 32, n_cells, dtype=np.uint64)
+    out = np.empty(n_obs, dtype=np.uint64)
+    for k in range(n_obs):
+        s = list(synth.rank_to_str(int(cells[int(rng.integers(0, n_cells))])))
+        i = 0
+        while i < len(s):
+            u = rng.random()
+            if u < 0.03: s[i] = "ACGT"[int(rng.integers(0, 4))]
+            elif u < 0.05: del s[i]; continue
+            elif u < 0.07: s.insert(i, "ACGT"[int(rng.integers(0, 4))]); i += 1
+            i += 1
+        s = ("".join(s) + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 4)))[:16]
+        out[k] = synth.str_to_rank(s)
+    return np.unique(out.astype(np.uint32))
+
+
+@pytest.mark.parametrize("algo,thr", [(1, 1), (2, 1), (1, 2), (1, 3)])
+def test_graph_vs_oracle(ctx, orc, algo, thr):
+    ranks = _observed_barcodes(300, 12000, 31)
+    ctx.graph_set_algo(algo)
+    T = orc.qgram_threshold(thr)
+    e = ctx.graph_edges(ranks, thr, T)
+    w = orc.graph_edges(ranks, thr, T, threads=8)
+    assert len(e) == len(w) and len(e) > 100
+    assert (e == w).all()
+    ctx.graph_set_algo(0)
+
+
+def test_graph_edge_cases(ctx):
+    assert len(ctx.graph_edges(np.zeros(0, np.uint32), 1, 5)) == 0
+    assert len(ctx.graph_edges(np.array([7], np.uint32), 1, 5)) == 0
+    e = ctx.graph_edges(np.array([0, 1], np.uint32), 1, 5)
+    assert len(e) == 1 and tuple(e[0]) == (0, 1, 1)
+    with pytest.raises(_native.BadgerHipError):
+        ctx.graph_edges(np.array([3, 3], np.uint32), 1, 5)
