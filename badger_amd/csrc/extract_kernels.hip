@@ -46,7 +46,9 @@ constexpr int32_t ONE = 1 << KEY_SHIFT;
 
 enum { C_NHITS = 0, C_BADREAD = 1, C_NWINDOWS = 2 };
 
-constexpr int READS_PER_BLOCK = 32;
+constexpr int READS_PER_BLOCK = 64;
+constexpr uint32_t HITBUF = 4096;          // per-block LDS staging of queue entries (32 KiB)
+constexpr uint64_t HIT_HOLE = ~0ull;       // unused queue slot (skipped by k_sw_windows)
 
 __device__ __forceinline__ uint32_t range_mask16(int64_t lo, int64_t hi)
 {
@@ -68,7 +70,11 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
 {
     __shared__ uint32_t s_kmer[256];     // 4096 x 2 bits: bit0 R1 6-mer, bit1 reverse-complement of one
     __shared__ uint2 s_cls[256];         // byte -> {isT | isA<<16, isN | bad<<16}
+    __shared__ uint64_t s_hits[HITBUF];  // this block's queue entries, flushed with ONE global reservation
+    __shared__ uint32_t s_nhits;
+    __shared__ unsigned long long s_base;
     const int tid = threadIdx.x;
+    if (tid == 0) s_nhits = 0;
     s_kmer[tid] = tables[tid];
     s_cls[tid] = reinterpret_cast<const uint2*>(tables + 256)[tid];
     __syncthreads();
@@ -165,7 +171,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             if (__ballot(bad != 0 && worker)) {
                 if (bad != 0 && worker) atomicMin(&counters[C_BADREAD], (unsigned long long)r);
             }
-            // append the hits of this step to the window queue
+            // append the hits of this step to the block's LDS staging buffer
             const uint32_t cnt = __popc(hitF) + __popc(hitR);
             uint32_t incl = cnt;
 #pragma unroll
@@ -175,27 +181,43 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             }
             const uint32_t total = __shfl(incl, 63);
             if (total) {
-                unsigned long long base = 0;
-                if (lane == 63) base = atomicAdd(&counters[C_NHITS], (unsigned long long)total);
-                base = __shfl(base, 63);
-                unsigned long long idx = base + incl - cnt;
+                uint32_t slot = 0;
+                if (lane == 63) slot = atomicAdd(&s_nhits, total);
+                slot = __shfl(slot, 63);
+                const bool fits = slot + total <= HITBUF;
+                unsigned long long gbase = 0;
+                if (!fits) {            // staging full (pathological read): this step goes straight to the queue
+                    if (lane == 63) gbase = atomicAdd(&counters[C_NHITS], (unsigned long long)total);
+                    gbase = __shfl(gbase, 63);
+                    for (uint32_t h = slot + lane; h < HITBUF && h < slot + total; h += 64) s_hits[h] = HIT_HOLE;
+                }
+                unsigned long long idx = (fits ? slot : gbase) + incl - cnt;
                 uint32_t m = hitF;
                 while (m) {
                     const int k = __builtin_ctz(m); m &= m - 1;
-                    const uint64_t pos = (uint64_t)(p0 + k);
-                    if (idx < hits_cap) hits[idx] = r | ((pos << 1) << 32);
+                    const uint64_t ent = r | (((uint64_t)(p0 + k) << 1) << 32);
+                    if (fits) s_hits[idx] = ent; else if (idx < hits_cap) hits[idx] = ent;
                     ++idx;
                 }
                 m = hitR;
                 while (m) {
                     const int k = __builtin_ctz(m); m &= m - 1;
-                    const uint64_t pos = (uint64_t)(L - KMER - (p0 + k));
-                    if (idx < hits_cap) hits[idx] = r | (((pos << 1) | 1ull) << 32);
+                    const uint64_t ent = r | ((((uint64_t)(L - KMER - (p0 + k)) << 1) | 1ull) << 32);
+                    if (fits) s_hits[idx] = ent; else if (idx < hits_cap) hits[idx] = ent;
                     ++idx;
                 }
             }
         }
         if (lane == 0) { polyt[2 * r] = ptF; polyt[2 * r + 1] = ptR; }
+    }
+    // flush: one global reservation per block, coalesced 8-byte stores
+    __syncthreads();
+    const uint32_t nst = s_nhits < HITBUF ? s_nhits : HITBUF;
+    if (tid == 0 && nst) s_base = atomicAdd(&counters[C_NHITS], (unsigned long long)nst);
+    __syncthreads();
+    if (nst) {
+        const unsigned long long gb = s_base;
+        for (uint32_t h = tid; h < nst; h += 256) if (gb + h < hits_cap) hits[gb + h] = s_hits[h];
     }
 }
 
@@ -325,16 +347,18 @@ void k_sw_windows(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     uint32_t nwin = 0;
     for (uint64_t base = (uint64_t)blockIdx.x * 256ull + (threadIdx.x & ~63); base < nh; base += stride) {
         const uint64_t g = base + lane;
-        const bool active = g < nh;
+        bool active = g < nh;
         uint64_t rs = 0; int64_t L = 0; uint32_t r = 0, strand = 0; int64_t pos = 0; int32_t pt = -1;
-        if (active) {
-            const uint64_t ent = hits[g];
+        const uint64_t ent = active ? hits[g] : HIT_HOLE;
+        const bool hole = ent == HIT_HOLE;
+        if (!hole) {
             r = (uint32_t)ent;
             const uint32_t ps = (uint32_t)(ent >> 32);
             strand = ps & 1u; pos = ps >> 1;
             rs = off[r]; L = (int64_t)(off[r + 1] - rs);
             pt = polyt[2 * (uint64_t)r + strand];
         }
+        active = active && !hole;
         const int64_t ws = pos - (R1_LEN - KMER) > 0 ? pos - (R1_LEN - KMER) : 0;       // common.py:96-97
         const int64_t we = pos + R1_LEN + 1 < L ? pos + R1_LEN + 1 : L;                 // :98-99 (strict: end = len)
         const int nfull = active ? (int)(we - ws) : 0;
