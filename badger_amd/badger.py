@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Stage 2 CLI: barcode correction, same flags and output file as the reference's badger.py
+(reference badger.py:23-47,62-132), with the edit-distance graph built on the MI355X.
+
+    python -m badger_amd.badger -r out.tsv -d tenX_v3 -l whitelist.txt -c 5000 [-t 1] [-hs]
+
+--stats and --ground_truth drive the reference's offline evaluation module (stats.py), which
+is outside the accelerated path; the flags are accepted and rejected with a message.
+"""
+import argparse
+import logging
+import sys
+from io import StringIO
+from traceback import print_exc
+
+from .barcode_graph import BarcodeGraph
+from .extract_raw_barcodes import BARCODE_CALLING_MODES, extract_barcodes_in_parallel, extract_barcodes_single_thread
+
+logger = logging.getLogger("BarcodeGraph")
+
+
+def parse_args(args):
+    p = argparse.ArgumentParser(formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--threshold", "-t", help="Maximal accepted difference between barcodes", type=int, dest="threshold", default=1)
+    p.add_argument("--reads", "-r", help="read in FASTQ/FASTA (can be gzipped), BAM or TSV from barcode extraction",
+                   type=str, dest="reads", required=True)
+    p.add_argument("--ground_truth", type=str, default=None,
+                   help="File connecting each observed barcode to its read ID containing true barcode, only used for statistics")
+    p.add_argument("--barcode_list", "-l", type=str, dest="barcode_list", default=None,
+                   help="List of all possible barcodes for the used method, helps identify correct barcodes")
+    p.add_argument("--data_type", "-d", choices=BARCODE_CALLING_MODES.keys(), type=str,
+                   help="Type of single cell sequencing data in the input")
+    p.add_argument("--true_barcodes", type=str, default=None,
+                   help="List of all true barcodes of the input data, for example obtained from short read data")
+    p.add_argument("--n_cells", "-c", help="expected number of cell associated barcodes", type=int, default=5000)
+    p.add_argument("--output", "-o", help="File prefix for output files", type=str, default="OUT")
+    p.add_argument("--interval", "-i", default=25, type=int,
+                   help="Percentage by which the number of cells is allowed to differ from estimated cell number, default 25%%")
+    p.add_argument("--stats", "-s", action="store_true", default=False,
+                   help="if set, true barcode statistics are run instead of barcode calling.")
+    p.add_argument("--threads", "-tr", dest="threads", default=1, type=int)
+    p.add_argument("--high_sens", "-hs", action="store_true", default=False,
+                   help="if set, Badger is run in high sensitivity mode. This increases recall but decreases precision")
+    p.add_argument("--device", type=int, default=0, help="MI355X device index")
+    return p.parse_args(args)
+
+
+def set_logger(logger_instance):
+    logger_instance.setLevel(logging.INFO)
+    if not logger_instance.handlers:
+        h = logging.StreamHandler(stream=sys.stdout)
+        h.setLevel(logging.INFO)
+        h.setFormatter(logging.Formatter("%(asctime)s - %(levelname)s - %(message)s"))
+        logger_instance.addHandler(h)
+    logger_instance.info("Starting")
+
+
+def import_tsv(path, bc_len):
+    """Stage-1 TSV -> (read_assignment, barcodes) the way reference badger.py:91-111 reads it:
+    repeated header rows are skipped, an empty barcode field counts as '*', 17-character
+    barcodes lose their last base in read_assignment (graph_construction trims its own copy)."""
+    read_assignment, barcodes = [], []
+    with open(path) as f:
+        header = f.readline().rstrip("\n").split("\t")
+        ci, cb = header.index("#read_id"), header.index("barcode")
+        for line in f:
+            fields = line.rstrip("\n").split("\t")
+            if len(fields) <= max(ci, cb):
+                continue
+            rid, bc = fields[ci], fields[cb]
+            if rid == "#read_id" or bc == "barcode":
+                continue
+            if bc in ("", "NA", "NaN", "nan", "N/A", "NULL", "null", "None"):   # pandas reads these as missing
+                bc = "*"
+            if bc != "*":
+                barcodes.append(bc)
+            read_assignment.append((rid, bc[:-1] if len(bc) == bc_len + 1 else bc))
+    return read_assignment, barcodes
+
+
+def load_true_barcodes(path):
+    """reference badger.py:73-80"""
+    vals = [l.rstrip("\n").split("\t")[0] for l in open(path) if l.strip()]
+    if vals and vals[0][-1] == "1":
+        vals = [v[:-2] for v in vals]
+    return set(vals)
+
+
+def main(args):
+    args = parse_args(args)
+    set_logger(logger)
+    if args.data_type and args.data_type.startswith("tenX"):
+        bc_len = 16
+    else:
+        logger.error("Please specify the type of single cell data used. Options are tenX_v2 and tenX_v3.")
+        sys.exit(-3)
+    if args.stats or args.ground_truth is not None:
+        logger.error("--stats / --ground_truth run the reference's offline evaluation module, which this build does not carry")
+        sys.exit(-4)
+    true_barcodes = load_true_barcodes(args.true_barcodes) if args.true_barcodes else None
+    barcode_list = None
+    if args.barcode_list:
+        with open(args.barcode_list) as f:
+            barcode_list = set(f.read().split("\n"))
+
+    if args.reads.endswith("tsv"):
+        read_assignment, barcodes = import_tsv(args.reads, bc_len)
+        logger.info("Imported barcodes from file")
+    else:
+        if args.threads == 1:
+            read_assignment = extract_barcodes_single_thread(args.reads, args.data_type)
+        else:
+            read_assignment = extract_barcodes_in_parallel(args.reads, args.data_type, args.threads)
+        barcodes = [ra[1] for ra in read_assignment if ra[1] != "*"]
+
+    logger.info("Initializing Graph")
+    graph = BarcodeGraph(args.threshold, device=args.device)
+    graph.graph_construction(barcodes, bc_len, args.threads)
+    logger.info("Graph construction done")
+    graph.cluster(true_barcodes, barcode_list, args.n_cells, bc_len, args.interval)
+    logger.info("Clustering done")
+    graph.output_file(read_assignment, args.output, true_barcodes, bc_len, args.high_sens)
+    print(len(graph.counts) - len(graph.edges))          # "disconnected" count (reference :131-132)
+
+
+if __name__ == "__main__":
+    try:
+        main(sys.argv[1:])
+    except (SystemExit, KeyboardInterrupt):
+        raise
+    except:  # noqa: E722  (same catch-all as the reference :177-196)
+        if logger.handlers:
+            buf = StringIO()
+            print_exc(file=buf)
+            logger.critical("Barcode Graph failed" + buf.getvalue())
+        else:
+            sys.stderr.write("Barcode Graph failed")
+            print_exc()
+        sys.exit(-1)

@@ -1,0 +1,80 @@
+"""One process per GPU.  Reads partition independently, so the data path needs no
+collective: each rank takes a contiguous range of reads, the whitelist is replicated, and
+results are concatenated in rank order.  torch.distributed (RCCL on the GPU box, gloo on CPU)
+is used only for the barrier, the max-over-ranks clock and the final gather of records."""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition(n, world, rank):
+    """Contiguous read-index range [lo, hi) of `rank` (sizes differ by at most one)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None, device=None):
+    rank, local_rank, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def barrier(device=None):
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def all_max(value, device=None):
+    """max over ranks of a python float"""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def timed(step, steps, device=None):
+    """K calls of step() bracketed by barrier + synchronize; returns max-over-ranks seconds."""
+    barrier(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    barrier(device)
+    return all_max(elapsed, device)
+
+
+def extract_sharded(extract_fn, bases, off, umi_len=12):
+    """Run extract_fn(bases, off_slice, umi_len) -> records on this rank's partition of the reads and
+    return, on rank 0, all records in read order (None elsewhere)."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    n = len(off) - 1
+    lo, hi = partition(n, world, rank)
+    mine = extract_fn(bases, off[lo:hi + 1], umi_len)
+    if world == 1:
+        return mine
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(mine.tobytes(), gathered, dst=0)
+    if rank != 0:
+        return None
+    return np.concatenate([np.frombuffer(b, dtype=mine.dtype) for b in gathered])

@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Stage 1 CLI: raw barcode extraction, same flags and TSV as the reference's
+extract_raw_barcodes.py (reference extract_raw_barcodes.py:360-391), MI355X underneath.
+
+    python -m badger_amd.extract_raw_barcodes --mode tenX_v3 -i reads.fq.gz -o out.tsv [-t N]
+
+What differs from the reference, by design:
+  * reads are cut into chunks of 100,000 (READ_CHUNK_SIZE, reference :32) and each chunk is
+    ONE call into the HIP library; `--threads` no longer buys CPU parallelism.  It is kept
+    because it selects the reference's two output shapes: threads == 1 writes one header
+    and a tab-separated .stats (reference :162-173); threads > 1 writes a header per chunk
+    and a space-separated .stats (reference :243-259) -- here always in input order, where
+    the reference concatenates chunks in completion order.
+  * new optional flags: --gpus (shard chunks round-robin over that many devices of the node).
+  * FASTA/FASTQ (optionally gzipped) are parsed here; BAM/SAM needs pysam like the reference.
+"""
+import argparse
+import gzip
+import logging
+import os
+import sys
+from collections import defaultdict
+from traceback import print_exc
+
+from .barcode_extraction.barcode_callers import (ReadStats, TenXBarcodeExtractorV2, TenXBarcodeExtractorV3,
+                                                 record_to_row)
+
+logger = logging.getLogger("BarcodeGraph")
+
+READ_CHUNK_SIZE = 100000
+BARCODE_CALLING_MODES = {"tenX_v2": TenXBarcodeExtractorV2, "tenX_v3": TenXBarcodeExtractorV3}
+
+
+# ----------------------------------------------------------------------------- readers
+def _fasta_records(handle):
+    rid, parts = None, []
+    for line in handle:
+        line = line.rstrip("\r\n")
+        if line.startswith(">"):
+            if rid is not None:
+                yield rid, "".join(parts)
+            fields = line[1:].split()
+            rid, parts = (fields[0] if fields else ""), []
+        elif rid is not None:
+            parts.append(line.strip())
+    if rid is not None:
+        yield rid, "".join(parts)
+
+
+def _fastq_records(handle):
+    while True:
+        head = handle.readline()
+        if not head:
+            return
+        head = head.rstrip("\r\n")
+        if not head:
+            continue
+        if not head.startswith("@"):
+            raise ValueError("malformed FASTQ record header: %r" % head[:50])
+        seq = handle.readline().rstrip("\r\n")
+        plus = handle.readline()
+        qual = handle.readline()
+        if not plus.startswith("+") or len(qual.rstrip("\r\n")) != len(seq):
+            raise ValueError("malformed FASTQ record %r" % head[:50])
+        fields = head[1:].split()
+        yield (fields[0] if fields else ""), seq
+
+
+def _bam_records(path, skip_secondary):
+    try:
+        import pysam
+    except ImportError:
+        raise RuntimeError("BAM/SAM input needs pysam, which is not installed")
+    for r in pysam.AlignmentFile(path, "rb"):
+        if skip_secondary and (r.is_secondary or r.is_supplementary):     # reference :144-145
+            continue
+        yield r.query_name, r.query_sequence
+
+
+def open_reads(input_file, skip_secondary=True):
+    """-> iterator of (read_id, sequence); None for an unknown extension (reference :80-97,181-197)."""
+    fname, ext = os.path.splitext(os.path.basename(input_file))
+    ext = ext.lower()
+    handle = None
+    if ext in (".gz", ".gzip"):
+        handle = gzip.open(input_file, "rt")
+        fname, ext = os.path.splitext(fname)
+        ext = ext.lower()
+    if ext in (".fq", ".fastq"):
+        return _fastq_records(handle or open(input_file))
+    if ext in (".fa", ".fasta"):
+        return _fasta_records(handle or open(input_file))
+    if ext in (".bam", ".sam"):
+        return _bam_records(input_file, skip_secondary)
+    return None
+
+
+def read_chunks(records, size=READ_CHUNK_SIZE):
+    chunk = []
+    for rec in records:
+        chunk.append(rec)
+        if len(chunk) >= size:
+            yield chunk
+            chunk = []
+    yield chunk                      # the reference also yields the trailing (possibly empty) chunk
+
+
+# ----------------------------------------------------------------------------- handlers
+class FileReadHandler:
+    def __init__(self, outfile):
+        self.output_table = outfile
+        self.output_file = open(outfile, "w")
+
+    def add_header(self, header):
+        self.output_file.write(header + "\n")
+
+    def add_read(self, barcode_result):
+        self.output_file.write(str(barcode_result) + "\n")
+
+    def add_rows(self, rows):
+        if rows:
+            self.output_file.write("\n".join(rows) + "\n")
+
+    def dump_stats(self, read_stat):
+        with open(self.output_table + ".stats", "w") as f:
+            f.write(str(read_stat))
+
+    def close(self):
+        if not self.output_file.closed:
+            self.output_file.close()
+
+    def __del__(self):
+        self.close()
+
+
+class ListReadHandler:
+    def __init__(self):
+        self.read_storage = []
+
+    def add_header(self, header):
+        pass
+
+    def add_read(self, r):
+        self.read_storage.append((r.read_id, r.barcode, r.UMI))
+
+    def add_rows(self, rows):
+        for row in rows:
+            f = row.split("\t")
+            self.read_storage.append((f[0], f[1], f[2]))
+
+    def dump_stats(self, read_stat):
+        pass
+
+
+class BarcodeCaller:
+    """Same seam as the reference's BarcodeCaller (reference :71-128): process_chunk() takes
+    list[(read_id, seq)], feeds the handler one row per read in input order, updates read_stat."""
+
+    def __init__(self, barcode_detector, read_handler):
+        self.barcode_detector = barcode_detector
+        self.read_handler = read_handler
+        self.read_handler.add_header(barcode_detector.result_type().header())
+        self.read_stat = ReadStats()
+
+    def process_chunk(self, read_chunk):
+        if not read_chunk:
+            return
+        recs = self.barcode_detector.extract_records([s for _, s in read_chunk])
+        self.read_handler.add_rows([record_to_row(rid, s, r) for (rid, s), r in zip(read_chunk, recs)])
+        self.read_stat.add_records(recs)
+
+    def process(self, input_file):
+        logger.info("Processing " + input_file)
+        records = open_reads(input_file, skip_secondary=False)     # single-thread BAM path keeps all records (:110-118)
+        if records is None:
+            logger.error("Unknown file format " + input_file)
+        else:
+            for chunk in read_chunks(records):
+                self.process_chunk(chunk)
+        logger.info("Finished " + input_file)
+
+
+# ----------------------------------------------------------------------------- drivers
+def _detectors(mode, gpus):
+    return [BARCODE_CALLING_MODES[mode](device=g) for g in range(max(1, gpus))]
+
+
+def process_single_thread(args):
+    logger.info("Processing " + args.input)
+    handler = FileReadHandler(args.output)
+    caller = BarcodeCaller(_detectors(args.mode, 1)[0], handler)
+    caller.process(args.input)
+    handler.dump_stats(caller.read_stat)
+    handler.close()
+    for line in str(caller.read_stat).split("\n"):
+        if line:
+            logger.info(line)
+    logger.info("Finished barcode calling")
+
+
+def process_in_parallel(args):
+    """Chunks go round-robin to the node's GPUs; output is written in chunk order, one header per
+    chunk and a space-separated merged .stats (the reference's parallel-mode file shape)."""
+    logger.info("Processing " + args.input)
+    records = open_reads(args.input, skip_secondary=True)
+    if records is None:
+        logger.error("Unknown file format " + args.input)
+        sys.exit(-1)
+    detectors = _detectors(args.mode, getattr(args, "gpus", 1))
+    logger.info("Barcode caller created")
+    stat_dict = defaultdict(int)
+    header = detectors[0].result_type().header()
+    with open(args.output, "w") as outf:
+        for k, chunk in enumerate(read_chunks(records)):
+            det = detectors[k % len(detectors)]
+            outf.write(header + "\n")
+            stats = ReadStats()
+            if chunk:
+                recs = det.extract_records([s for _, s in chunk])
+                outf.write("\n".join(record_to_row(rid, s, r) for (rid, s), r in zip(chunk, recs)) + "\n")
+                stats.add_records(recs)
+            for line in str(stats).split("\n"):
+                v = line.strip().split("\t")
+                if len(v) == 2:
+                    stat_dict[v[0]] += int(v[1])
+    with open(args.output + ".stats", "w") as out_stats:
+        for k, v in stat_dict.items():
+            logger.info("%s %d" % (k, v))
+            out_stats.write("%s %d\n" % (k, v))
+    logger.info("Finished barcode calling")
+
+
+def extract_barcodes_single_thread(input_file, mode):
+    logger.info("Extracting from " + input_file)
+    handler = ListReadHandler()
+    BarcodeCaller(_detectors(mode, 1)[0], handler).process(input_file)
+    logger.info("Finished barcode extraction")
+    return handler.read_storage
+
+
+def extract_barcodes_in_parallel(input_file, mode, threads):
+    logger.info("Extracting from " + input_file)
+    records = open_reads(input_file, skip_secondary=True)
+    if records is None:
+        logger.error("Unknown file format " + input_file)
+        sys.exit(-1)
+    handler = ListReadHandler()
+    caller = BarcodeCaller(_detectors(mode, 1)[0], handler)
+    for chunk in read_chunks(records):
+        caller.process_chunk(chunk)
+    logger.info("Finished barcode extraction")
+    return handler.read_storage
+
+
+def set_logger(logger_instance):
+    logger_instance.setLevel(logging.INFO)
+    if not logger_instance.handlers:
+        ch = logging.StreamHandler(sys.stdout)
+        ch.setLevel(logging.INFO)
+        ch.setFormatter(logging.Formatter("%(asctime)s - %(levelname)s - %(message)s"))
+        logger_instance.addHandler(ch)
+
+
+def parse_args(sys_argv):
+    p = argparse.ArgumentParser(formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--output", "-o", type=str, help="output prefix name", required=True)
+    p.add_argument("--mode", type=str, help="mode to be used", choices=BARCODE_CALLING_MODES.keys(), default="double")
+    p.add_argument("--input", "-i", type=str, help="input reads in [gzipped] FASTA, FASTQ, BAM, SAM", required=True)
+    p.add_argument("--threads", "-t", type=int, help="threads to use (16)", default=16)
+    p.add_argument("--tmp_dir", type=str, help="folder for temporary files (unused: no temporary files are written)")
+    p.add_argument("--gpus", type=int, default=1, help="number of MI355X devices of this node to shard chunks over")
+    return p.parse_args(sys_argv)
+
+
+def main(sys_argv):
+    args = parse_args(sys_argv)
+    set_logger(logger)
+    if args.mode not in BARCODE_CALLING_MODES:
+        raise KeyError(args.mode)          # the reference's default 'double' is not a valid key either
+    if args.threads == 1:
+        process_single_thread(args)
+    else:
+        process_in_parallel(args)
+
+
+if __name__ == "__main__":
+    try:
+        main(sys.argv[1:])
+    except SystemExit:
+        raise
+    except:  # noqa: E722  (same catch-all and exit code as the reference :383-391)
+        print_exc()
+        sys.exit(-1)

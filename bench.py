@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from badger_amd import _native, synth  # noqa: E402
+from badger_amd import dist as bdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -62,9 +63,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = bdist.env_rank()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
@@ -73,10 +72,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    bdist.init(backend="nccl", device=dev)           # RCCL; only the barrier and the clock use it
 
     # ---- inputs, resident in HBM before the clock starts
     wl = synth.make_whitelist(args.whitelist)
@@ -113,23 +109,7 @@ def main():
     ctx.profile(True)
     ctx.profile_reset()
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    barrier()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = bdist.timed(step, args.steps, dev)    # barrier + sync, K steps, sync + barrier, max over ranks
     prof = ctx.profile_read()
     ctx.profile(False)
 
@@ -169,8 +149,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(bases, off_u, wl, 100000, 48)
         print(json.dumps(line))
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        bdist.barrier(dev)
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

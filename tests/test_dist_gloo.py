@@ -1,0 +1,56 @@
+"""The N>1 path on CPU: world_size 2 over gloo.  Partitioning, the rank-ordered gather and the
+max-over-ranks clock.  (The per-shard arithmetic is the oracle here -- no GPU in this tier.)"""
+import os
+import socket
+import time
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from badger_amd import dist as bdist, synth
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    from oracle import pyoracle as orc
+    bdist.init(backend="gloo")
+    wl = synth.make_whitelist(500)
+    bases, off = synth.make_reads(301, wl, seed=5)
+    b, o = bases.numpy(), off.numpy().astype(np.uint64)
+    recs = bdist.extract_sharded(lambda bb, oo, u: orc.extract_batch(bb, oo, u, threads=1), b, o, 12)
+    t = bdist.timed(lambda: time.sleep(0.05 * (rank + 1)), 2)
+    if rank == 0:
+        whole = orc.extract_batch(b, o, 12, threads=1)
+        q.put((bool((recs == whole).all()), len(recs), t))
+    bdist.barrier()
+
+
+def test_partition_covers_everything():
+    for n in (0, 1, 7, 8, 100, 1000003):
+        for w in (1, 2, 3, 8):
+            parts = [bdist.partition(n, w, r) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
+
+
+def test_world2_gloo_sharded_extract_and_clock():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, n, t = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert same and n == 301
+    assert t >= 0.19          # max over ranks: rank 1 sleeps 2 x 0.1 s
