@@ -110,100 +110,160 @@ void k_nearest_scan(const uint32_t* __restrict__ q, const uint32_t* __restrict__
   }
 }
 
-// ---- probe path, levels 0 and 1: one query per lane ---------------------------
+// ---- probe path ----------------------------------------------------------------
+// Pass 1 (k_nearest_pairs), one query per lane.  A 16-mer is four blocks of four bases.  A
+// whitelist entry within Hamming distance 2 of the query agrees with it on at least two whole
+// blocks, so it sits in one of six buckets keyed by a pair of blocks (6 tables, 65,536 buckets
+// each, ~nw/65536 entries per bucket).  Scanning those six buckets settles distance 0 and 1
+// completely (equal-length strings at Levenshtein distance 1 differ by one substitution) and
+// finds every distance-2 entry that is two substitutions away.  An entry is counted in the
+// first pair of agreeing blocks only, so ties are exact.
+// Pass 2 (k_nearest_delins), 16 lanes per query that still has no hit below distance 2: the
+// remaining distance-2 entries are one deletion + one insertion away, i.e. share a 15-mer
+// deletion variant with the query.  Lane i probes del(q,i) in a 2^30-bit map of all deletion
+// variants of the whitelist; only on a hit are the 64 re-insertions looked up.
+struct PairTables {
+    const uint32_t* off;     // [6][65537]
+    const uint2* ent;        // [6][nw] {rank, caller index}
+    const uint32_t* delmap;  // 2^30 bits
+    uint32_t nw;
+};
+
+__device__ __forceinline__ uint32_t pair_key(uint32_t r, int p)
+{
+    // pairs (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); block k = bits [8k, 8k+8)
+    const int bi = p < 3 ? 0 : (p < 5 ? 1 : 2);
+    const int bj = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
+    return ((r >> (8 * bi)) & 0xFFu) | (((r >> (8 * bj)) & 0xFFu) << 8);
+}
+
+__device__ __forceinline__ int canonical_pair(uint32_t x)
+{
+    const bool c0 = (x & 0xFFu) == 0, c1 = (x & 0xFF00u) == 0, c2 = (x & 0xFF0000u) == 0, c3 = (x & 0xFF000000u) == 0;
+    return (c0 && c1) ? 0 : (c0 && c2) ? 1 : (c0 && c3) ? 2 : (c1 && c2) ? 3 : (c1 && c3) ? 4 : 5;
+}
+
+__device__ __forceinline__ uint32_t hamming16(uint32_t x)
+{
+    return __popc((x | (x >> 1)) & 0x55555555u);
+}
+
 __global__ __launch_bounds__(256)
-void k_nearest_l01(const uint32_t* __restrict__ q, uint32_t nq, WlIndex ix, uint32_t max_ed,
-                   uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
-                   uint32_t* __restrict__ list2, uint32_t* __restrict__ counters)
+void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t nq, PairTables pt, uint32_t max_ed,
+                     uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
+                     uint32_t* __restrict__ list2, uint32_t* __restrict__ counters)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= nq) return;
     const uint32_t qq = q[i];
-    uint32_t o = 0;
-    if (wl_lookup(ix, qq, o)) { best_idx[i] = o; best_ed[i] = 0; n_ties[i] = 1; return; }
-    if (max_ed >= 1u) {
-        uint32_t bidx = NONE_IDX, ties = 0;
-        for (int pos = 0; pos < 16; ++pos) {
+    uint32_t best = 3u, bidx = NONE_IDX, ties = 0u;
 #pragma unroll
-            for (uint32_t x = 1; x < 4; ++x) {
-                if (wl_lookup(ix, qq ^ (x << (2 * pos)), o)) { ++ties; bidx = o < bidx ? o : bidx; }
+    for (int p = 0; p < 6; ++p) {
+        const uint32_t key = pair_key(qq, p);
+        const uint32_t* o = pt.off + (size_t)p * 65537u + key;
+        const uint32_t lo = o[0], hi = o[1];
+        const uint2* e = pt.ent + (size_t)p * pt.nw;
+        for (uint32_t k = lo; k < hi; ++k) {
+            const uint2 w = e[k];
+            const uint32_t x = qq ^ w.x;
+            const uint32_t h = hamming16(x);
+            if (h <= 2u && h <= best && canonical_pair(x) == p) {
+                if (h < best) { best = h; bidx = w.y; ties = 1u; }
+                else { ties++; bidx = w.y < bidx ? w.y : bidx; }
             }
         }
-        if (ties) { best_idx[i] = bidx; best_ed[i] = 1; n_ties[i] = (uint16_t)ties; return; }
     }
-    if (max_ed >= 2u) { list2[atomicAdd(&counters[0], 1u)] = i; return; }
-    best_idx[i] = NONE_IDX; best_ed[i] = 255; n_ties[i] = 0;
+    if (best > max_ed) { best = 255u; bidx = NONE_IDX; ties = 0u; }
+    best_idx[i] = bidx; best_ed[i] = (uint8_t)(best == 3u ? 255u : best);
+    n_ties[i] = (uint16_t)(ties > 0xFFFFu ? 0xFFFFu : ties);
+    if (max_ed >= 2u && (best == 2u || best == 3u || best == 255u)) list2[atomicAdd(&counters[0], 1u)] = i;
 }
 
-// ---- probe path, level 2: one wave per unmatched query ------------------------
 __device__ __forceinline__ uint32_t low_mask(int bases) { return bases >= 16 ? 0xFFFFFFFFu : ((1u << (2 * bases)) - 1u); }
 
 __global__ __launch_bounds__(256)
-void k_nearest_l2(const uint32_t* __restrict__ q, const uint32_t* __restrict__ list2,
-                  const uint32_t* counters, WlIndex ix,
-                  uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
-                  uint32_t* __restrict__ list3, uint32_t* counters_out)
+void k_build_delmap(const uint32_t* __restrict__ wl, uint32_t nw, uint32_t* __restrict__ delmap)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t w = g >> 4; const int i = (int)(g & 15u);
+    if (w >= nw) return;
+    const uint32_t r = wl[w];
+    const uint32_t lm = low_mask(i);
+    const uint32_t d = ((r & lm) | ((r >> 2) & ~lm)) & 0x3FFFFFFFu;
+    atomicOr(&delmap[d >> 5], 1u << (d & 31u));
+}
+
+__global__ __launch_bounds__(256)
+void k_nearest_delins(const uint32_t* __restrict__ q, const uint32_t* __restrict__ list2,
+                      const uint32_t* counters, WlIndex ix, const uint32_t* __restrict__ delmap,
+                      uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
+                      uint32_t* __restrict__ list3, uint32_t* counters_out)
 {
     const uint32_t n2 = counters[0];
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t nwaves = gridDim.x * 4u;
-    for (uint32_t s = wave; s < n2; s += nwaves) {
-        const uint32_t qi = list2[s];
-        const uint32_t qq = q[qi];
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const uint32_t gq = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u + (uint32_t)grp;     // query slot of this 16-lane group
+    const uint32_t ngroups = gridDim.x * 16u;
+    for (uint32_t s0 = gq - (uint32_t)grp; s0 < n2; s0 += ngroups) {      // wave-uniform loop bound
+        const uint32_t s = s0 + (uint32_t)grp;
+        const bool on = s < n2;
+        const uint32_t qi = on ? list2[s] : 0u;
+        const uint32_t qq = on ? q[qi] : 0u;
         uint32_t found[4] = { 0, 0, 0, 0 }; int nf = 0; bool overflow = false;
-        auto probe = [&](uint32_t cand) {
-            uint32_t o;
-            if (wl_lookup(ix, cand, o)) {
-                bool dup = false;
-                for (int k = 0; k < 4; ++k) dup |= (k < nf && found[k] == o);
-                if (!dup) { if (nf < 4) { found[0] = nf == 0 ? o : found[0]; found[1] = nf == 1 ? o : found[1];
-                                          found[2] = nf == 2 ? o : found[2]; found[3] = nf == 3 ? o : found[3]; ++nf; }
-                            else overflow = true; }
+        // deletion variant of this lane; equal neighbours give equal variants -> keep the first of a run
+        const int i = sub;
+        const uint32_t lm = low_mask(i);
+        const uint32_t d = ((qq & lm) | ((qq >> 2) & ~lm)) & 0x3FFFFFFFu;
+        const bool dup_del = i > 0 && (((qq >> (2 * i)) ^ (qq >> (2 * i - 2))) & 3u) == 0u;
+        const bool hit = on && !dup_del && ((delmap[d >> 5] >> (d & 31u)) & 1u);
+        if (hit) {
+            for (int t = 0; t < 64; ++t) {
+                const int sl = t >> 2; const uint32_t c = (uint32_t)t & 3u;
+                // inserting c next to an equal base repeats the previous slot's string
+                if (sl > 0 && ((d >> (2 * sl - 2)) & 3u) == c) continue;
+                const uint32_t sm = low_mask(sl);
+                const uint32_t r = (d & sm) | (c << (2 * sl)) | ((d & ~sm) << 2);
+                if (hamming16(r ^ qq) <= 2u) continue;          // pass 1 has it (or it is the query itself)
+                uint32_t o;
+                if (wl_lookup(ix, r, o)) {
+                    const bool dup = (nf > 0 && found[0] == o) || (nf > 1 && found[1] == o) ||
+                                     (nf > 2 && found[2] == o) || (nf > 3 && found[3] == o);
+                    if (!dup) {
+                        if (nf < 4) { found[0] = nf == 0 ? o : found[0]; found[1] = nf == 1 ? o : found[1];
+                                      found[2] = nf == 2 ? o : found[2]; found[3] = nf == 3 ? o : found[3]; ++nf; }
+                        else overflow = true;
+                    }
+                }
             }
-        };
-        // (a) two substitutions: 120 position pairs x 9 letter pairs
-        for (int t = lane; t < 1080; t += 64) {
-            const int pi = t / 9, xy = t - pi * 9;
-            // unrank pair index -> (i<j): rows of decreasing length 15,14,...,1
-            int i = 0, rem = pi;
-            while (rem >= 15 - i) { rem -= 15 - i; ++i; }
-            const int j = i + 1 + rem;
-            const uint32_t x = 1u + (uint32_t)(xy / 3), y = 1u + (uint32_t)(xy % 3);
-            probe(qq ^ (x << (2 * i)) ^ (y << (2 * j)));
         }
-        // (b) delete base i, insert letter c at slot sl of the 15-mer
-        for (int t = lane; t < 1024; t += 64) {
-            const int i = t >> 6, sl = (t >> 2) & 15; const uint32_t c = (uint32_t)t & 3u;
-            const uint32_t lm = low_mask(i);
-            const uint32_t d = (qq & lm) | ((qq >> 2) & ~lm);           // 15 bases (top slot is garbage-free: zero)
-            const uint32_t sm = low_mask(sl);
-            const uint32_t r = (d & sm) | (c << (2 * sl)) | ((d & ~sm) << 2);
-            // r == q or one substitution away cannot be in the whitelist here (levels 0/1 found nothing)
-            probe(r);
-        }
-        // wave merge: distinct hits, lowest caller index
-        uint32_t bidx = NONE_IDX, ties = 0;
-        const bool any_over = __ballot(overflow) != 0;
+        // merge inside the 16-lane group: distinct hits, lowest caller index
+        const unsigned long long gmask = 0xFFFFull << (16 * grp);
+        const bool any_over = (__ballot(overflow) & gmask) != 0;
+        uint32_t add = 0, midx = NONE_IDX;
         int pending = nf;
         while (true) {
-            const unsigned long long bal = __ballot(pending > 0);
-            if (!bal) break;
-            const int src = __builtin_ctzll(bal);
+            const unsigned long long bal_all = __ballot(pending > 0);
+            if (!bal_all) break;
+            const unsigned long long bal = bal_all & gmask;
+            const int src = bal ? __builtin_ctzll(bal) : lane;
             const uint32_t v = __shfl(found[0], src);
-            ++ties; bidx = v < bidx ? v : bidx;
-            // drop v everywhere (a lane's list holds distinct values: at most one match)
-            const bool h0 = pending > 0 && found[0] == v, h1 = pending > 1 && found[1] == v;
-            const bool h2 = pending > 2 && found[2] == v, h3 = pending > 3 && found[3] == v;
-            if (h0) { found[0] = found[1]; found[1] = found[2]; found[2] = found[3]; }
-            else if (h1) { found[1] = found[2]; found[2] = found[3]; }
-            else if (h2) { found[2] = found[3]; }
-            if (h0 || h1 || h2 || h3) --pending;
+            if (bal) {
+                ++add; midx = v < midx ? v : midx;
+                const bool h0 = pending > 0 && found[0] == v, h1 = pending > 1 && found[1] == v;
+                const bool h2 = pending > 2 && found[2] == v, h3 = pending > 3 && found[3] == v;
+                if (h0) { found[0] = found[1]; found[1] = found[2]; found[2] = found[3]; }
+                else if (h1) { found[1] = found[2]; found[2] = found[3]; }
+                else if (h2) { found[2] = found[3]; }
+                if (h0 || h1 || h2 || h3) --pending;
+            }
         }
-        if (lane == 0) {
-            if (any_over) { list3[atomicAdd(&counters_out[1], 1u)] = qi; }
-            else if (ties) { best_idx[qi] = bidx; best_ed[qi] = 2; n_ties[qi] = (uint16_t)ties; }
-            else { best_idx[qi] = NONE_IDX; best_ed[qi] = 255; n_ties[qi] = 0; }
+        if (on && sub == 0) {
+            if (any_over) list3[atomicAdd(&counters_out[1], 1u)] = qi;
+            else if (add) {
+                const uint32_t cur_ed = best_ed[qi];
+                uint32_t t = add, bi = midx;
+                if (cur_ed == 2u) { t += n_ties[qi]; const uint32_t o = best_idx[qi]; bi = o < bi ? o : bi; }
+                best_idx[qi] = bi; best_ed[qi] = 2; n_ties[qi] = (uint16_t)(t > 0xFFFFu ? 0xFFFFu : t);
+            }
         }
     }
 }
@@ -244,6 +304,33 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
     BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_prefix.p, prefix.data(), sizeof(uint32_t) * prefix.size(), hipMemcpyHostToDevice));
     BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_bitmap.p, bitmap.data(), sizeof(uint32_t) * bitmap.size(), hipMemcpyHostToDevice));
     ctx->w_n = nw; ctx->w_pbits = pbits; ctx->w_bbits = bbits;
+
+    // six block-pair tables (counting sort by the 16-bit pair key)
+    std::vector<uint32_t> poff(6u * 65537u, 0u);
+    std::vector<uint2> pent(6ull * nw);
+    for (int p = 0; p < 6; ++p) {
+        const int bi = p < 3 ? 0 : (p < 5 ? 1 : 2);
+        const int bj = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
+        uint32_t* o = poff.data() + (size_t)p * 65537u;
+        auto key = [&](uint32_t r) { return ((r >> (8 * bi)) & 0xFFu) | (((r >> (8 * bj)) & 0xFFu) << 8); };
+        for (uint32_t i = 0; i < nw; ++i) o[key(srt[i]) + 1]++;
+        for (uint32_t k = 0; k < 65536u; ++k) o[k + 1] += o[k];
+        std::vector<uint32_t> fill(o, o + 65536);
+        uint2* e = pent.data() + (size_t)p * nw;
+        for (uint32_t i = 0; i < nw; ++i) { uint2 v; v.x = srt[i]; v.y = order[i]; e[fill[key(srt[i])]++] = v; }
+    }
+    if ((rc = bdg_reserve(ctx, ctx->w_poff, sizeof(uint32_t) * poff.size()))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->w_pent, sizeof(uint2) * pent.size()))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->w_delmap, size_t(1) << 27))) return rc;          // 2^30 bits
+    BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_poff.p, poff.data(), sizeof(uint32_t) * poff.size(), hipMemcpyHostToDevice));
+    BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_pent.p, pent.data(), sizeof(uint2) * pent.size(), hipMemcpyHostToDevice));
+    BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->w_delmap.p, 0, size_t(1) << 27, ctx->stream));
+    {
+        const uint64_t threads = 16ull * nw;
+        hipLaunchKernelGGL(k_build_delmap, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
+                           static_cast<const uint32_t*>(ctx->w_sorted.p), nw, static_cast<uint32_t*>(ctx->w_delmap.p));
+    }
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return BDG_OK;
 }
 
@@ -273,16 +360,18 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_
     BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 16, st));
     WlIndex ix{ srt, org, static_cast<const uint32_t*>(ctx->w_prefix.p), static_cast<const uint32_t*>(ctx->w_bitmap.p),
                 ctx->w_n, 32 - ctx->w_pbits, 32 - ctx->w_bbits };
+    PairTables pt{ static_cast<const uint32_t*>(ctx->w_poff.p), static_cast<const uint2*>(ctx->w_pent.p),
+                   static_cast<const uint32_t*>(ctx->w_delmap.p), ctx->w_n };
     {
-        ScopedKernelTimer tm(ctx, "k_nearest_l01");
-        hipLaunchKernelGGL(k_nearest_l01, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, nq, ix, max_ed,
+        ScopedKernelTimer tm(ctx, "k_nearest_pairs");
+        hipLaunchKernelGGL(k_nearest_pairs, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, nq, pt, max_ed,
                            d_best_idx, d_best_ed, d_n_ties, list2, counters);
     }
     if (max_ed >= 2) {
         {
-            ScopedKernelTimer tm(ctx, "k_nearest_l2");
-            const uint32_t grid = std::min<uint32_t>((nq + 3) / 4, 256u * 8u);
-            hipLaunchKernelGGL(k_nearest_l2, dim3(grid), dim3(256), 0, st, d_q, list2, counters, ix,
+            ScopedKernelTimer tm(ctx, "k_nearest_delins");
+            const uint32_t grid = std::min<uint32_t>((nq + 15) / 16, 256u * 8u);
+            hipLaunchKernelGGL(k_nearest_delins, dim3(grid), dim3(256), 0, st, d_q, list2, counters, ix, pt.delmap,
                                d_best_idx, d_best_ed, d_n_ties, list3, counters);
         }
         // queries whose hit list overflowed (one lane found more than 4 distinct entries): exhaustive
