@@ -6,18 +6,24 @@
 // (kmer_indexer.py:49-75), detect_exact_positions (:85-114) and the SSW local
 // alignment behind align_pattern_ssw (:42-51).
 //
-// Three launches per batch, no host round trip in between:
-//   k_scan_reads     one wave per read, 16 B/lane coalesced loads straight from the
-//                    ASCII buffer: polyT start of both strands (the reverse strand is
-//                    derived from the same bytes: T-windows of the reverse complement
+// Launches per batch, no host round trip in between:
+//   k_scan_reads     one wave per read, 16 B/lane coalesced loads straight from the ASCII
+//                    buffer: polyT start of both strands (T-windows of the reverse complement
 //                    are A-windows of the read) and every R1 6-mer hit of both strands
-//                    (4096-entry 2-bit LUT in LDS), appended to a window queue with one
-//                    wave-aggregated atomic per kilobase.
-//   k_sw_windows     one lane per queued window: 22 x <=39 Smith-Waterman in registers
-//                    (22 row registers, the pattern is a compile-time constant so a
-//                    column costs one 22-bit equality mask), SSW's end-cell tie rule
-//                    folded into a single running max over packed (score,col,row) keys;
-//                    per read-strand winner by 64-bit atomicMax on (score, first hit).
+//                    (4096-entry 2-bit LUT in LDS).  The <=16 hits a lane finds in its vector
+//                    form one CLUSTER {read, strand, first hit, 16-bit offset mask}; clusters
+//                    are staged in LDS and flushed with one global reservation per block into
+//                    queue A (first hit left of polyT: relaxed search applies) or queue B.
+//   k_strict_filter  queue B only matters if an alignment reaches score 17, which implies
+//                    semi-global edit distance <= 5: Myers' 22-bit search per hit; survivors
+//                    join queue A as single-hit clusters.
+//   k_sw_clusters    one lane per cluster: ONE 22-row Smith-Waterman pass over the union of the
+//                    cluster's windows (all start at the first hit's window start, so the
+//                    first hit's strict and relaxed windows are column prefixes of the union:
+//                    their results are snapshots of the running key).  If the union cannot beat
+//                    the first hit, no later hit of the cluster can replace it as "first
+//                    strictly best" (common.py:102-103) and they are skipped; otherwise they
+//                    are re-queued (queue C) and aligned one by one by a second launch.
 //   k_finalize_reads one lane per read: delta checks, reverse pass for strict hits,
 //                    polyT re-search, barcode/UMI slicing, strand choice, 32-byte record.
 //
@@ -44,11 +50,14 @@ constexpr uint32_t EQ0 = eq_mask(0), EQ1 = eq_mask(1), EQ2 = eq_mask(2), EQ3 = e
 constexpr int KEY_SHIFT = 11;                 // score | (63-col) << 5 | (31-row)
 constexpr int32_t ONE = 1 << KEY_SHIFT;
 
-enum { C_NHITS = 0, C_BADREAD = 1, C_NWINDOWS = 2 };
+enum { C_NA = 0, C_BADREAD = 1, C_NWINDOWS = 2, C_NB = 3, C_NKEPT = 4, C_NC = 5, C_NHITS = 6 };
 
 constexpr int READS_PER_BLOCK = 64;
-constexpr uint32_t HITBUF = 4096;          // per-block LDS staging of queue entries (32 KiB)
-constexpr uint64_t HIT_HOLE = ~0ull;       // unused queue slot (skipped by k_sw_windows)
+constexpr uint32_t HITBUF = 1024;          // per-block LDS staging of clusters (16 KiB)
+constexpr uint32_t HOLE_R = 0xFFFFFFFFu;   // unused queue slot
+
+// queue entry: {read, (pos << 1) | strand, offset mask of the hits (bit 0 = first hit), unused}
+typedef uint4 QEnt;
 
 __device__ __forceinline__ uint32_t range_mask16(int64_t lo, int64_t hi)
 {
@@ -65,16 +74,18 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                   const uint64_t* __restrict__ off, uint32_t n,
                   const uint32_t* __restrict__ tables,
                   int32_t* __restrict__ polyt,
-                  uint64_t* __restrict__ hits, uint64_t hits_cap,
+                  QEnt* __restrict__ qa, QEnt* __restrict__ qb, uint64_t qcap,
                   unsigned long long* __restrict__ counters)
 {
     __shared__ uint32_t s_kmer[256];     // 4096 x 2 bits: bit0 R1 6-mer, bit1 reverse-complement of one
     __shared__ uint2 s_cls[256];         // byte -> {isT | isA<<16, isN | bad<<16}
-    __shared__ uint64_t s_hits[HITBUF];  // this block's queue entries, flushed with ONE global reservation
-    __shared__ uint32_t s_nhits;
-    __shared__ unsigned long long s_base;
+    __shared__ QEnt s_ent[HITBUF];       // this block's clusters
+    __shared__ uint16_t s_slot[HITBUF];  // class bit (15) | slot inside the class
+    __shared__ int32_t s_pt[READS_PER_BLOCK][2];
+    __shared__ uint32_t s_nent, s_cls_cnt[2];
+    __shared__ unsigned long long s_base[2];
     const int tid = threadIdx.x;
-    if (tid == 0) s_nhits = 0;
+    if (tid == 0) { s_nent = 0; s_cls_cnt[0] = 0; s_cls_cnt[1] = 0; }
     s_kmer[tid] = tables[tid];
     s_cls[tid] = reinterpret_cast<const uint2*>(tables + 256)[tid];
     __syncthreads();
@@ -82,6 +93,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     const int lane = tid & 63, wv = tid >> 6;
     const uint64_t r_begin = (uint64_t)blockIdx.x * READS_PER_BLOCK;
     const uint64_t r_end = r_begin + READS_PER_BLOCK < n ? r_begin + READS_PER_BLOCK : n;
+    uint32_t nhits_stat = 0;
 
     for (uint64_t r = r_begin + wv; r < r_end; r += 4) {
         const uint64_t s = off[r];
@@ -171,8 +183,9 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             if (__ballot(bad != 0 && worker)) {
                 if (bad != 0 && worker) atomicMin(&counters[C_BADREAD], (unsigned long long)r);
             }
-            // append the hits of this step to the block's LDS staging buffer
-            const uint32_t cnt = __popc(hitF) + __popc(hitR);
+            // one cluster per lane and strand: first hit + offsets of the others
+            nhits_stat += __popc(hitF) + __popc(hitR);
+            const uint32_t cnt = (hitF ? 1u : 0u) + (hitR ? 1u : 0u);
             uint32_t incl = cnt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -182,82 +195,118 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             const uint32_t total = __shfl(incl, 63);
             if (total) {
                 uint32_t slot = 0;
-                if (lane == 63) slot = atomicAdd(&s_nhits, total);
+                if (lane == 63) slot = atomicAdd(&s_nent, total);
                 slot = __shfl(slot, 63);
                 const bool fits = slot + total <= HITBUF;
                 unsigned long long gbase = 0;
-                if (!fits) {            // staging full (pathological read): this step goes straight to the queue
-                    if (lane == 63) gbase = atomicAdd(&counters[C_NHITS], (unsigned long long)total);
+                if (!fits) {            // staging full (pathological read): this step goes straight to queue A
+                    if (lane == 63) gbase = atomicAdd(&counters[C_NA], (unsigned long long)total);
                     gbase = __shfl(gbase, 63);
-                    for (uint32_t h = slot + lane; h < HITBUF && h < slot + total; h += 64) s_hits[h] = HIT_HOLE;
+                    for (uint32_t h = slot + lane; h < HITBUF && h < slot + total; h += 64) s_ent[h].x = HOLE_R;
                 }
                 unsigned long long idx = (fits ? slot : gbase) + incl - cnt;
-                uint32_t m = hitF;
-                while (m) {
-                    const int k = __builtin_ctz(m); m &= m - 1;
-                    const uint64_t ent = r | (((uint64_t)(p0 + k) << 1) << 32);
-                    if (fits) s_hits[idx] = ent; else if (idx < hits_cap) hits[idx] = ent;
+                if (hitF) {
+                    const int k0 = __builtin_ctz(hitF);
+                    const QEnt e = make_uint4((uint32_t)r, (uint32_t)(p0 + k0) << 1, hitF >> k0, 0u);
+                    if (fits) s_ent[idx] = e; else if (idx < qcap) qa[idx] = e;
                     ++idx;
                 }
-                m = hitR;
-                while (m) {
-                    const int k = __builtin_ctz(m); m &= m - 1;
-                    const uint64_t ent = r | ((((uint64_t)(L - KMER - (p0 + k)) << 1) | 1ull) << 32);
-                    if (fits) s_hits[idx] = ent; else if (idx < hits_cap) hits[idx] = ent;
-                    ++idx;
+                if (hitR) {
+                    const int k1 = 31 - __builtin_clz(hitR);
+                    const QEnt e = make_uint4((uint32_t)r, ((uint32_t)(L - KMER - (p0 + k1)) << 1) | 1u,
+                                              __brev(hitR) >> (31 - k1), 0u);
+                    if (fits) s_ent[idx] = e; else if (idx < qcap) qa[idx] = e;
                 }
             }
         }
-        if (lane == 0) { polyt[2 * r] = ptF; polyt[2 * r + 1] = ptR; }
+        if (lane == 0) { polyt[2 * r] = ptF; polyt[2 * r + 1] = ptR; s_pt[r - r_begin][0] = ptF; s_pt[r - r_begin][1] = ptR; }
     }
-    // flush: one global reservation per block, coalesced 8-byte stores
+    // flush.  A cluster whose first hit lies left of polyT can win the relaxed search and always gets
+    // a full alignment (queue A); the others only matter if they reach score 17 and go through the
+    // cheap filter first (queue B).  One global reservation per block and queue.
     __syncthreads();
-    const uint32_t nst = s_nhits < HITBUF ? s_nhits : HITBUF;
-    if (tid == 0 && nst) s_base = atomicAdd(&counters[C_NHITS], (unsigned long long)nst);
-    __syncthreads();
-    if (nst) {
-        const unsigned long long gb = s_base;
-        for (uint32_t h = tid; h < nst; h += 256) if (gb + h < hits_cap) hits[gb + h] = s_hits[h];
+    const uint32_t nst = s_nent < HITBUF ? s_nent : HITBUF;
+    for (uint32_t h = tid; h < nst; h += 256) {
+        const QEnt e = s_ent[h];
+        uint32_t cls = 0, need = 1;
+        if (e.x != HOLE_R) {
+            const int32_t pt = s_pt[e.x - (uint32_t)r_begin][e.y & 1u];
+            cls = (pt >= 0 && (int64_t)(e.y >> 1) + KMER <= (int64_t)pt + 1) ? 0u : 1u;
+            need = cls ? __popc(e.z) : 1u;              // queue B holds single hits: the filter is per window
+        }
+        const uint32_t slot = atomicAdd(&s_cls_cnt[cls], need);
+        s_slot[h] = (uint16_t)((cls << 15) | slot);
     }
+    __syncthreads();
+    if (tid < 2 && s_cls_cnt[tid])
+        s_base[tid] = atomicAdd(&counters[tid == 0 ? C_NA : C_NB], (unsigned long long)s_cls_cnt[tid]);
+    __syncthreads();
+    for (uint32_t h = tid; h < nst; h += 256) {
+        const uint32_t sl = s_slot[h];
+        const QEnt e = s_ent[h];
+        unsigned long long g = s_base[sl >> 15] + (sl & 0x7FFFu);
+        if (!(sl >> 15)) { if (g < qcap) qa[g] = e; }
+        else if (e.x == HOLE_R) { if (g < qcap) qb[g] = e; }
+        else {
+            uint32_t m = e.z;
+            while (m) {
+                const int j = __builtin_ctz(m); m &= m - 1;
+                if (g < qcap) qb[g] = make_uint4(e.x, e.y + ((uint32_t)j << 1), 1u, 0u);
+                ++g;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nhits_stat += __shfl_xor(nhits_stat, d);
+    if (lane == 0 && nhits_stat) atomicAdd(&counters[C_NHITS], (unsigned long long)nhits_stat);
 }
 
 // ---------------------------------------------------------------------------
-// Window loader: 40 characters of strand `strand` starting at strand position x0,
+// Window loader: 4*NW characters of strand `strand` starting at strand position x0,
 // walking in direction dir, as raw forward bytes (char k = byte k of w[]).
 // Characters outside the read are garbage; the caller masks them (k >= n).
 // ---------------------------------------------------------------------------
+template <int NW>
 __device__ __forceinline__ void load_block(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                                            uint64_t rs, int64_t L, int strand, int64_t x0, int dir,
-                                           uint32_t (&w)[10])
+                                           uint32_t (&w)[NW])
 {
     const int64_t f0 = strand ? (L - 1 - x0) : x0;
     const bool asc = (dir > 0) != (strand != 0);
-    const int64_t a = (int64_t)rs + (asc ? f0 : f0 - 39);
+    const int64_t a = (int64_t)rs + (asc ? f0 : f0 - (4 * NW - 1));
     const int64_t a_al = a & ~3ll;
     const uint32_t sh = (uint32_t)(a - a_al);
-    uint32_t t[11];
+    uint32_t t[NW + 1];
 #pragma unroll
-    for (int i = 0; i < 11; ++i) {
+    for (int i = 0; i < NW + 1; ++i) {
         const int64_t idx = a_al + 4 * i;
         t[i] = (idx >= 0 && (uint64_t)idx + 4 <= total_rounded)
                    ? *reinterpret_cast<const uint32_t*>(bases + idx) : 0u;
     }
-    uint32_t u[10];
+    uint32_t u[NW];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) u[i] = __builtin_amdgcn_alignbyte(t[i + 1], t[i], sh);
+    for (int i = 0; i < NW; ++i) u[i] = __builtin_amdgcn_alignbyte(t[i + 1], t[i], sh);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) w[i] = asc ? u[i] : __builtin_bswap32(u[9 - i]);
+    for (int i = 0; i < NW; ++i) w[i] = asc ? u[i] : __builtin_bswap32(u[NW - 1 - i]);
 }
 
-__device__ __forceinline__ bool block_has_N(const uint32_t (&w)[10])
+template <int NW>
+__device__ __forceinline__ bool block_has_N(const uint32_t (&w)[NW])
 {
     uint32_t any = 0;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < NW; ++i) {
         const uint32_t x = w[i] ^ 0x4E4E4E4Eu;
         any |= (x - 0x01010101u) & ~x & 0x80808080u;
     }
     return any != 0;
+}
+
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 // ---------------------------------------------------------------------------
@@ -265,18 +314,22 @@ __device__ __forceinline__ bool block_has_N(const uint32_t (&w)[10])
 // (columns), +1/-1/-1 linear gaps, N scores 0.  Returns the maximum over all cells of
 //   (H << 11) | (63 - col) << 5 | (31 - row)
 // i.e. the best score, its first column, and the smallest row in that column --
-// the end cell SSW reports (see oracle/badger_oracle.c, sw_scan).
+// the end cell SSW reports (see oracle/badger_oracle.c, sw_scan).  The running key
+// after column n1-1 / n2-1 is returned in snap1 / snap2: the result for the window
+// made of the first n1 / n2 columns.
 // REV: rows are pattern[end_read - r] (reverse pass of ssw_align).
 // ---------------------------------------------------------------------------
-template <bool WITH_N, bool REV>
-__device__ __forceinline__ uint32_t sw_block(uint32_t (&w)[10], int n, uint32_t comp, int end_read)
+template <int NW, bool WITH_N, bool REV>
+__device__ __forceinline__ uint32_t sw_block(uint32_t (&w)[NW], int ndw, int n, uint32_t comp, int end_read,
+                                             int n1, int n2, uint32_t& snap1, uint32_t& snap2)
 {
     int32_t hs[R1_LEN];
 #pragma unroll
     for (int i = 0; i < R1_LEN; ++i) hs[i] = 0;
     int32_t acc = 0;
+    uint32_t s1 = 0, s2 = 0;
 #pragma nounroll
-    for (int d = 0; d < 10; ++d) {
+    for (int d = 0; d < ndw; ++d) {
         const uint32_t cur = w[0];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -296,7 +349,7 @@ __device__ __forceinline__ uint32_t sw_block(uint32_t (&w)[10], int n, uint32_t 
 #pragma unroll
             for (int i = 0; i < R1_LEN; ++i) {
                 const int32_t tl = hs[i] - ONE;                                  // H(i, j-1) - 1
-                int32_t dg = (int32_t)(((e >> i) & 1u) << (KEY_SHIFT + 1)) + diag_t;   // H(i-1,j-1) +/- 1
+                int32_t dg = (int32_t)(__builtin_amdgcn_ubfe(e, i, 1) << (KEY_SHIFT + 1)) + diag_t;   // H(i-1,j-1) +/- 1
                 if (WITH_N) dg += dN;
                 const int32_t tu = up - ONE;                                     // H(i-1, j) - 1
                 int32_t h = max(max(dg, tl), tu);
@@ -308,16 +361,14 @@ __device__ __forceinline__ uint32_t sw_block(uint32_t (&w)[10], int n, uint32_t 
                 if (i & 1) acc = max(max(acc, keyprev), key);
                 else keyprev = key;
             }
+            s1 = (j + 1 == n1) ? (uint32_t)acc : s1;
+            s2 = (j + 1 == n2) ? (uint32_t)acc : s2;
         }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) w[i] = w[i + 1];
+        for (int i = 0; i < NW - 1; ++i) w[i] = w[i + 1];
     }
+    snap1 = s1; snap2 = s2;
     return (uint32_t)acc;
-}
-
-__device__ __forceinline__ uint32_t sw_window(uint32_t (&w)[10], int n, uint32_t comp, bool anyN)
-{
-    return anyN ? sw_block<true, false>(w, n, comp, 0) : sw_block<false, false>(w, n, comp, 0);
 }
 
 __device__ __forceinline__ uint64_t make_key(uint32_t acc, uint32_t pos)
@@ -329,62 +380,157 @@ __device__ __forceinline__ uint64_t make_key(uint32_t acc, uint32_t pos)
 }
 
 // ---------------------------------------------------------------------------
-// k_sw_windows: one lane per queued hit (detect_exact_positions loop body,
+// k_strict_filter: one lane per queue-B cluster.  A local alignment of R1 with score >= 17
+// (+1/-1/-1, N = 0) leaves at most 5 of the 22 pattern bases unmatched or mispaired, so R1
+// occurs in the window with semi-global edit distance <= 5.  Myers' 22-bit search decides that
+// at about a tenth of the cost of the alignment; only surviving hits join queue A.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t myers_search(uint32_t (&w)[10], int n, uint32_t comp)
+{
+    uint32_t pv = 0x3FFFFFu, mv = 0u, score = R1_LEN, best = R1_LEN;
+#pragma nounroll
+    for (int d = 0; d < 10; ++d) {
+        const uint32_t cur = w[0];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = d * 4 + b;
+            const uint32_t c = (cur >> (8 * b)) & 0xFFu;
+            const uint32_t code = ((c >> 1) & 3u) ^ (comp << 1);
+            uint32_t eq = (code & 2u) ? ((code & 1u) ? EQ3 : EQ2) : ((code & 1u) ? EQ1 : EQ0);
+            const bool live = j < n;
+            eq = (live && c != (uint32_t)'N') ? eq : 0u;
+            const uint32_t xv = eq | mv;
+            const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+            uint32_t ph = mv | ~(xh | pv);
+            uint32_t mh = pv & xh;
+            score += (ph >> (R1_LEN - 1)) & 1u;
+            score -= (mh >> (R1_LEN - 1)) & 1u;
+            ph <<= 1;                       // search: D[0][j] = 0
+            mh <<= 1;
+            pv = mh | ~(xv | ph);
+            mv = ph & xv;
+            best = (live && score < best) ? score : best;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w[i] = w[i + 1];
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(256)
+void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
+                     const uint64_t* __restrict__ off,
+                     const QEnt* __restrict__ qb, QEnt* __restrict__ qa, uint64_t qcap,
+                     unsigned long long* __restrict__ counters)
+{
+    unsigned long long nb = counters[C_NB];
+    if (nb > qcap) nb = qcap;
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
+    uint32_t nkept = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256ull + (threadIdx.x & ~63); base < nb; base += stride) {
+        const uint64_t g = base + lane;
+        QEnt e = make_uint4(HOLE_R, 0, 0, 0);
+        if (g < nb) e = qb[g];
+        const bool active = e.x != HOLE_R;
+        uint64_t rs = 0; int64_t L = 0;
+        if (active) { rs = off[e.x]; L = (int64_t)(off[e.x + 1] - rs); }
+        const uint32_t strand = e.y & 1u;
+        const int64_t pos = (int64_t)(e.y >> 1);
+        const int64_t ws = pos - (R1_LEN - KMER) > 0 ? pos - (R1_LEN - KMER) : 0;
+        const int64_t we = pos + R1_LEN + 1 < L ? pos + R1_LEN + 1 : L;
+        uint32_t w[10];
+        load_block<10>(bases, total_rounded, rs, L, (int)strand, ws, +1, w);
+        const uint32_t k = myers_search(w, active ? (int)(we - ws) : 0, strand);
+        const bool keep = active && k <= 5u;
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            unsigned long long gb = 0;
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            if (lane == 0) gb = atomicAdd(&counters[C_NA], (unsigned long long)cnt);
+            gb = __shfl(gb, 0);
+            if (keep) {
+                const unsigned long long idx = gb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (idx < qcap) qa[idx] = make_uint4(e.x, e.y, 1u, 0u);
+            }
+            nkept += lane == 0 ? cnt : 0u;
+        }
+    }
+    if (lane == 0 && nkept) atomicAdd(&counters[C_NKEPT], (unsigned long long)nkept);
+}
+
+// ---------------------------------------------------------------------------
+// k_sw_clusters: one lane per cluster (detect_exact_positions loop body,
 // barcode_extraction/common.py:91-103, for the relaxed and the strict search at once).
 // ---------------------------------------------------------------------------
+constexpr int CW = 14;                       // 56 columns: 16 + 15 + 23 = 54 at most
+
 __global__ __launch_bounds__(256)
-void k_sw_windows(const uint8_t* __restrict__ bases, uint64_t total_rounded,
-                  const uint64_t* __restrict__ off, uint32_t n_reads,
-                  const int32_t* __restrict__ polyt,
-                  const uint64_t* __restrict__ hits, uint64_t hits_cap,
-                  unsigned long long* __restrict__ counters,
-                  unsigned long long* __restrict__ keys)
+void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
+                   const uint64_t* __restrict__ off, uint32_t n_reads,
+                   const int32_t* __restrict__ polyt,
+                   const QEnt* __restrict__ q, int count_idx, uint64_t qcap,
+                   QEnt* __restrict__ qc,
+                   unsigned long long* __restrict__ counters,
+                   unsigned long long* __restrict__ keys)
 {
-    unsigned long long nh = counters[C_NHITS];
-    if (nh > hits_cap) nh = hits_cap;
+    unsigned long long nq = counters[count_idx];
+    if (nq > qcap) nq = qcap;
     const int lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * 256ull;
     uint32_t nwin = 0;
-    for (uint64_t base = (uint64_t)blockIdx.x * 256ull + (threadIdx.x & ~63); base < nh; base += stride) {
+    for (uint64_t base = (uint64_t)blockIdx.x * 256ull + (threadIdx.x & ~63); base < nq; base += stride) {
         const uint64_t g = base + lane;
-        bool active = g < nh;
-        uint64_t rs = 0; int64_t L = 0; uint32_t r = 0, strand = 0; int64_t pos = 0; int32_t pt = -1;
-        const uint64_t ent = active ? hits[g] : HIT_HOLE;
-        const bool hole = ent == HIT_HOLE;
-        if (!hole) {
-            r = (uint32_t)ent;
-            const uint32_t ps = (uint32_t)(ent >> 32);
-            strand = ps & 1u; pos = ps >> 1;
-            rs = off[r]; L = (int64_t)(off[r + 1] - rs);
-            pt = polyt[2 * (uint64_t)r + strand];
-        }
-        active = active && !hole;
+        QEnt e = make_uint4(HOLE_R, 0, 0, 0);
+        if (g < nq) e = q[g];
+        const bool active = e.x != HOLE_R;
+        const uint32_t r = active ? e.x : 0u, strand = e.y & 1u, mask = active ? e.z : 0u;
+        const int64_t pos = active ? (int64_t)(e.y >> 1) : 0;
+        uint64_t rs = 0; int64_t L = 0; int32_t pt = -1;
+        if (active) { rs = off[r]; L = (int64_t)(off[r + 1] - rs); pt = polyt[2 * (uint64_t)r + strand]; }
         const int64_t ws = pos - (R1_LEN - KMER) > 0 ? pos - (R1_LEN - KMER) : 0;       // common.py:96-97
         const int64_t we = pos + R1_LEN + 1 < L ? pos + R1_LEN + 1 : L;                 // :98-99 (strict: end = len)
-        const int nfull = active ? (int)(we - ws) : 0;
-        uint32_t w[10];
-        load_block(bases, total_rounded, rs, L, (int)strand, ws, +1, w);
-        const bool anyN = __ballot(active && block_has_N(w)) != 0;
-        uint32_t w2[10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) w2[i] = w[i];
-        const uint32_t acc = sw_window(w, nfull, strand, anyN);
-        const uint32_t score = acc >> KEY_SHIFT;
-        const uint64_t key = make_key(acc, (uint32_t)pos);
-        nwin += active ? 1u : 0u;
-        if (active && score >= 17u)                                                      // barcode_callers.py:200
-            atomicMax(&keys[2ull * n_reads + 2ull * r + strand], (unsigned long long)key);
+        const int64_t last = pos + (mask ? 31 - __builtin_clz(mask) : 0);
+        const int64_t wu = last + R1_LEN + 1 < L ? last + R1_LEN + 1 : L;               // end of the cluster's union
         // relaxed search (barcode_callers.py:186-192): hits inside sequence[0:polyT+1], end = polyT+1
         const bool relaxed = active && pt >= 0 && pos + KMER <= (int64_t)pt + 1;
         const int64_t we_r = pos + R1_LEN + 1 < (int64_t)pt + 1 ? pos + R1_LEN + 1 : (int64_t)pt + 1;
-        const bool clipped = relaxed && we_r < we;
-        uint64_t key_r = key; uint32_t score_r = score;
-        if (__ballot(clipped)) {
-            const uint32_t acc2 = sw_window(w2, clipped ? (int)(we_r - ws) : 0, strand, anyN);
-            if (clipped) { key_r = make_key(acc2, (uint32_t)pos); score_r = acc2 >> KEY_SHIFT; nwin += 1u; }
+        const int n_s = active ? (int)(we - ws) : 0;
+        const int n_r = relaxed ? (int)(we_r - ws) : 0;
+        const int n_u = active ? (int)(wu - ws) : 0;
+        uint32_t w[CW];
+        load_block<CW>(bases, total_rounded, rs, L, (int)strand, ws, +1, w);
+        const bool anyN = __ballot(active && block_has_N<CW>(w)) != 0;
+        const int ndw = (wave_max(n_u) + 3) >> 2;
+        uint32_t acc_s = 0, acc_r = 0;
+        const uint32_t acc_u = anyN ? sw_block<CW, true, false>(w, ndw, n_u, strand, 0, n_s, n_r, acc_s, acc_r)
+                                    : sw_block<CW, false, false>(w, ndw, n_u, strand, 0, n_s, n_r, acc_s, acc_r);
+        nwin += active ? 1u : 0u;
+        const uint32_t score_s = acc_s >> KEY_SHIFT;
+        if (active && score_s >= 17u)                                                    // barcode_callers.py:200
+            atomicMax(&keys[2ull * n_reads + 2ull * r + strand], (unsigned long long)make_key(acc_s, (uint32_t)pos));
+        if (relaxed && (acc_r >> KEY_SHIFT) >= 9u)                                       // barcode_callers.py:191
+            atomicMax(&keys[2ull * r + strand], (unsigned long long)make_key(acc_r, (uint32_t)pos));
+        // Every window of the cluster lies inside the union, so no later hit scores above the union.
+        // If the union does not beat the first hit, none of them can replace it (strictly greater is
+        // required, common.py:102); otherwise align them one by one (queue C, second launch).
+        uint32_t rest = (active && (acc_u >> KEY_SHIFT) > score_s) ? (mask & ~1u) : 0u;
+        if (__ballot(rest != 0)) {
+            const uint32_t cnt = __popc(rest);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            const uint32_t total = __shfl(incl, 63);
+            unsigned long long gb = 0;
+            if (lane == 63) gb = atomicAdd(&counters[C_NC], (unsigned long long)total);
+            gb = __shfl(gb, 63);
+            unsigned long long idx = gb + incl - cnt;
+            while (rest) {
+                const int j = __builtin_ctz(rest); rest &= rest - 1;
+                if (idx < qcap) qc[idx] = make_uint4(r, ((uint32_t)(pos + j) << 1) | strand, 1u, 0u);
+                ++idx;
+            }
         }
-        if (relaxed && score_r >= 9u)                                                    // barcode_callers.py:191
-            atomicMax(&keys[2ull * r + strand], (unsigned long long)key_r);
     }
     // window count (statistics only)
 #pragma unroll
@@ -428,11 +574,12 @@ __device__ StrandRes finalize_strand(const uint8_t* __restrict__ bases, uint64_t
     }
     if (__ballot(need_rev)) {
         uint32_t w[10];
-        load_block(bases, total_rounded, rs, L, strand, ws_s + end_ref_s, -1, w);
-        const bool anyN = __ballot(need_rev && block_has_N(w)) != 0;
+        load_block<10>(bases, total_rounded, rs, L, strand, ws_s + end_ref_s, -1, w);
+        const bool anyN = __ballot(need_rev && block_has_N<10>(w)) != 0;
         const int ncol = need_rev ? end_ref_s + 1 : 0;
-        const uint32_t acc = anyN ? sw_block<true, true>(w, ncol, (uint32_t)strand, end_read_s)
-                                  : sw_block<false, true>(w, ncol, (uint32_t)strand, end_read_s);
+        uint32_t sn1, sn2;
+        const uint32_t acc = anyN ? sw_block<10, true, true>(w, 10, ncol, (uint32_t)strand, end_read_s, 0, 0, sn1, sn2)
+                                  : sw_block<10, false, true>(w, 10, ncol, (uint32_t)strand, end_read_s, 0, 0, sn1, sn2);
         if (need_rev) {
             const int rr = 31 - (int)(acc & 31u);
             const int read_begin = end_read_s - rr;
@@ -565,29 +712,45 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     if ((rc = bdg_reserve(ctx, ctx->x_polyt, sizeof(int32_t) * 2ull * n))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->x_keys, sizeof(uint64_t) * 4ull * n))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->x_counters, 64))) return rc;
-    uint64_t want = total_bytes / 16 + 4096;
+    // three cluster queues (A: aligned, B: filtered first, C: re-queued hits of a cluster), 16 B per entry
+    uint64_t want = total_bytes / 48 + 4096;
     if (want < ctx->x_hits_cap) want = ctx->x_hits_cap;
-    if ((rc = bdg_reserve(ctx, ctx->x_hits, sizeof(uint64_t) * want))) return rc;
-    ctx->x_hits_cap = ctx->x_hits.bytes / sizeof(uint64_t);
+    if ((rc = bdg_reserve(ctx, ctx->x_hits, sizeof(QEnt) * 3ull * want))) return rc;
+    ctx->x_hits_cap = ctx->x_hits.bytes / sizeof(QEnt) / 3;
+    const uint64_t qcap = ctx->x_hits_cap;
+    QEnt* qa = static_cast<QEnt*>(ctx->x_hits.p);
+    QEnt* qb = qa + qcap;
+    QEnt* qc = qb + qcap;
 
     hipStream_t st = ctx->stream;
     const uint64_t total_rounded = (total_bytes + 15ull) & ~15ull;
     auto* counters = static_cast<unsigned long long*>(ctx->x_counters.p);
+    auto* keys = static_cast<unsigned long long*>(ctx->x_keys.p);
+    const auto* pt = static_cast<const int32_t*>(ctx->x_polyt.p);
     BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, st));
     BDG_HIP_TRY(ctx, hipMemsetAsync(counters + C_BADREAD, 0xFF, 8, st));
-    BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->x_keys.p, 0, sizeof(uint64_t) * 4ull * n, st));
+    BDG_HIP_TRY(ctx, hipMemsetAsync(keys, 0, sizeof(uint64_t) * 4ull * n, st));
     {
         ScopedKernelTimer tm(ctx, "k_scan_reads");
         const uint32_t grid = (n + READS_PER_BLOCK - 1) / READS_PER_BLOCK;
         hipLaunchKernelGGL(k_scan_reads, dim3(grid), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
                            static_cast<const uint32_t*>(ctx->x_lut.p), static_cast<int32_t*>(ctx->x_polyt.p),
-                           static_cast<uint64_t*>(ctx->x_hits.p), ctx->x_hits_cap, counters);
+                           qa, qb, qcap, counters);
     }
     {
-        ScopedKernelTimer tm(ctx, "k_sw_windows");
-        hipLaunchKernelGGL(k_sw_windows, dim3(256 * 8), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
-                           static_cast<const int32_t*>(ctx->x_polyt.p), static_cast<const uint64_t*>(ctx->x_hits.p),
-                           ctx->x_hits_cap, counters, static_cast<unsigned long long*>(ctx->x_keys.p));
+        ScopedKernelTimer tm(ctx, "k_strict_filter");
+        hipLaunchKernelGGL(k_strict_filter, dim3(256 * 8), dim3(256), 0, st, d_bases, total_rounded, d_off,
+                           qb, qa, qcap, counters);
+    }
+    {
+        ScopedKernelTimer tm(ctx, "k_sw_clusters");
+        hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 8), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,
+                           qa, (int)C_NA, qcap, qc, counters, keys);
+    }
+    {
+        ScopedKernelTimer tm(ctx, "k_sw_requeued");
+        hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 2), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,
+                           qc, (int)C_NC, qcap, qb, counters, keys);      // single hits: nothing is re-queued
     }
     {
         ScopedKernelTimer tm(ctx, "k_finalize_reads");
@@ -607,8 +770,9 @@ int bdg_extract_status_impl(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_window
     BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (bad_read) *bad_read = c[C_BADREAD];
     if (n_windows) *n_windows = c[C_NWINDOWS];
-    if (c[C_NHITS] > ctx->x_hits_cap) {
-        const uint64_t want = c[C_NHITS] + 4096;
+    if (c[C_NA] > ctx->x_hits_cap || c[C_NB] > ctx->x_hits_cap || c[C_NC] > ctx->x_hits_cap) {
+        uint64_t want = c[C_NA] > c[C_NB] ? c[C_NA] : c[C_NB];
+        want = (want > c[C_NC] ? want : c[C_NC]) + c[C_NKEPT] + 4096;
         ctx->x_hits_cap = want;            // next launch reserves this much
         return bdg_fail(ctx, BDG_E_CAPACITY, "window queue overflow: rerun the batch (workspace grown)");
     }
