@@ -52,8 +52,8 @@ constexpr int32_t ONE = 1 << KEY_SHIFT;
 
 enum { C_NA = 0, C_BADREAD = 1, C_NWINDOWS = 2, C_NB = 3, C_NKEPT = 4, C_NC = 5, C_NHITS = 6 };
 
-constexpr int READS_PER_BLOCK = 64;
-constexpr uint32_t HITBUF = 1024;          // per-block LDS staging of clusters (16 KiB)
+constexpr int READS_PER_BLOCK = 32;
+constexpr uint32_t HITBUF = 512;           // per-group LDS staging of clusters (8 KiB)
 constexpr uint32_t HOLE_R = 0xFFFFFFFFu;   // unused queue slot
 
 // queue entry: {read, (pos << 1) | strand, offset mask of the hits (bit 0 = first hit), unused}
@@ -68,7 +68,20 @@ __device__ __forceinline__ uint32_t range_mask16(int64_t lo, int64_t hi)
 
 // ---------------------------------------------------------------------------
 // k_scan_reads
+// Persistent blocks (tables are loaded into LDS once per block); each block walks groups of
+// 32 consecutive reads, 8 reads per wave.  The group's offsets are staged in LDS and the next
+// 16-byte vector of a lane is loaded before the current one is processed, so a wave never waits
+// on an offset->data dependent load pair.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ uint4 load_vec(const uint8_t* __restrict__ bases, uint64_t total_rounded,
+                                          uint64_t s, int64_t L, int t, int lane)
+{
+    const uint64_t g0 = (s & ~15ull) + (uint64_t)(t * 63 + lane) * 16ull;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (g0 < total_rounded && (int64_t)g0 - (int64_t)s < L) v = *reinterpret_cast<const uint4*>(bases + g0);
+    return v;
+}
+
 __global__ __launch_bounds__(256)
 void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                   const uint64_t* __restrict__ off, uint32_t n,
@@ -77,182 +90,201 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                   QEnt* __restrict__ qa, QEnt* __restrict__ qb, uint64_t qcap,
                   unsigned long long* __restrict__ counters)
 {
-    __shared__ uint32_t s_kmer[256];     // 4096 x 2 bits: bit0 R1 6-mer, bit1 reverse-complement of one
+    __shared__ uint32_t s_kmer[4096];    // 6-mer code -> bit0 R1 6-mer, bit16 reverse-complement of one
     __shared__ uint2 s_cls[256];         // byte -> {isT | isA<<16, isN | bad<<16}
-    __shared__ QEnt s_ent[HITBUF];       // this block's clusters
+    __shared__ QEnt s_ent[HITBUF];       // this group's clusters
     __shared__ uint16_t s_slot[HITBUF];  // class bit (15) | slot inside the class
+    __shared__ uint64_t s_off[READS_PER_BLOCK + 1];
     __shared__ int32_t s_pt[READS_PER_BLOCK][2];
     __shared__ uint32_t s_nent, s_cls_cnt[2];
     __shared__ unsigned long long s_base[2];
     const int tid = threadIdx.x;
-    if (tid == 0) { s_nent = 0; s_cls_cnt[0] = 0; s_cls_cnt[1] = 0; }
-    s_kmer[tid] = tables[tid];
+    for (int k = tid; k < 4096; k += 256) s_kmer[k] = tables[768 + k];
     s_cls[tid] = reinterpret_cast<const uint2*>(tables + 256)[tid];
-    __syncthreads();
 
     const int lane = tid & 63, wv = tid >> 6;
-    const uint64_t r_begin = (uint64_t)blockIdx.x * READS_PER_BLOCK;
-    const uint64_t r_end = r_begin + READS_PER_BLOCK < n ? r_begin + READS_PER_BLOCK : n;
+    const uint32_t ngroups = (n + READS_PER_BLOCK - 1) / READS_PER_BLOCK;
     uint32_t nhits_stat = 0;
 
-    for (uint64_t r = r_begin + wv; r < r_end; r += 4) {
-        const uint64_t s = off[r];
-        const int64_t L = (int64_t)(off[r + 1] - s);
-        const uint64_t base_al = s & ~15ull;
-        const int64_t span = (int64_t)(s - base_al) + L;
-        const int niter = L > 0 ? (int)((span + 1007) / 1008) : 0;
-        int32_t ptF = -1, ptR = -1;
-        bool foundF = false;
+    for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const uint64_t r_begin = (uint64_t)grp * READS_PER_BLOCK;
+        const uint32_t nr = (uint32_t)(r_begin + READS_PER_BLOCK < n ? READS_PER_BLOCK : n - r_begin);
+        __syncthreads();                                   // previous group's flush is done with LDS
+        if (tid == 0) { s_nent = 0; s_cls_cnt[0] = 0; s_cls_cnt[1] = 0; }
+        if ((uint32_t)tid <= nr) s_off[tid] = off[r_begin + tid];
+        __syncthreads();
 
-        for (int t = 0; t < niter; ++t) {
-            const uint64_t g0 = base_al + (uint64_t)(t * 63 + lane) * 16ull;
-            const int64_t p0 = (int64_t)g0 - (int64_t)s;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (g0 < total_rounded && p0 < L) v = *reinterpret_cast<const uint4*>(bases + g0);
-            const uint32_t words[4] = { v.x, v.y, v.z, v.w };
-            uint32_t ta = 0, nb = 0, codes = 0;
+        bool have_pref = false;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        for (uint32_t ri = wv; ri < nr; ri += 4) {
+            const uint64_t r = r_begin + ri;
+            const uint64_t s = s_off[ri];
+            const int64_t L = (int64_t)(s_off[ri + 1] - s);
+            const uint64_t base_al = s & ~15ull;
+            const int64_t span = (int64_t)(s - base_al) + L;
+            const int niter = L > 0 ? (int)((span + 1007) / 1008) : 0;
+            int32_t ptF = -1, ptR = -1;
+            bool foundF = false;
+            if (!have_pref && niter > 0) v = load_vec(bases, total_rounded, s, L, 0, lane);
+            have_pref = false;
+
+            for (int t = 0; t < niter; ++t) {
+                // issue the next vector's load first
+                uint4 vn = make_uint4(0, 0, 0, 0);
+                if (t + 1 < niter) vn = load_vec(bases, total_rounded, s, L, t + 1, lane);
+                else if (ri + 4 < nr) {
+                    const uint64_t s2 = s_off[ri + 4];
+                    const int64_t L2 = (int64_t)(s_off[ri + 5] - s2);
+                    if (L2 > 0) { vn = load_vec(bases, total_rounded, s2, L2, 0, lane); have_pref = true; }
+                }
+                const int64_t p0 = (int64_t)(base_al + (uint64_t)(t * 63 + lane) * 16ull) - (int64_t)s;
+                const uint32_t words[4] = { v.x, v.y, v.z, v.w };
+                uint32_t ta = 0, nb = 0, codes = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t b = (words[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                const uint2 c = s_cls[b];
-                ta |= c.x << k;
-                nb |= c.y << k;
-                codes |= ((b >> 1) & 3u) << (2 * k);
-            }
-            const uint32_t rm = range_mask16(-p0, L - p0);
-            const uint32_t T = ta & 0xFFFFu & rm;
-            const uint32_t A = (ta >> 16) & rm;
-            const uint32_t N = ((nb & 0xFFFFu) | ~rm) & 0xFFFFu;    // out-of-read behaves like N
-            const uint32_t bad = (nb >> 16) & rm;
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t b = (words[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                    const uint2 c = s_cls[b];
+                    ta |= c.x << k;
+                    nb |= c.y << k;
+                    codes |= ((b >> 1) & 3u) << (2 * k);
+                }
+                const uint32_t rm = range_mask16(-p0, L - p0);
+                const uint32_t T = ta & 0xFFFFu & rm;
+                const uint32_t A = (ta >> 16) & rm;
+                const uint32_t N = ((nb & 0xFFFFu) | ~rm) & 0xFFFFu;    // out-of-read behaves like N
+                const uint32_t bad = (nb >> 16) & rm;
 
-            const uint32_t TA1 = __shfl_down(T | (A << 16), 1);
-            const uint32_t N1 = __shfl_down(N, 1);
-            const uint32_t codes1 = __shfl_down(codes, 1);
-            const uint32_t T32 = T | (TA1 << 16);
-            const uint32_t A32 = A | (TA1 & 0xFFFF0000u);
-            const uint32_t N32 = N | (N1 << 16);
-            const bool worker = lane < 63;       // lane 63 only feeds lane 62; its bytes are lane 0 of the next step
+                const uint32_t TA1 = __shfl_down(T | (A << 16), 1);
+                const uint32_t N1 = __shfl_down(N, 1);
+                const uint32_t codes1 = __shfl_down(codes, 1);
+                const uint32_t T32 = T | (TA1 << 16);
+                const uint32_t A32 = A | (TA1 & 0xFFFF0000u);
+                const uint32_t N32 = N | (N1 << 16);
+                const bool worker = lane < 63;       // lane 63 only feeds lane 62; its bytes are lane 0 of the next step
 
-            uint32_t qT = 0, qA = 0, hitF = 0, hitR = 0;
+                // 16 windows of 16 bases: bit 5 of popcount + 20 is set iff the count is >= 12 (int(16 * 0.75), common.py:11)
+                uint32_t qT = 0, qA = 0, hits = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t cT = __popc((T32 >> k) & 0xFFFFu);
-                const uint32_t cA = __popc((A32 >> k) & 0xFFFFu);
-                qT |= (cT >= 12u ? 1u : 0u) << k;              // int(16 * 0.75), common.py:11
-                qA |= (cA >= 12u ? 1u : 0u) << k;
-                const uint32_t key = __builtin_amdgcn_alignbit(codes1, codes, 2 * k) & 0xFFFu;
-                uint32_t f = (s_kmer[key >> 4] >> ((key & 15u) * 2u)) & 3u;
-                f = ((N32 >> k) & 0x3Fu) == 0u ? f : 0u;
-                hitF |= (f & 1u) << k;
-                hitR |= (f >> 1) << k;
-            }
-            // window starts allowed by the loop bounds of common.py:17,28
-            qT &= range_mask16(-p0, L - 16 - p0);              // 0 <= p < L-16
-            qA &= range_mask16(1 - p0, L - 16 - p0 + 1);       // reverse strand: 0 <= L-16-p < L-16
-            if (!worker) { qT = 0; qA = 0; hitF = 0; hitR = 0; }
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t cT = __popc(__builtin_amdgcn_ubfe(T32, k, 16)) + 20u;
+                    const uint32_t cA = __popc(__builtin_amdgcn_ubfe(A32, k, 16)) + 20u;
+                    qT |= (k >= 5 ? (cT << (k - 5)) : (cT >> (5 - k))) & (1u << k);
+                    qA |= (k >= 5 ? (cA << (k - 5)) : (cA >> (5 - k))) & (1u << k);
+                    // byte offset of the 6-mer code in the table: code * 4
+                    const uint32_t ko = (k == 0 ? (codes << 2) : __builtin_amdgcn_alignbit(codes1, codes, 2 * k - 2)) & 0x3FFCu;
+                    hits |= *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_kmer) + ko) << k;
+                }
+                // 6-mers touching an N or leaving the read never match
+                uint32_t nv = N32 | (N32 >> 1);
+                nv |= nv >> 2;
+                nv |= N32 >> 4; nv |= N32 >> 5;
+                const uint32_t valid = ~nv & 0xFFFFu;
+                uint32_t hitF = hits & valid, hitR = (hits >> 16) & valid;
+                // window starts allowed by the loop bounds of common.py:17,28
+                qT &= range_mask16(-p0, L - 16 - p0);              // 0 <= p < L-16
+                qA &= range_mask16(1 - p0, L - 16 - p0 + 1);       // reverse strand: 0 <= L-16-p < L-16
+                if (!worker) { qT = 0; qA = 0; hitF = 0; hitR = 0; }
 
-            if (!foundF) {
-                const unsigned long long bal = __ballot(qT != 0);
-                if (bal) {
-                    const int src = __builtin_ctzll(bal);
-                    int32_t val = 0;
-                    if (lane == src) {
-                        const int k = __builtin_ctz(qT);
-                        const uint32_t tt = (T32 & (T32 >> 1) & (T32 >> 2)) >> k;     // 'TTT' starts, common.py:31
-                        val = (int32_t)(p0 + k + (tt ? __builtin_ctz(tt) : 0));
+                if (!foundF) {
+                    const unsigned long long bal = __ballot(qT != 0);
+                    if (bal) {
+                        const int src = __builtin_ctzll(bal);
+                        int32_t val = 0;
+                        if (lane == src) {
+                            const int k = __builtin_ctz(qT);
+                            const uint32_t tt = (T32 & (T32 >> 1) & (T32 >> 2)) >> k;     // 'TTT' starts, common.py:31
+                            val = (int32_t)(p0 + k + (tt ? __builtin_ctz(tt) : 0));
+                        }
+                        ptF = __shfl(val, src);
+                        foundF = true;
                     }
-                    ptF = __shfl(val, src);
-                    foundF = true;
                 }
-            }
-            {
-                const unsigned long long bal = __ballot(qA != 0);
-                if (bal) {
-                    const int src = 63 - __builtin_clzll(bal);
-                    int32_t val = 0;
-                    if (lane == src) {
-                        const int k = 31 - __builtin_clz(qA);
-                        const uint32_t aa = A32 & (A32 >> 1) & (A32 >> 2);
-                        const uint32_t m = aa & ((1u << (k + 14)) - 1u);
-                        const int j = m ? 31 - __builtin_clz(m) : k + 13;
-                        val = (int32_t)((L - 16 - (p0 + k)) + (k + 13 - j));
+                {
+                    const unsigned long long bal = __ballot(qA != 0);
+                    if (bal) {
+                        const int src = 63 - __builtin_clzll(bal);
+                        int32_t val = 0;
+                        if (lane == src) {
+                            const int k = 31 - __builtin_clz(qA);
+                            const uint32_t aa = A32 & (A32 >> 1) & (A32 >> 2);
+                            const uint32_t m = aa & ((1u << (k + 14)) - 1u);
+                            const int j = m ? 31 - __builtin_clz(m) : k + 13;
+                            val = (int32_t)((L - 16 - (p0 + k)) + (k + 13 - j));
+                        }
+                        ptR = __shfl(val, src);
                     }
-                    ptR = __shfl(val, src);
                 }
-            }
-            if (__ballot(bad != 0 && worker)) {
-                if (bad != 0 && worker) atomicMin(&counters[C_BADREAD], (unsigned long long)r);
-            }
-            // one cluster per lane and strand: first hit + offsets of the others
-            nhits_stat += __popc(hitF) + __popc(hitR);
-            const uint32_t cnt = (hitF ? 1u : 0u) + (hitR ? 1u : 0u);
-            uint32_t incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
-            }
-            const uint32_t total = __shfl(incl, 63);
-            if (total) {
-                uint32_t slot = 0;
-                if (lane == 63) slot = atomicAdd(&s_nent, total);
-                slot = __shfl(slot, 63);
-                const bool fits = slot + total <= HITBUF;
-                unsigned long long gbase = 0;
-                if (!fits) {            // staging full (pathological read): this step goes straight to queue A
-                    if (lane == 63) gbase = atomicAdd(&counters[C_NA], (unsigned long long)total);
-                    gbase = __shfl(gbase, 63);
-                    for (uint32_t h = slot + lane; h < HITBUF && h < slot + total; h += 64) s_ent[h].x = HOLE_R;
+                if (__ballot(bad != 0 && worker)) {
+                    if (bad != 0 && worker) atomicMin(&counters[C_BADREAD], (unsigned long long)r);
                 }
-                unsigned long long idx = (fits ? slot : gbase) + incl - cnt;
-                if (hitF) {
-                    const int k0 = __builtin_ctz(hitF);
-                    const QEnt e = make_uint4((uint32_t)r, (uint32_t)(p0 + k0) << 1, hitF >> k0, 0u);
-                    if (fits) s_ent[idx] = e; else if (idx < qcap) qa[idx] = e;
-                    ++idx;
+                // one cluster per lane and strand: first hit + offsets of the others
+                nhits_stat += __popc(hitF) + __popc(hitR);
+                const unsigned long long balF = __ballot(hitF != 0), balR = __ballot(hitR != 0);
+                const uint32_t total = (uint32_t)(__popcll(balF) + __popcll(balR));
+                if (total) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const uint32_t excl = (uint32_t)(__popcll(balF & below) + __popcll(balR & below));
+                    uint32_t slot = 0;
+                    if (lane == 0) slot = atomicAdd(&s_nent, total);
+                    slot = __shfl(slot, 0);
+                    const bool fits = slot + total <= HITBUF;
+                    unsigned long long gbase = 0;
+                    if (!fits) {            // staging full (pathological reads): this step goes straight to queue A
+                        if (lane == 0) gbase = atomicAdd(&counters[C_NA], (unsigned long long)total);
+                        gbase = __shfl(gbase, 0);
+                        for (uint32_t h = slot + lane; h < HITBUF && h < slot + total; h += 64) s_ent[h].x = HOLE_R;
+                    }
+                    unsigned long long idx = (fits ? slot : gbase) + excl;
+                    if (hitF) {
+                        const int k0 = __builtin_ctz(hitF);
+                        const QEnt e = make_uint4((uint32_t)r, (uint32_t)(p0 + k0) << 1, hitF >> k0, 0u);
+                        if (fits) s_ent[idx] = e; else if (idx < qcap) qa[idx] = e;
+                        ++idx;
+                    }
+                    if (hitR) {
+                        const int k1 = 31 - __builtin_clz(hitR);
+                        const QEnt e = make_uint4((uint32_t)r, ((uint32_t)(L - KMER - (p0 + k1)) << 1) | 1u,
+                                                  __brev(hitR) >> (31 - k1), 0u);
+                        if (fits) s_ent[idx] = e; else if (idx < qcap) qa[idx] = e;
+                    }
                 }
-                if (hitR) {
-                    const int k1 = 31 - __builtin_clz(hitR);
-                    const QEnt e = make_uint4((uint32_t)r, ((uint32_t)(L - KMER - (p0 + k1)) << 1) | 1u,
-                                              __brev(hitR) >> (31 - k1), 0u);
-                    if (fits) s_ent[idx] = e; else if (idx < qcap) qa[idx] = e;
-                }
+                v = vn;
             }
+            if (lane == 0) { polyt[2 * r] = ptF; polyt[2 * r + 1] = ptR; s_pt[ri][0] = ptF; s_pt[ri][1] = ptR; }
         }
-        if (lane == 0) { polyt[2 * r] = ptF; polyt[2 * r + 1] = ptR; s_pt[r - r_begin][0] = ptF; s_pt[r - r_begin][1] = ptR; }
-    }
-    // flush.  A cluster whose first hit lies left of polyT can win the relaxed search and always gets
-    // a full alignment (queue A); the others only matter if they reach score 17 and go through the
-    // cheap filter first (queue B).  One global reservation per block and queue.
-    __syncthreads();
-    const uint32_t nst = s_nent < HITBUF ? s_nent : HITBUF;
-    for (uint32_t h = tid; h < nst; h += 256) {
-        const QEnt e = s_ent[h];
-        uint32_t cls = 0, need = 1;
-        if (e.x != HOLE_R) {
-            const int32_t pt = s_pt[e.x - (uint32_t)r_begin][e.y & 1u];
-            cls = (pt >= 0 && (int64_t)(e.y >> 1) + KMER <= (int64_t)pt + 1) ? 0u : 1u;
-            need = cls ? __popc(e.z) : 1u;              // queue B holds single hits: the filter is per window
+        // flush.  A cluster whose first hit lies left of polyT can win the relaxed search and always gets
+        // a full alignment (queue A); the others only matter if they reach score 17 and go through the
+        // cheap per-window filter first (queue B, single hits).  One global reservation per group and queue.
+        __syncthreads();
+        const uint32_t nst = s_nent < HITBUF ? s_nent : HITBUF;
+        for (uint32_t h = tid; h < nst; h += 256) {
+            const QEnt e = s_ent[h];
+            uint32_t cls = 0, need = 1;
+            if (e.x != HOLE_R) {
+                const int32_t pt = s_pt[e.x - (uint32_t)r_begin][e.y & 1u];
+                cls = (pt >= 0 && (int64_t)(e.y >> 1) + KMER <= (int64_t)pt + 1) ? 0u : 1u;
+                need = cls ? __popc(e.z) : 1u;
+            }
+            const uint32_t slot = atomicAdd(&s_cls_cnt[cls], need);
+            s_slot[h] = (uint16_t)((cls << 15) | slot);
         }
-        const uint32_t slot = atomicAdd(&s_cls_cnt[cls], need);
-        s_slot[h] = (uint16_t)((cls << 15) | slot);
-    }
-    __syncthreads();
-    if (tid < 2 && s_cls_cnt[tid])
-        s_base[tid] = atomicAdd(&counters[tid == 0 ? C_NA : C_NB], (unsigned long long)s_cls_cnt[tid]);
-    __syncthreads();
-    for (uint32_t h = tid; h < nst; h += 256) {
-        const uint32_t sl = s_slot[h];
-        const QEnt e = s_ent[h];
-        unsigned long long g = s_base[sl >> 15] + (sl & 0x7FFFu);
-        if (!(sl >> 15)) { if (g < qcap) qa[g] = e; }
-        else if (e.x == HOLE_R) { if (g < qcap) qb[g] = e; }
-        else {
-            uint32_t m = e.z;
-            while (m) {
-                const int j = __builtin_ctz(m); m &= m - 1;
-                if (g < qcap) qb[g] = make_uint4(e.x, e.y + ((uint32_t)j << 1), 1u, 0u);
-                ++g;
+        __syncthreads();
+        if (tid < 2 && s_cls_cnt[tid])
+            s_base[tid] = atomicAdd(&counters[tid == 0 ? C_NA : C_NB], (unsigned long long)s_cls_cnt[tid]);
+        __syncthreads();
+        for (uint32_t h = tid; h < nst; h += 256) {
+            const uint32_t sl = s_slot[h];
+            const QEnt e = s_ent[h];
+            unsigned long long g = s_base[sl >> 15] + (sl & 0x7FFFu);
+            if (!(sl >> 15)) { if (g < qcap) qa[g] = e; }
+            else if (e.x == HOLE_R) { if (g < qcap) qb[g] = e; }
+            else {
+                uint32_t m = e.z;
+                while (m) {
+                    const int j = __builtin_ctz(m); m &= m - 1;
+                    if (g < qcap) qb[g] = make_uint4(e.x, e.y + ((uint32_t)j << 1), 1u, 0u);
+                    ++g;
+                }
             }
         }
     }
@@ -670,9 +702,11 @@ void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
 }
 
 // host-side tables -------------------------------------------------------------
-void build_tables(uint32_t* t /* 256 + 512 words */)
+constexpr int TABLE_WORDS = 768 + 4096;
+
+void build_tables(uint32_t* t /* 256 (packed 2-bit LUT, unused by the kernels) + 512 (byte classes) + 4096 (direct 6-mer table) */)
 {
-    memset(t, 0, sizeof(uint32_t) * 768);
+    memset(t, 0, sizeof(uint32_t) * TABLE_WORDS);
     auto comp = [](char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; };
     for (int q = 0; q + KMER <= R1_LEN; ++q) {
         uint32_t kf = 0, kr = 0;
@@ -682,6 +716,8 @@ void build_tables(uint32_t* t /* 256 + 512 words */)
         }
         t[kf >> 4] |= 1u << ((kf & 15u) * 2u);
         t[kr >> 4] |= 2u << ((kr & 15u) * 2u);
+        t[768 + kf] |= 1u;
+        t[768 + kr] |= 1u << 16;
     }
     for (int b = 0; b < 256; ++b) {
         const bool isA = b == 'A', isC = b == 'C', isG = b == 'G', isT = b == 'T', isN = b == 'N';
@@ -704,7 +740,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     if (total_bytes >= (1ull << 62)) return bdg_fail(ctx, BDG_E_ARG, "total_bytes too large");
     int rc;
     if (!ctx->x_lut.p) {
-        uint32_t t[768];
+        uint32_t t[TABLE_WORDS];
         build_tables(t);
         if ((rc = bdg_reserve(ctx, ctx->x_lut, sizeof(t)))) return rc;
         BDG_HIP_TRY(ctx, hipMemcpy(ctx->x_lut.p, t, sizeof(t), hipMemcpyHostToDevice));
@@ -732,7 +768,8 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     BDG_HIP_TRY(ctx, hipMemsetAsync(keys, 0, sizeof(uint64_t) * 4ull * n, st));
     {
         ScopedKernelTimer tm(ctx, "k_scan_reads");
-        const uint32_t grid = (n + READS_PER_BLOCK - 1) / READS_PER_BLOCK;
+        const uint32_t ngroups = (n + READS_PER_BLOCK - 1) / READS_PER_BLOCK;
+        const uint32_t grid = ngroups < 256u * 5u ? ngroups : 256u * 5u;       // persistent: 5 blocks per CU
         hipLaunchKernelGGL(k_scan_reads, dim3(grid), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
                            static_cast<const uint32_t*>(ctx->x_lut.p), static_cast<int32_t*>(ctx->x_polyt.p),
                            qa, qb, qcap, counters);

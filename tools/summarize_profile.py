@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Condense a tools/pmc_profile.sh output directory into profiles/<tag>_summary.json and
+profiles/traffic.json (HBM bytes per launch per kernel, what bench.py reports as roofline.traffic).
+
+HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE counts 128-byte requests as 64 bytes for wide coalesced streaming reads, so it is
+doubled for the streaming kernels (k_scan_reads); WRITE_SIZE is exact for 16-byte stores.
+For gather-dominated kernels the doubling is uncalibrated and reported as a bracket [x1, x2]."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kname(full):
+    i = full.find("k_")
+    return full[i:full.find("(", i)]
+
+
+summary = collections.defaultdict(dict)
+for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+    for r in csv.DictReader(open(f)):
+        k = kname(r["Name"])
+        summary[k]["calls"] = int(r["Calls"])
+        summary[k]["avg_ns"] = float(r["AverageNs"])
+        summary[k]["min_ns"] = float(r["MinNs"])
+        summary[k]["max_ns"] = float(r["MaxNs"])
+for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
+    if not os.path.isdir(d):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in agg.items():
+        for c, v in cs.items():
+            summary[k][c] = sum(v) / len(v)
+STREAMING = {"k_scan_reads"}
+traffic = {}
+for k, s in summary.items():
+    if "FETCH_SIZE" in s and "WRITE_SIZE" in s:
+        rd1, wr = s["FETCH_SIZE"] * 1024.0, s["WRITE_SIZE"] * 1024.0
+        s["hbm_bytes_fetch_x1"] = rd1 + wr
+        s["hbm_bytes_fetch_x2"] = 2 * rd1 + wr
+        traffic[k] = s["hbm_bytes_fetch_x2"] if k in STREAMING else s["hbm_bytes_fetch_x1"]
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+json.dump(summary, open(os.path.join(ROOT, "profiles", tag + "_summary.json"), "w"), indent=1, sort_keys=True)
+json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
+for k in sorted(summary):
+    s = summary[k]
+    print("%-26s avg %8.1f us  VALU %6.1fM  hbm %s" % (k, s.get("avg_ns", 0) / 1e3, s.get("SQ_INSTS_VALU", 0) / 1e6,
+                                                     ("%.3f GB" % (traffic[k] / 1e9)) if k in traffic else "-"))
