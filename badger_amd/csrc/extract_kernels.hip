@@ -50,10 +50,8 @@ constexpr uint32_t EQ0 = eq_mask(0), EQ1 = eq_mask(1), EQ2 = eq_mask(2), EQ3 = e
 constexpr int KEY_SHIFT = 11;                 // score | (63-col) << 5 | (31-row)
 constexpr int32_t ONE = 1 << KEY_SHIFT;
 
-enum { C_NA = 0, C_BADREAD = 1, C_NWINDOWS = 2, C_NB = 3, C_NKEPT = 4, C_NC = 5, C_NHITS = 6 };
+enum { C_NAB = 0 /* queue A count | queue B count << 32 */, C_BADREAD = 1, C_NWINDOWS = 2, C_NKEPT = 4, C_NC = 5, C_NHITS = 6 };
 
-constexpr int READS_PER_BLOCK = 32;
-constexpr uint32_t HITBUF = 512;           // per-group LDS staging of clusters (8 KiB)
 constexpr uint32_t HOLE_R = 0xFFFFFFFFu;   // unused queue slot
 
 // queue entry: {read, (pos << 1) | strand, offset mask of the hits (bit 0 = first hit), unused}
@@ -68,18 +66,33 @@ __device__ __forceinline__ uint32_t range_mask16(int64_t lo, int64_t hi)
 
 // ---------------------------------------------------------------------------
 // k_scan_reads
-// Persistent blocks (tables are loaded into LDS once per block); each block walks groups of
-// 32 consecutive reads, 8 reads per wave.  The group's offsets are staged in LDS and the next
-// 16-byte vector of a lane is loaded before the current one is processed, so a wave never waits
-// on an offset->data dependent load pair.
+// Autonomous waves, no block barrier after the tables are in LDS.  A wave repeatedly takes a TASK
+// of 8 consecutive reads from an XCD-sharded counter (the next task is taken, and its offsets are
+// loaded, while the current one is processed).  The task's reads are laid end to end as a stream of
+// 16-byte vectors; each step the wave's lanes take 63 consecutive vectors of that stream (lane 63
+// repeats as lane 0 of the next step: it only feeds lane 62's look-ahead), so short tails of one
+// read and the head of the next share a step.  polyT is reduced per read segment with ballots.
+// Clusters are staged in a per-wave LDS region and flushed to the global queues with ONE packed
+// 64-bit reservation (A count | B count << 32) every few tasks.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint4 load_vec(const uint8_t* __restrict__ bases, uint64_t total_rounded,
-                                          uint64_t s, int64_t L, int t, int lane)
+constexpr int TASK_READS = 8;
+constexpr uint32_t WENT = 320;             // per-wave staging (5 KiB)
+constexpr uint32_t WFLUSH = 192;           // flush once this many clusters are staged
+constexpr int TASK_SHARDS = 8;
+
+struct TaskTab {                           // per wave, double buffered
+    uint64_t s[TASK_READS];                // read start (byte index)
+    int32_t  L[TASK_READS];                // read length
+    uint32_t pend[TASK_READS];             // vectors of reads 0..j inclusive
+};
+
+__device__ __forceinline__ uint32_t find_read(const TaskTab& t, uint32_t slot)
 {
-    const uint64_t g0 = (s & ~15ull) + (uint64_t)(t * 63 + lane) * 16ull;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (g0 < total_rounded && (int64_t)g0 - (int64_t)s < L) v = *reinterpret_cast<const uint4*>(bases + g0);
-    return v;
+    // number of reads whose vectors end at or before `slot` (pend is non-decreasing)
+    uint32_t j = t.pend[3] <= slot ? 4u : 0u;
+    j += t.pend[j + 1] <= slot ? 2u : 0u;
+    j += t.pend[j] <= slot ? 1u : 0u;
+    return j;
 }
 
 __global__ __launch_bounds__(256)
@@ -88,210 +101,272 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                   const uint32_t* __restrict__ tables,
                   int32_t* __restrict__ polyt,
                   QEnt* __restrict__ qa, QEnt* __restrict__ qb, uint64_t qcap,
-                  unsigned long long* __restrict__ counters)
+                  unsigned long long* __restrict__ counters,
+                  unsigned int* __restrict__ task_ctr)
 {
     __shared__ uint32_t s_kmer[4096];    // 6-mer code -> bit0 R1 6-mer, bit16 reverse-complement of one
     __shared__ uint2 s_cls[256];         // byte -> {isT | isA<<16, isN | bad<<16}
-    __shared__ QEnt s_ent[HITBUF];       // this group's clusters
-    __shared__ uint16_t s_slot[HITBUF];  // class bit (15) | slot inside the class
-    __shared__ uint64_t s_off[READS_PER_BLOCK + 1];
-    __shared__ int32_t s_pt[READS_PER_BLOCK][2];
-    __shared__ uint32_t s_nent, s_cls_cnt[2];
-    __shared__ unsigned long long s_base[2];
+    __shared__ QEnt s_ent[4][WENT];      // per-wave cluster staging
+    __shared__ TaskTab s_tab[4][2];
+    __shared__ int32_t s_pt[4][32][2];   // polyT of the wave's last 32 reads (ring by read index)
     const int tid = threadIdx.x;
     for (int k = tid; k < 4096; k += 256) s_kmer[k] = tables[768 + k];
     s_cls[tid] = reinterpret_cast<const uint2*>(tables + 256)[tid];
+    __syncthreads();
 
     const int lane = tid & 63, wv = tid >> 6;
-    const uint32_t ngroups = (n + READS_PER_BLOCK - 1) / READS_PER_BLOCK;
-    uint32_t nhits_stat = 0;
+    const uint32_t ntasks = (n + TASK_READS - 1) / TASK_READS;
+    const uint32_t shard = blockIdx.x % TASK_SHARDS;
+    QEnt* ent = s_ent[wv];
+    uint32_t nent = 0, nhits_stat = 0;
 
-    for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const uint64_t r_begin = (uint64_t)grp * READS_PER_BLOCK;
-        const uint32_t nr = (uint32_t)(r_begin + READS_PER_BLOCK < n ? READS_PER_BLOCK : n - r_begin);
-        __syncthreads();                                   // previous group's flush is done with LDS
-        if (tid == 0) { s_nent = 0; s_cls_cnt[0] = 0; s_cls_cnt[1] = 0; }
-        if ((uint32_t)tid <= nr) s_off[tid] = off[r_begin + tid];
-        __syncthreads();
-
-        bool have_pref = false;
+    // take a task: k-th grab of this shard is task k * TASK_SHARDS + shard
+    auto grab = [&]() -> uint32_t {
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(&task_ctr[shard * 32], 1u);
+        k = __shfl(k, 0);
+        const unsigned long long t = (unsigned long long)k * TASK_SHARDS + shard;
+        return t < ntasks ? (uint32_t)t : 0xFFFFFFFFu;
+    };
+    // offsets of a task -> table (lanes 0..8 load, everybody computes through shuffles)
+    auto load_tab = [&](uint32_t task, TaskTab& tb) {
+        const uint64_t r0 = (uint64_t)task * TASK_READS;
+        const uint32_t nr = (uint32_t)(n - r0 < TASK_READS ? n - r0 : TASK_READS);
+        uint64_t o = 0;
+        if ((uint32_t)lane <= nr) o = off[r0 + lane];
+        const uint64_t o1 = __shfl_down(o, 1);
+        int64_t L = (uint32_t)lane < nr ? (int64_t)(o1 - o) : 0;
+        bool bad = false;
+        if (L < 0 || L >= (1ll << 30) || o + (uint64_t)L > total_rounded) { bad = (uint32_t)lane < nr; L = 0; }
+        if (bad) atomicMin(&counters[C_BADREAD], (unsigned long long)(r0 + lane));      // corrupt offsets: report, never loop on them
+        uint32_t nv = L > 0 ? (uint32_t)(((o & 15ull) + (uint64_t)L + 15ull) >> 4) : 0u;
+        uint32_t incl = nv;
+#pragma unroll
+        for (int d = 1; d < TASK_READS; d <<= 1) { const uint32_t x = __shfl_up(incl, d); if (lane >= d) incl += x; }
+        if (lane < TASK_READS) { tb.s[lane] = o; tb.L[lane] = (int32_t)L; tb.pend[lane] = incl; }
+    };
+    auto slot_vec = [&](const TaskTab& tb, uint32_t slot, uint32_t nslots) -> uint4 {
         uint4 v = make_uint4(0, 0, 0, 0);
-        for (uint32_t ri = wv; ri < nr; ri += 4) {
-            const uint64_t r = r_begin + ri;
-            const uint64_t s = s_off[ri];
-            int64_t L = (int64_t)(s_off[ri + 1] - s);
-            if (L < 0 || L >= (1ll << 30) || s + (uint64_t)L > total_rounded) {     // corrupt offsets: report, never loop on them
-                if (lane == 0) atomicMin(&counters[C_BADREAD], (unsigned long long)r);
-                L = 0;
+        if (slot < nslots) {
+            const uint32_t j = find_read(tb, slot);
+            const uint32_t vidx = slot - (j ? tb.pend[j - 1] : 0u);
+            const uint64_t g0 = (tb.s[j] & ~15ull) + 16ull * vidx;
+            if (g0 < total_rounded) v = *reinterpret_cast<const uint4*>(bases + g0);
+        }
+        return v;
+    };
+    // flush the wave's staged clusters: queue A (first hit left of polyT) / queue B (single hits for the filter)
+    auto flush = [&]() {
+        if (nent == 0) return;
+        uint32_t tA = 0, tB = 0;
+        for (uint32_t h0 = 0; h0 < nent; h0 += 64) {
+            const uint32_t h = h0 + lane;
+            uint32_t a = 0, b = 0;
+            if (h < nent) {
+                const QEnt e = ent[h];
+                const int32_t pt = s_pt[wv][e.w][e.y & 1u];
+                const bool isA = pt >= 0 && (int64_t)(e.y >> 1) + KMER <= (int64_t)pt + 1;
+                a = isA ? 1u : 0u; b = isA ? 0u : __popc(e.z);
             }
-            const uint64_t base_al = s & ~15ull;
-            const int64_t span = (int64_t)(s - base_al) + L;
-            const int niter = L > 0 ? (int)((span + 1007) / 1008) : 0;
-            int32_t ptF = -1, ptR = -1;
-            bool foundF = false;
-            if (!have_pref && niter > 0) v = load_vec(bases, total_rounded, s, L, 0, lane);
-            have_pref = false;
-
-            for (int t = 0; t < niter; ++t) {
-                // issue the next vector's load first
-                uint4 vn = make_uint4(0, 0, 0, 0);
-                if (t + 1 < niter) vn = load_vec(bases, total_rounded, s, L, t + 1, lane);
-                else if (ri + 4 < nr) {
-                    const uint64_t s2 = s_off[ri + 4];
-                    const int64_t L2 = (int64_t)(s_off[ri + 5] - s2);
-                    if (L2 > 0 && L2 < (1ll << 30) && s2 + (uint64_t)L2 <= total_rounded) { vn = load_vec(bases, total_rounded, s2, L2, 0, lane); have_pref = true; }
-                }
-                const int64_t p0 = (int64_t)(base_al + (uint64_t)(t * 63 + lane) * 16ull) - (int64_t)s;
-                const uint32_t words[4] = { v.x, v.y, v.z, v.w };
-                uint32_t ta = 0, nb = 0, codes = 0;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const uint32_t b = (words[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                    const uint2 c = s_cls[b];
-                    ta |= c.x << k;
-                    nb |= c.y << k;
-                    codes |= ((b >> 1) & 3u) << (2 * k);
-                }
-                const uint32_t rm = range_mask16(-p0, L - p0);
-                const uint32_t T = ta & 0xFFFFu & rm;
-                const uint32_t A = (ta >> 16) & rm;
-                const uint32_t N = ((nb & 0xFFFFu) | ~rm) & 0xFFFFu;    // out-of-read behaves like N
-                const uint32_t bad = (nb >> 16) & rm;
-
-                const uint32_t TA1 = __shfl_down(T | (A << 16), 1);
-                const uint32_t N1 = __shfl_down(N, 1);
-                const uint32_t codes1 = __shfl_down(codes, 1);
-                const uint32_t T32 = T | (TA1 << 16);
-                const uint32_t A32 = A | (TA1 & 0xFFFF0000u);
-                const uint32_t N32 = N | (N1 << 16);
-                const bool worker = lane < 63;       // lane 63 only feeds lane 62; its bytes are lane 0 of the next step
-
-                // 16 windows of 16 bases: bit 5 of popcount + 20 is set iff the count is >= 12 (int(16 * 0.75), common.py:11)
-                uint32_t qT = 0, qA = 0, hits = 0;
+            for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+            tA += a; tB += b;
+        }
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&counters[C_NAB], (unsigned long long)tA | ((unsigned long long)tB << 32));
+        base = __shfl(base, 0);
+        unsigned long long gA = base & 0xFFFFFFFFull, gB = base >> 32;
+        for (uint32_t h0 = 0; h0 < nent; h0 += 64) {
+            const uint32_t h = h0 + lane;
+            QEnt e = make_uint4(0, 0, 0, 0);
+            bool isA = false; uint32_t nb = 0;
+            if (h < nent) {
+                e = ent[h];
+                const int32_t pt = s_pt[wv][e.w][e.y & 1u];
+                isA = pt >= 0 && (int64_t)(e.y >> 1) + KMER <= (int64_t)pt + 1;
+                nb = isA ? 0u : __popc(e.z);
+            }
+            const unsigned long long balA = __ballot(isA);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (isA) { const unsigned long long g = gA + (uint32_t)__popcll(balA & below); if (g < qcap) qa[g] = make_uint4(e.x, e.y, e.z, 0u); }
+            gA += (uint32_t)__popcll(balA);
+            uint32_t incl = nb;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const uint32_t cT = __popc(__builtin_amdgcn_ubfe(T32, k, 16)) + 20u;
-                    const uint32_t cA = __popc(__builtin_amdgcn_ubfe(A32, k, 16)) + 20u;
-                    qT |= (k >= 5 ? (cT << (k - 5)) : (cT >> (5 - k))) & (1u << k);
-                    qA |= (k >= 5 ? (cA << (k - 5)) : (cA >> (5 - k))) & (1u << k);
-                    // byte offset of the 6-mer code in the table: code * 4
-                    const uint32_t ko = (k == 0 ? (codes << 2) : __builtin_amdgcn_alignbit(codes1, codes, 2 * k - 2)) & 0x3FFCu;
-                    hits |= *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_kmer) + ko) << k;
-                }
-                // 6-mers touching an N or leaving the read never match
-                uint32_t nv = N32 | (N32 >> 1);
-                nv |= nv >> 2;
-                nv |= N32 >> 4; nv |= N32 >> 5;
-                const uint32_t valid = ~nv & 0xFFFFu;
-                uint32_t hitF = hits & valid, hitR = (hits >> 16) & valid;
-                // window starts allowed by the loop bounds of common.py:17,28
-                qT &= range_mask16(-p0, L - 16 - p0);              // 0 <= p < L-16
-                qA &= range_mask16(1 - p0, L - 16 - p0 + 1);       // reverse strand: 0 <= L-16-p < L-16
-                if (!worker) { qT = 0; qA = 0; hitF = 0; hitR = 0; }
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d); if (lane >= d) incl += x; }
+            unsigned long long g = gB + incl - nb;
+            uint32_t m = nb ? e.z : 0u;
+            while (m) {
+                const int j = __builtin_ctz(m); m &= m - 1;
+                if (g < qcap) qb[g] = make_uint4(e.x, e.y + ((uint32_t)j << 1), 1u, 0u);
+                ++g;
+            }
+            gB += __shfl(incl, 63);
+        }
+        nent = 0;
+    };
 
-                if (!foundF) {
-                    const unsigned long long bal = __ballot(qT != 0);
-                    if (bal) {
-                        const int src = __builtin_ctzll(bal);
-                        int32_t val = 0;
-                        if (lane == src) {
-                            const int k = __builtin_ctz(qT);
-                            const uint32_t tt = (T32 & (T32 >> 1) & (T32 >> 2)) >> k;     // 'TTT' starts, common.py:31
-                            val = (int32_t)(p0 + k + (tt ? __builtin_ctz(tt) : 0));
-                        }
-                        ptF = __shfl(val, src);
-                        foundF = true;
-                    }
-                }
-                {
-                    const unsigned long long bal = __ballot(qA != 0);
-                    if (bal) {
-                        const int src = 63 - __builtin_clzll(bal);
-                        int32_t val = 0;
-                        if (lane == src) {
-                            const int k = 31 - __builtin_clz(qA);
-                            const uint32_t aa = A32 & (A32 >> 1) & (A32 >> 2);
-                            const uint32_t m = aa & ((1u << (k + 14)) - 1u);
-                            const int j = m ? 31 - __builtin_clz(m) : k + 13;
-                            val = (int32_t)((L - 16 - (p0 + k)) + (k + 13 - j));
-                        }
-                        ptR = __shfl(val, src);
-                    }
-                }
-                if (__ballot(bad != 0 && worker)) {
-                    if (bad != 0 && worker) atomicMin(&counters[C_BADREAD], (unsigned long long)r);
-                }
-                // one cluster per lane and strand: first hit + offsets of the others
-                nhits_stat += __popc(hitF) + __popc(hitR);
-                const unsigned long long balF = __ballot(hitF != 0), balR = __ballot(hitR != 0);
-                const uint32_t total = (uint32_t)(__popcll(balF) + __popcll(balR));
-                if (total) {
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    const uint32_t excl = (uint32_t)(__popcll(balF & below) + __popcll(balR & below));
-                    uint32_t slot = 0;
-                    if (lane == 0) slot = atomicAdd(&s_nent, total);
-                    slot = __shfl(slot, 0);
-                    const bool fits = slot + total <= HITBUF;
-                    unsigned long long gbase = 0;
-                    if (!fits) {            // staging full (pathological reads): this step goes straight to queue A
-                        if (lane == 0) gbase = atomicAdd(&counters[C_NA], (unsigned long long)total);
-                        gbase = __shfl(gbase, 0);
-                        for (uint32_t h = slot + lane; h < HITBUF && h < slot + total; h += 64) s_ent[h].x = HOLE_R;
-                    }
-                    unsigned long long idx = (fits ? slot : gbase) + excl;
-                    if (hitF) {
-                        const int k0 = __builtin_ctz(hitF);
-                        const QEnt e = make_uint4((uint32_t)r, (uint32_t)(p0 + k0) << 1, hitF >> k0, 0u);
-                        if (fits) s_ent[idx] = e; else if (idx < qcap) qa[idx] = e;
-                        ++idx;
-                    }
-                    if (hitR) {
-                        const int k1 = 31 - __builtin_clz(hitR);
-                        const QEnt e = make_uint4((uint32_t)r, ((uint32_t)(L - KMER - (p0 + k1)) << 1) | 1u,
-                                                  __brev(hitR) >> (31 - k1), 0u);
-                        if (fits) s_ent[idx] = e; else if (idx < qcap) qa[idx] = e;
-                    }
-                }
-                v = vn;
+    int cur = 0;
+    uint32_t tseq = 0, since_flush = 0;     // ring slot of read j of the current task: (tseq & 3) * 8 + j
+    uint32_t task = grab();
+    if (task != 0xFFFFFFFFu) load_tab(task, s_tab[wv][cur]);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    bool have_v = false;
+    while (task != 0xFFFFFFFFu) {
+        const uint32_t next_task = grab();
+        if (next_task != 0xFFFFFFFFu) load_tab(next_task, s_tab[wv][cur ^ 1]);
+        __builtin_amdgcn_wave_barrier();
+        const TaskTab& tb = s_tab[wv][cur];
+        const uint64_t r0 = (uint64_t)task * TASK_READS;
+        const uint32_t nr = (uint32_t)(n - r0 < TASK_READS ? n - r0 : TASK_READS);
+        const uint32_t nslots = tb.pend[TASK_READS - 1];
+        const uint32_t niter = (nslots + 62u) / 63u;
+        const uint32_t ring0 = (tseq & 3u) * TASK_READS;
+        if (lane < 2 * TASK_READS) s_pt[wv][ring0 + (lane >> 1)][lane & 1] = -1;
+        __builtin_amdgcn_wave_barrier();
+        if (!have_v) v = slot_vec(tb, (uint32_t)lane, nslots);
+        have_v = false;
+
+        for (uint32_t it = 0; it < niter; ++it) {
+            const uint32_t slot = it * 63u + (uint32_t)lane;
+            // next step's vector first (or the next task's first vectors)
+            uint4 vn = make_uint4(0, 0, 0, 0);
+            if (it + 1 < niter) vn = slot_vec(tb, slot + 63u, nslots);
+            else if (next_task != 0xFFFFFFFFu) {
+                const TaskTab& tn = s_tab[wv][cur ^ 1];
+                vn = slot_vec(tn, (uint32_t)lane, tn.pend[TASK_READS - 1]);
+                have_v = true;
             }
-            if (lane == 0) { polyt[2 * r] = ptF; polyt[2 * r + 1] = ptR; s_pt[ri][0] = ptF; s_pt[ri][1] = ptR; }
-        }
-        // flush.  A cluster whose first hit lies left of polyT can win the relaxed search and always gets
-        // a full alignment (queue A); the others only matter if they reach score 17 and go through the
-        // cheap per-window filter first (queue B, single hits).  One global reservation per group and queue.
-        __syncthreads();
-        const uint32_t nst = s_nent < HITBUF ? s_nent : HITBUF;
-        for (uint32_t h = tid; h < nst; h += 256) {
-            const QEnt e = s_ent[h];
-            uint32_t cls = 0, need = 1;
-            if (e.x != HOLE_R) {
-                const int32_t pt = s_pt[e.x - (uint32_t)r_begin][e.y & 1u];
-                cls = (pt >= 0 && (int64_t)(e.y >> 1) + KMER <= (int64_t)pt + 1) ? 0u : 1u;
-                need = cls ? __popc(e.z) : 1u;
+            const bool act = slot < nslots;
+            const uint32_t j = act ? find_read(tb, slot) : TASK_READS - 1u;
+            const uint32_t vidx = slot - (j ? tb.pend[j - 1] : 0u);
+            const uint64_t s = tb.s[j];
+            const int64_t L = act ? (int64_t)tb.L[j] : 0;
+            const int64_t p0 = 16ll * vidx - (int64_t)(s & 15ull);
+            const uint64_t r = r0 + j;
+
+            const uint32_t words[4] = { v.x, v.y, v.z, v.w };
+            uint32_t ta = 0, nb = 0, codes = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t b = (words[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                const uint2 c = s_cls[b];
+                ta |= c.x << k;
+                nb |= c.y << k;
+                codes |= ((b >> 1) & 3u) << (2 * k);
             }
-            const uint32_t slot = atomicAdd(&s_cls_cnt[cls], need);
-            s_slot[h] = (uint16_t)((cls << 15) | slot);
-        }
-        __syncthreads();
-        if (tid < 2 && s_cls_cnt[tid])
-            s_base[tid] = atomicAdd(&counters[tid == 0 ? C_NA : C_NB], (unsigned long long)s_cls_cnt[tid]);
-        __syncthreads();
-        for (uint32_t h = tid; h < nst; h += 256) {
-            const uint32_t sl = s_slot[h];
-            const QEnt e = s_ent[h];
-            unsigned long long g = s_base[sl >> 15] + (sl & 0x7FFFu);
-            if (!(sl >> 15)) { if (g < qcap) qa[g] = e; }
-            else if (e.x == HOLE_R) { if (g < qcap) qb[g] = e; }
-            else {
-                uint32_t m = e.z;
-                while (m) {
-                    const int j = __builtin_ctz(m); m &= m - 1;
-                    if (g < qcap) qb[g] = make_uint4(e.x, e.y + ((uint32_t)j << 1), 1u, 0u);
-                    ++g;
+            const uint32_t rm = range_mask16(-p0, L - p0);
+            const uint32_t T = ta & 0xFFFFu & rm;
+            const uint32_t A = (ta >> 16) & rm;
+            const uint32_t N = ((nb & 0xFFFFu) | ~rm) & 0xFFFFu;    // out-of-read behaves like N
+            const uint32_t bad = (nb >> 16) & rm;
+
+            // look-ahead from the next lane, unless that lane belongs to another read
+            const uint32_t j_next = __shfl_down(act ? j : 0xFFu, 1);     // all lanes must take part: an inactive source lane reads as 0
+            const bool same_next = lane < 63 && j_next == j;
+            uint32_t TA1 = __shfl_down(T | (A << 16), 1);
+            uint32_t N1 = __shfl_down(N, 1);
+            const uint32_t codes1 = __shfl_down(codes, 1);
+            if (!same_next) { TA1 = 0; N1 = 0xFFFFu; }
+            const uint32_t T32 = T | (TA1 << 16);
+            const uint32_t A32 = A | (TA1 & 0xFFFF0000u);
+            const uint32_t N32 = N | (N1 << 16);
+            const bool worker = act && lane < 63;
+
+            // 16 windows of 16 bases: bit 5 of popcount + 20 is set iff the count is >= 12 (int(16 * 0.75), common.py:11)
+            uint32_t qT = 0, qA = 0, hits = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t cT = __popc(__builtin_amdgcn_ubfe(T32, k, 16)) + 20u;
+                const uint32_t cA = __popc(__builtin_amdgcn_ubfe(A32, k, 16)) + 20u;
+                qT |= (k >= 5 ? (cT << (k - 5)) : (cT >> (5 - k))) & (1u << k);
+                qA |= (k >= 5 ? (cA << (k - 5)) : (cA >> (5 - k))) & (1u << k);
+                const uint32_t ko = (k == 0 ? (codes << 2) : __builtin_amdgcn_alignbit(codes1, codes, 2 * k - 2)) & 0x3FFCu;
+                hits |= *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_kmer) + ko) << k;
+            }
+            uint32_t nv = N32 | (N32 >> 1);
+            nv |= nv >> 2;
+            nv |= N32 >> 4; nv |= N32 >> 5;
+            const uint32_t valid = ~nv & 0xFFFFu;               // 6-mers touching an N or leaving the read never match
+            uint32_t hitF = hits & valid, hitR = (hits >> 16) & valid;
+            qT &= range_mask16(-p0, L - 16 - p0);              // 0 <= p < L-16          (common.py:17,28)
+            qA &= range_mask16(1 - p0, L - 16 - p0 + 1);       // reverse strand: 0 <= L-16-p < L-16
+            if (!worker) { qT = 0; qA = 0; hitF = 0; hitR = 0; }
+
+            // polyT candidates of this lane
+            int32_t valF = -1, valR = -1;
+            if (qT) {
+                const int k = __builtin_ctz(qT);
+                const uint32_t tt = (T32 & (T32 >> 1) & (T32 >> 2)) >> k;         // 'TTT' starts, common.py:31
+                valF = (int32_t)(p0 + k + (tt ? __builtin_ctz(tt) : 0));
+            }
+            if (qA) {
+                const int k = 31 - __builtin_clz(qA);
+                const uint32_t aa = A32 & (A32 >> 1) & (A32 >> 2);
+                const uint32_t m = aa & ((1u << (k + 14)) - 1u);
+                const int jj = m ? 31 - __builtin_clz(m) : k + 13;
+                valR = (int32_t)((L - 16 - (p0 + k)) + (k + 13 - jj));
+            }
+            const unsigned long long balT = __ballot(qT != 0), balA = __ballot(qA != 0);
+            if (balT | balA) {
+                // per read present in this step: first T-rich window, last A-rich window
+                const unsigned long long wk = __ballot(worker);
+                const uint32_t j_lo = __shfl(j, 0), j_hi = __shfl(j, wk ? 63 - __builtin_clzll(wk) : 0);
+                for (uint32_t jj = j_lo; jj <= j_hi; ++jj) {
+                    const unsigned long long seg = __ballot(worker && j == jj);
+                    const uint32_t ring = ring0 + jj;
+                    const unsigned long long bt = balT & seg, ba = balA & seg;
+                    if (bt && s_pt[wv][ring][0] == -1) {
+                        const int32_t pv = __shfl(valF, __builtin_ctzll(bt));
+                        if (lane == 0) s_pt[wv][ring][0] = pv;
+                    }
+                    if (ba) {
+                        const int32_t pv = __shfl(valR, 63 - __builtin_clzll(ba));
+                        if (lane == 0) s_pt[wv][ring][1] = pv;
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
+            if (__ballot(bad != 0 && worker)) {
+                if (bad != 0 && worker) atomicMin(&counters[C_BADREAD], (unsigned long long)r);
+            }
+            // one cluster per lane and strand: first hit + offsets of the others
+            nhits_stat += __popc(hitF) + __popc(hitR);
+            const unsigned long long balF = __ballot(hitF != 0), balR = __ballot(hitR != 0);
+            const uint32_t total = (uint32_t)(__popcll(balF) + __popcll(balR));
+            if (total) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t excl = (uint32_t)(__popcll(balF & below) + __popcll(balR & below));
+                const bool fits = nent + total <= WENT;
+                unsigned long long gbase = 0;
+                if (!fits) {            // staging full (pathological reads): this step goes straight to queue A
+                    if (lane == 0) gbase = atomicAdd(&counters[C_NAB], (unsigned long long)total) & 0xFFFFFFFFull;
+                    gbase = __shfl(gbase, 0);
+                }
+                unsigned long long idx = (fits ? nent : gbase) + excl;
+                if (hitF) {
+                    const int k0 = __builtin_ctz(hitF);
+                    const QEnt e = make_uint4((uint32_t)r, (uint32_t)(p0 + k0) << 1, hitF >> k0, fits ? ring0 + j : 0u);
+                    if (fits) ent[idx] = e; else if (idx < qcap) qa[idx] = e;
+                    ++idx;
+                }
+                if (hitR) {
+                    const int k1 = 31 - __builtin_clz(hitR);
+                    const QEnt e = make_uint4((uint32_t)r, ((uint32_t)(L - KMER - (p0 + k1)) << 1) | 1u,
+                                              __brev(hitR) >> (31 - k1), fits ? ring0 + j : 0u);
+                    if (fits) ent[idx] = e; else if (idx < qcap) qa[idx] = e;
+                }
+                if (fits) nent += total;
+            }
+            v = vn;
         }
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < 2 * nr) polyt[2 * r0 + lane] = s_pt[wv][ring0 + (lane >> 1)][lane & 1];
+        ++tseq; ++since_flush;
+        if (nent >= WFLUSH || since_flush >= 3) { flush(); since_flush = 0; }      // staged clusters never outlive the 4-task ring
+        task = next_task;
+        cur ^= 1;
     }
+    flush();
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) nhits_stat += __shfl_xor(nhits_stat, d);
     if (lane == 0 && nhits_stat) atomicAdd(&counters[C_NHITS], (unsigned long long)nhits_stat);
@@ -459,7 +534,7 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                      const QEnt* __restrict__ qb, QEnt* __restrict__ qa, uint64_t qcap,
                      unsigned long long* __restrict__ counters)
 {
-    unsigned long long nb = counters[C_NB];
+    unsigned long long nb = counters[C_NAB] >> 32;
     if (nb > qcap) nb = qcap;
     const int lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * 256ull;
@@ -483,7 +558,7 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         if (m) {
             unsigned long long gb = 0;
             const uint32_t cnt = (uint32_t)__popcll(m);
-            if (lane == 0) gb = atomicAdd(&counters[C_NA], (unsigned long long)cnt);
+            if (lane == 0) gb = atomicAdd(&counters[C_NAB], (unsigned long long)cnt) & 0xFFFFFFFFull;
             gb = __shfl(gb, 0);
             if (keep) {
                 const unsigned long long idx = gb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -511,6 +586,7 @@ void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                    unsigned long long* __restrict__ keys)
 {
     unsigned long long nq = counters[count_idx];
+    if (count_idx == C_NAB) nq &= 0xFFFFFFFFull;
     if (nq > qcap) nq = qcap;
     const int lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * 256ull;
@@ -751,7 +827,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     }
     if ((rc = bdg_reserve(ctx, ctx->x_polyt, sizeof(int32_t) * 2ull * n))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->x_keys, sizeof(uint64_t) * 4ull * n))) return rc;
-    if ((rc = bdg_reserve(ctx, ctx->x_counters, 64))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->x_counters, 64 + TASK_SHARDS * 128))) return rc;     // counters | task counters (one 128-B line each)
     // three cluster queues (A: aligned, B: filtered first, C: re-queued hits of a cluster), 16 B per entry
     uint64_t want = total_bytes / 48 + 4096;
     if (want < ctx->x_hits_cap) want = ctx->x_hits_cap;
@@ -767,16 +843,18 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     auto* counters = static_cast<unsigned long long*>(ctx->x_counters.p);
     auto* keys = static_cast<unsigned long long*>(ctx->x_keys.p);
     const auto* pt = static_cast<const int32_t*>(ctx->x_polyt.p);
-    BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, st));
+    BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64 + TASK_SHARDS * 128, st));
     BDG_HIP_TRY(ctx, hipMemsetAsync(counters + C_BADREAD, 0xFF, 8, st));
     BDG_HIP_TRY(ctx, hipMemsetAsync(keys, 0, sizeof(uint64_t) * 4ull * n, st));
     {
         ScopedKernelTimer tm(ctx, "k_scan_reads");
-        const uint32_t ngroups = (n + READS_PER_BLOCK - 1) / READS_PER_BLOCK;
-        const uint32_t grid = ngroups < 256u * 5u ? ngroups : 256u * 5u;       // persistent: 5 blocks per CU
+        const uint32_t ntasks = (n + TASK_READS - 1) / TASK_READS;
+        uint32_t grid = (ntasks + 3) / 4;
+        if (grid > 256u * 5u) grid = 256u * 5u;                                  // persistent: 5 blocks per CU
+        grid = (grid + TASK_SHARDS - 1) / TASK_SHARDS * TASK_SHARDS;            // every shard has a block
         hipLaunchKernelGGL(k_scan_reads, dim3(grid), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
                            static_cast<const uint32_t*>(ctx->x_lut.p), static_cast<int32_t*>(ctx->x_polyt.p),
-                           qa, qb, qcap, counters);
+                           qa, qb, qcap, counters, reinterpret_cast<unsigned int*>(counters + 8));
     }
     {
         ScopedKernelTimer tm(ctx, "k_strict_filter");
@@ -786,7 +864,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     {
         ScopedKernelTimer tm(ctx, "k_sw_clusters");
         hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 8), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,
-                           qa, (int)C_NA, qcap, qc, counters, keys);
+                           qa, (int)C_NAB, qcap, qc, counters, keys);
     }
     {
         ScopedKernelTimer tm(ctx, "k_sw_requeued");
@@ -811,8 +889,9 @@ int bdg_extract_status_impl(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_window
     BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (bad_read) *bad_read = c[C_BADREAD];
     if (n_windows) *n_windows = c[C_NWINDOWS];
-    if (c[C_NA] > ctx->x_hits_cap || c[C_NB] > ctx->x_hits_cap || c[C_NC] > ctx->x_hits_cap) {
-        uint64_t want = c[C_NA] > c[C_NB] ? c[C_NA] : c[C_NB];
+    const uint64_t cA = c[C_NAB] & 0xFFFFFFFFull, cB = c[C_NAB] >> 32;
+    if (cA > ctx->x_hits_cap || cB > ctx->x_hits_cap || c[C_NC] > ctx->x_hits_cap) {
+        uint64_t want = cA > cB ? cA : cB;
         want = (want > c[C_NC] ? want : c[C_NC]) + c[C_NKEPT] + 4096;
         ctx->x_hits_cap = want;            // next launch reserves this much
         return bdg_fail(ctx, BDG_E_CAPACITY, "window queue overflow: rerun the batch (workspace grown)");
