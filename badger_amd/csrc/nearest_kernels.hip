@@ -157,19 +157,29 @@ void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t nq, PairTables pt,
     if (i >= nq) return;
     const uint32_t qq = q[i];
     uint32_t best = 3u, bidx = NONE_IDX, ties = 0u;
+    uint32_t lo[6], hi[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {                      // all six bucket bounds first: independent loads
+        const uint32_t* o = pt.off + (size_t)p * 65537u + pair_key(qq, p);
+        lo[p] = o[0]; hi[p] = o[1];
+    }
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
-        const uint32_t key = pair_key(qq, p);
-        const uint32_t* o = pt.off + (size_t)p * 65537u + key;
-        const uint32_t lo = o[0], hi = o[1];
-        const uint2* e = pt.ent + (size_t)p * pt.nw;
-        for (uint32_t k = lo; k < hi; ++k) {
-            const uint2 w = e[k];
-            const uint32_t x = qq ^ w.x;
-            const uint32_t h = hamming16(x);
-            if (h <= 2u && h <= best && canonical_pair(x) == p) {
-                if (h < best) { best = h; bidx = w.y; ties = 1u; }
-                else { ties++; bidx = w.y < bidx ? w.y : bidx; }
+        if (p == 1 && best == 0u) break;               // an exact match sits in table 0 and nothing can tie with it
+        const uint2* e = pt.ent + (size_t)p * (((size_t)pt.nw + 1) & ~size_t(1));
+        // two entries per 16-byte load; the table base is 16-byte aligned, so even entry indices are too
+        for (uint32_t k = lo[p] & ~1u; k < hi[p]; k += 2) {
+            const uint4 w2 = *reinterpret_cast<const uint4*>(e + k);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const uint32_t wr = half ? w2.z : w2.x, wo = half ? w2.w : w2.y;
+                const uint32_t kk = k + half;
+                const uint32_t x = qq ^ wr;
+                const uint32_t h = hamming16(x);
+                if (kk >= lo[p] && kk < hi[p] && h <= 2u && h <= best && canonical_pair(x) == p) {
+                    if (h < best) { best = h; bidx = wo; ties = 1u; }
+                    else { ties++; bidx = wo < bidx ? wo : bidx; }
+                }
             }
         }
     }
@@ -201,42 +211,62 @@ void k_nearest_delins(const uint32_t* __restrict__ q, const uint32_t* __restrict
 {
     const uint32_t n2 = counters[0];
     const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
-    const uint32_t gq = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u + (uint32_t)grp;     // query slot of this 16-lane group
+    const uint32_t wave_slot0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u;     // first query slot of this wave
     const uint32_t ngroups = gridDim.x * 16u;
-    for (uint32_t s0 = gq - (uint32_t)grp; s0 < n2; s0 += ngroups) {      // wave-uniform loop bound
+    const unsigned long long gmask = 0xFFFFull << (16 * grp);
+    for (uint32_t s0 = wave_slot0; s0 < n2; s0 += ngroups) {                      // wave-uniform loop bound
         const uint32_t s = s0 + (uint32_t)grp;
         const bool on = s < n2;
         const uint32_t qi = on ? list2[s] : 0u;
         const uint32_t qq = on ? q[qi] : 0u;
-        uint32_t found[4] = { 0, 0, 0, 0 }; int nf = 0; bool overflow = false;
-        // deletion variant of this lane; equal neighbours give equal variants -> keep the first of a run
-        const int i = sub;
-        const uint32_t lm = low_mask(i);
+        // lane i of the group: deletion variant i (equal neighbours give equal variants: keep the first of a run)
+        const uint32_t lm = low_mask(sub);
         const uint32_t d = ((qq & lm) | ((qq >> 2) & ~lm)) & 0x3FFFFFFFu;
-        const bool dup_del = i > 0 && (((qq >> (2 * i)) ^ (qq >> (2 * i - 2))) & 3u) == 0u;
+        const bool dup_del = sub > 0 && (((qq >> (2 * sub)) ^ (qq >> (2 * sub - 2))) & 3u) == 0u;
         const bool hit = on && !dup_del && ((delmap[d >> 5] >> (d & 31u)) & 1u);
-        if (hit) {
-            for (int t = 0; t < 64; ++t) {
-                const int sl = t >> 2; const uint32_t c = (uint32_t)t & 3u;
-                // inserting c next to an equal base repeats the previous slot's string
-                if (sl > 0 && ((d >> (2 * sl - 2)) & 3u) == c) continue;
-                const uint32_t sm = low_mask(sl);
-                const uint32_t r = (d & sm) | (c << (2 * sl)) | ((d & ~sm) << 2);
-                if (hamming16(r ^ qq) <= 2u) continue;          // pass 1 has it (or it is the query itself)
-                uint32_t o;
-                if (wl_lookup(ix, r, o)) {
-                    const bool dup = (nf > 0 && found[0] == o) || (nf > 1 && found[1] == o) ||
-                                     (nf > 2 && found[2] == o) || (nf > 3 && found[3] == o);
-                    if (!dup) {
-                        if (nf < 4) { found[0] = nf == 0 ? o : found[0]; found[1] = nf == 1 ? o : found[1];
-                                      found[2] = nf == 2 ? o : found[2]; found[3] = nf == 3 ? o : found[3]; ++nf; }
-                        else overflow = true;
+        unsigned long long pend = __ballot(hit);
+        uint32_t found[4] = { 0, 0, 0, 0 }; int nf = 0; bool overflow = false;
+        // each variant that occurs in the whitelist: the group's 16 lanes take one insertion slot each, 4 letters
+        while (pend) {
+            const unsigned long long mine = pend & gmask;
+            const int src = mine ? __builtin_ctzll(mine) : lane;
+            const uint32_t dv = __shfl(d, src);
+            if (mine) {
+                const uint32_t sm = low_mask(sub);
+                const uint32_t prev = sub > 0 ? (dv >> (2 * sub - 2)) & 3u : 4u;
+                uint32_t r[4]; bool go[4]; uint32_t o[4] = { 0, 0, 0, 0 };
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) {
+                    r[c] = (dv & sm) | (c << (2 * sub)) | ((dv & ~sm) << 2);
+                    // inserting c next to an equal base repeats the previous slot's string; Hamming <= 2 is pass 1's
+                    go[c] = prev != c && hamming16(r[c] ^ qq) > 2u;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) go[c] = go[c] && wl_lookup(ix, r[c], o[c]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (go[c]) {
+                        const uint32_t oo = o[c];
+                        const bool dup = (nf > 0 && found[0] == oo) || (nf > 1 && found[1] == oo) ||
+                                         (nf > 2 && found[2] == oo) || (nf > 3 && found[3] == oo);
+                        if (!dup) {
+                            if (nf < 4) { found[0] = nf == 0 ? oo : found[0]; found[1] = nf == 1 ? oo : found[1];
+                                          found[2] = nf == 2 ? oo : found[2]; found[3] = nf == 3 ? oo : found[3]; ++nf; }
+                            else overflow = true;
+                        }
                     }
                 }
             }
+            // every group drops the variant it just handled
+            unsigned long long done = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned long long m = pend & (0xFFFFull << (16 * g));
+                if (m) done |= 1ull << __builtin_ctzll(m);
+            }
+            pend &= ~done;
         }
         // merge inside the 16-lane group: distinct hits, lowest caller index
-        const unsigned long long gmask = 0xFFFFull << (16 * grp);
         const bool any_over = (__ballot(overflow) & gmask) != 0;
         uint32_t add = 0, midx = NONE_IDX;
         int pending = nf;
@@ -261,7 +291,7 @@ void k_nearest_delins(const uint32_t* __restrict__ q, const uint32_t* __restrict
             else if (add) {
                 const uint32_t cur_ed = best_ed[qi];
                 uint32_t t = add, bi = midx;
-                if (cur_ed == 2u) { t += n_ties[qi]; const uint32_t o = best_idx[qi]; bi = o < bi ? o : bi; }
+                if (cur_ed == 2u) { t += n_ties[qi]; const uint32_t o2 = best_idx[qi]; bi = o2 < bi ? o2 : bi; }
                 best_idx[qi] = bi; best_ed[qi] = 2; n_ties[qi] = (uint16_t)(t > 0xFFFFu ? 0xFFFFu : t);
             }
         }
@@ -307,7 +337,8 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
 
     // six block-pair tables (counting sort by the 16-bit pair key)
     std::vector<uint32_t> poff(6u * 65537u, 0u);
-    std::vector<uint2> pent(6ull * nw);
+    const size_t nwe = ((size_t)nw + 1) & ~size_t(1);          // table stride: even, so every table starts 16-byte aligned
+    std::vector<uint2> pent(6ull * nwe, make_uint2(0, 0));
     for (int p = 0; p < 6; ++p) {
         const int bi = p < 3 ? 0 : (p < 5 ? 1 : 2);
         const int bj = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
@@ -316,7 +347,7 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
         for (uint32_t i = 0; i < nw; ++i) o[key(srt[i]) + 1]++;
         for (uint32_t k = 0; k < 65536u; ++k) o[k + 1] += o[k];
         std::vector<uint32_t> fill(o, o + 65536);
-        uint2* e = pent.data() + (size_t)p * nw;
+        uint2* e = pent.data() + (size_t)p * nwe;
         for (uint32_t i = 0; i < nw; ++i) { uint2 v; v.x = srt[i]; v.y = order[i]; e[fill[key(srt[i])]++] = v; }
     }
     if ((rc = bdg_reserve(ctx, ctx->w_poff, sizeof(uint32_t) * poff.size()))) return rc;
