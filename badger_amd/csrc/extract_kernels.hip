@@ -57,10 +57,9 @@ constexpr uint32_t HOLE_R = 0xFFFFFFFFu;   // unused queue slot
 // queue entry: {read, (pos << 1) | strand, offset mask of the hits (bit 0 = first hit), unused}
 typedef uint4 QEnt;
 
-__device__ __forceinline__ uint32_t range_mask16(int64_t lo, int64_t hi)
+__device__ __forceinline__ uint32_t range_mask16(int32_t lo, int32_t hi)
 {
-    int l = lo < 0 ? 0 : (lo > 16 ? 16 : (int)lo);
-    int h = hi < 0 ? 0 : (hi > 16 ? 16 : (int)hi);
+    const int l = min(max(lo, 0), 16), h = min(max(hi, 0), 16);
     return h > l ? (((1u << h) - 1u) & ~((1u << l) - 1u)) : 0u;
 }
 
@@ -76,7 +75,7 @@ __device__ __forceinline__ uint32_t range_mask16(int64_t lo, int64_t hi)
 // 64-bit reservation (A count | B count << 32) every few tasks.
 // ---------------------------------------------------------------------------
 constexpr int TASK_READS = 8;
-constexpr uint32_t WENT = 320;             // per-wave staging (5 KiB)
+constexpr uint32_t WENT = 320;             // per-wave staging (2.5 KiB)
 constexpr uint32_t WFLUSH = 192;           // flush once this many clusters are staged
 constexpr int TASK_SHARDS = 8;
 
@@ -95,7 +94,7 @@ __device__ __forceinline__ uint32_t find_read(const TaskTab& t, uint32_t slot)
     return j;
 }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 5)
 void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                   const uint64_t* __restrict__ off, uint32_t n,
                   const uint32_t* __restrict__ tables,
@@ -104,20 +103,22 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                   unsigned long long* __restrict__ counters,
                   unsigned int* __restrict__ task_ctr)
 {
-    __shared__ uint32_t s_kmer[4096];    // 6-mer code -> bit0 R1 6-mer, bit16 reverse-complement of one
+    __shared__ uint16_t s_kmer[4096];    // 6-mer code -> bit0 R1 6-mer, bit8 reverse-complement of one
     __shared__ uint2 s_cls[256];         // byte -> {isT | isA<<16, isN | bad<<16}
-    __shared__ QEnt s_ent[4][WENT];      // per-wave cluster staging
+    __shared__ uint2 s_ent[4][WENT];     // per-wave cluster staging {(pos << 1) | strand, mask | ring slot << 16}
+    __shared__ uint32_t s_ringr[4][32];  // read index of each ring slot
     __shared__ TaskTab s_tab[4][2];
-    __shared__ int32_t s_pt[4][32][2];   // polyT of the wave's last 32 reads (ring by read index)
+    __shared__ int32_t s_pt[4][32][2];   // polyT of the reads of the wave's last 4 tasks (ring)
+    __shared__ uint32_t s_cand[4][128];  // T/A-rich window candidates of one step
     const int tid = threadIdx.x;
-    for (int k = tid; k < 4096; k += 256) s_kmer[k] = tables[768 + k];
+    for (int k = tid; k < 4096; k += 256) { const uint32_t t = tables[768 + k]; s_kmer[k] = (uint16_t)((t & 1u) | ((t >> 16) << 8)); }
     s_cls[tid] = reinterpret_cast<const uint2*>(tables + 256)[tid];
     __syncthreads();
 
     const int lane = tid & 63, wv = tid >> 6;
     const uint32_t ntasks = (n + TASK_READS - 1) / TASK_READS;
     const uint32_t shard = blockIdx.x % TASK_SHARDS;
-    QEnt* ent = s_ent[wv];
+    uint2* ent = s_ent[wv];
     uint32_t nent = 0, nhits_stat = 0;
 
     // take a task: k-th grab of this shard is task k * TASK_SHARDS + shard
@@ -163,10 +164,10 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             const uint32_t h = h0 + lane;
             uint32_t a = 0, b = 0;
             if (h < nent) {
-                const QEnt e = ent[h];
-                const int32_t pt = s_pt[wv][e.w][e.y & 1u];
-                const bool isA = pt >= 0 && (int64_t)(e.y >> 1) + KMER <= (int64_t)pt + 1;
-                a = isA ? 1u : 0u; b = isA ? 0u : __popc(e.z);
+                const uint2 e = ent[h];
+                const int32_t pt = s_pt[wv][e.y >> 16][e.x & 1u];
+                const bool isA = pt >= 0 && (int64_t)(e.x >> 1) + KMER <= (int64_t)pt + 1;
+                a = isA ? 1u : 0u; b = isA ? 0u : __popc(e.y & 0xFFFFu);
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
@@ -181,14 +182,15 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             QEnt e = make_uint4(0, 0, 0, 0);
             bool isA = false; uint32_t nb = 0;
             if (h < nent) {
-                e = ent[h];
-                const int32_t pt = s_pt[wv][e.w][e.y & 1u];
-                isA = pt >= 0 && (int64_t)(e.y >> 1) + KMER <= (int64_t)pt + 1;
+                const uint2 st = ent[h];
+                e = make_uint4(s_ringr[wv][st.y >> 16], st.x, st.y & 0xFFFFu, 0u);
+                const int32_t pt = s_pt[wv][st.y >> 16][st.x & 1u];
+                isA = pt >= 0 && (int64_t)(st.x >> 1) + KMER <= (int64_t)pt + 1;
                 nb = isA ? 0u : __popc(e.z);
             }
             const unsigned long long balA = __ballot(isA);
             const unsigned long long below = (1ull << lane) - 1ull;
-            if (isA) { const unsigned long long g = gA + (uint32_t)__popcll(balA & below); if (g < qcap) qa[g] = make_uint4(e.x, e.y, e.z, 0u); }
+            if (isA) { const unsigned long long g = gA + (uint32_t)__popcll(balA & below); if (g < qcap) qa[g] = e; }
             gA += (uint32_t)__popcll(balA);
             uint32_t incl = nb;
 #pragma unroll
@@ -218,10 +220,30 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const TaskTab& tb = s_tab[wv][cur];
         const uint64_t r0 = (uint64_t)task * TASK_READS;
         const uint32_t nr = (uint32_t)(n - r0 < TASK_READS ? n - r0 : TASK_READS);
-        const uint32_t nslots = tb.pend[TASK_READS - 1];
+        uint32_t P[TASK_READS];                 // vectors of reads 0..k inclusive, wave-uniform (scalar registers)
+#pragma unroll
+        for (int k = 0; k < TASK_READS; ++k) P[k] = __builtin_amdgcn_readfirstlane(tb.pend[k]);
+        const uint32_t nslots = P[TASK_READS - 1];
         const uint32_t niter = (nslots + 62u) / 63u;
+        // slot -> (read j, first slot of read j): compares against scalars, no dependent LDS search
+        auto map_slot = [&](uint32_t slot, uint32_t& jj, uint32_t& base) {
+            jj = 0; base = 0;
+#pragma unroll
+            for (int k = 0; k < TASK_READS - 1; ++k) { const bool ge = P[k] <= slot; jj += ge ? 1u : 0u; base = ge ? P[k] : base; }
+        };
+        auto slot_vec_cur = [&](uint32_t slot) -> uint4 {
+            uint4 vv = make_uint4(0, 0, 0, 0);
+            if (slot < nslots) {
+                uint32_t jj, base;
+                map_slot(slot, jj, base);
+                const uint64_t g0 = (tb.s[jj] & ~15ull) + 16ull * (slot - base);
+                if (g0 < total_rounded) vv = *reinterpret_cast<const uint4*>(bases + g0);
+            }
+            return vv;
+        };
         const uint32_t ring0 = (tseq & 3u) * TASK_READS;
         if (lane < 2 * TASK_READS) s_pt[wv][ring0 + (lane >> 1)][lane & 1] = -1;
+        if (lane < TASK_READS) s_ringr[wv][ring0 + lane] = (uint32_t)(r0 + lane);
         __builtin_amdgcn_wave_barrier();
         if (!have_v) v = slot_vec(tb, (uint32_t)lane, nslots);
         have_v = false;
@@ -230,35 +252,68 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             const uint32_t slot = it * 63u + (uint32_t)lane;
             // next step's vector first (or the next task's first vectors)
             uint4 vn = make_uint4(0, 0, 0, 0);
-            if (it + 1 < niter) vn = slot_vec(tb, slot + 63u, nslots);
+            if (it + 1 < niter) vn = slot_vec_cur(slot + 63u);
             else if (next_task != 0xFFFFFFFFu) {
                 const TaskTab& tn = s_tab[wv][cur ^ 1];
                 vn = slot_vec(tn, (uint32_t)lane, tn.pend[TASK_READS - 1]);
                 have_v = true;
             }
             const bool act = slot < nslots;
-            const uint32_t j = act ? find_read(tb, slot) : TASK_READS - 1u;
-            const uint32_t vidx = slot - (j ? tb.pend[j - 1] : 0u);
+            uint32_t j, jbase;
+            map_slot(act ? slot : nslots - 1u, j, jbase);
+            const uint32_t vidx = slot - jbase;
             const uint64_t s = tb.s[j];
-            const int64_t L = act ? (int64_t)tb.L[j] : 0;
-            const int64_t p0 = 16ll * vidx - (int64_t)(s & 15ull);
+            const int32_t L = act ? tb.L[j] : 0;
+            const int32_t p0 = 16 * (int32_t)vidx - (int32_t)(s & 15ull);
             const uint64_t r = r0 + j;
 
+            // byte classes.  Fast path: (byte >> 1) & 7 is a perfect hash of "ACTG" (0..3) and 'N' (7); v_perm maps it
+            // to the expected letter and to the T / A / N flags, v_dot4 packs four flags into a nibble.  Any byte that
+            // is not its expected letter (bad base, or the zero padding behind the last read) sends the wave through
+            // the exact per-byte table instead.
             const uint32_t words[4] = { v.x, v.y, v.z, v.w };
-            uint32_t ta = 0, nb = 0, codes = 0;
+            uint32_t T, A, N, bad = 0, codes;
+            uint32_t sel[4], diff = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t b = (words[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                const uint2 c = s_cls[b];
-                ta |= c.x << k;
-                nb |= c.y << k;
-                codes |= ((b >> 1) & 3u) << (2 * k);
+            for (int d = 0; d < 4; ++d) {
+                sel[d] = (words[d] >> 1) & 0x07070707u;
+                diff |= __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, sel[d]) ^ words[d];
             }
             const uint32_t rm = range_mask16(-p0, L - p0);
-            const uint32_t T = ta & 0xFFFFu & rm;
-            const uint32_t A = (ta >> 16) & rm;
-            const uint32_t N = ((nb & 0xFFFFu) | ~rm) & 0xFFFFu;    // out-of-read behaves like N
-            const uint32_t bad = (nb >> 16) & rm;
+            if (__ballot(diff != 0) == 0) {
+                uint32_t t01 = 0, t23 = 0, a01 = 0, a23 = 0, n01 = 0, n23 = 0, c[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t wgt = (d & 1) ? 0x80402010u : 0x08040201u;
+                    const uint32_t fT = __builtin_amdgcn_perm(0u, 0x00010000u, sel[d]);
+                    const uint32_t fA = __builtin_amdgcn_perm(0u, 0x00000001u, sel[d]);
+                    const uint32_t fN = __builtin_amdgcn_perm(0x01000000u, 0u, sel[d]);
+                    if (d < 2) { t01 = __builtin_amdgcn_udot4(fT, wgt, t01, false); a01 = __builtin_amdgcn_udot4(fA, wgt, a01, false);
+                                 n01 = __builtin_amdgcn_udot4(fN, wgt, n01, false); }
+                    else       { t23 = __builtin_amdgcn_udot4(fT, wgt, t23, false); a23 = __builtin_amdgcn_udot4(fA, wgt, a23, false);
+                                 n23 = __builtin_amdgcn_udot4(fN, wgt, n23, false); }
+                    c[d] = __builtin_amdgcn_udot4(sel[d] & 0x03030303u, 0x40100401u, 0u, false);
+                }
+                T = (t01 | (t23 << 8)) & rm;
+                A = (a01 | (a23 << 8)) & rm;
+                N = ((n01 | (n23 << 8)) | ~rm) & 0xFFFFu;       // out-of-read behaves like N
+                codes = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+            } else {
+                uint32_t ta = 0, nb = 0;
+                codes = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t b = (words[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                    const uint2 cc = s_cls[b];
+                    ta |= cc.x << k;
+                    nb |= cc.y << k;
+                    codes |= ((b >> 1) & 3u) << (2 * k);
+                }
+                T = ta & 0xFFFFu & rm;
+                A = (ta >> 16) & rm;
+                N = ((nb & 0xFFFFu) | ~rm) & 0xFFFFu;
+                bad = (nb >> 16) & rm;
+            }
 
             // look-ahead from the next lane, unless that lane belongs to another read
             const uint32_t j_next = __shfl_down(act ? j : 0xFFu, 1);     // all lanes must take part: an inactive source lane reads as 0
@@ -272,25 +327,60 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             const uint32_t N32 = N | (N1 << 16);
             const bool worker = act && lane < 63;
 
-            // 16 windows of 16 bases: bit 5 of popcount + 20 is set iff the count is >= 12 (int(16 * 0.75), common.py:11)
-            uint32_t qT = 0, qA = 0, hits = 0;
+            // R1 6-mer hits of both strands: 16 table probes
+            uint32_t hlo = 0, hhi = 0;          // probes of bases 0..7 / 8..15: F bits 0..7, R bits 8..15 of each
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const uint32_t cT = __popc(__builtin_amdgcn_ubfe(T32, k, 16)) + 20u;
-                const uint32_t cA = __popc(__builtin_amdgcn_ubfe(A32, k, 16)) + 20u;
-                qT |= (k >= 5 ? (cT << (k - 5)) : (cT >> (5 - k))) & (1u << k);
-                qA |= (k >= 5 ? (cA << (k - 5)) : (cA >> (5 - k))) & (1u << k);
-                const uint32_t ko = (k == 0 ? (codes << 2) : __builtin_amdgcn_alignbit(codes1, codes, 2 * k - 2)) & 0x3FFCu;
-                hits |= *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_kmer) + ko) << k;
+                // byte offset of the 6-mer code in the table: code * 2
+                const uint32_t ko = (k == 0 ? (codes << 1) : __builtin_amdgcn_alignbit(codes1, codes, 2 * k - 1)) & 0x1FFEu;
+                const uint32_t e = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(s_kmer) + ko);
+                if (k < 8) hlo |= e << k; else hhi |= e << (k - 8);
             }
+            const uint32_t hits = (hlo & 0xFFu) | ((hhi & 0xFFu) << 8) | ((hlo & 0xFF00u) << 8) | ((hhi & 0xFF00u) << 16);
             uint32_t nv = N32 | (N32 >> 1);
             nv |= nv >> 2;
             nv |= N32 >> 4; nv |= N32 >> 5;
             const uint32_t valid = ~nv & 0xFFFFu;               // 6-mers touching an N or leaving the read never match
             uint32_t hitF = hits & valid, hitR = (hits >> 16) & valid;
+            if (!worker) { hitF = 0; hitR = 0; }
+
+            // polyT windows.  A 16-window with >= 12 T (int(16 * 0.75), common.py:11) needs >= 12 T among the 31 bases a
+            // lane can see, which few lanes have: those lanes hand their mask to a compact set of lanes, so the 16-shift
+            // count loop runs once per wave for T and A candidates together instead of twice in every lane.
+            uint32_t qT = 0, qA = 0;
+            {
+                const bool cT = worker && __popc(T32 & 0x7FFFFFFFu) >= 12, cA = worker && __popc(A32 & 0x7FFFFFFFu) >= 12;
+                const unsigned long long bT = __ballot(cT), bA = __ballot(cA);
+                const uint32_t nT = (uint32_t)__popcll(bT), nc = nT + (uint32_t)__popcll(bA);
+                if (nc) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const uint32_t rkT = (uint32_t)__popcll(bT & below), rkA = nT + (uint32_t)__popcll(bA & below);
+                    uint32_t* cand = s_cand[wv];
+                    if (cT) cand[rkT] = T32;
+                    if (cA) cand[rkA] = A32;
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t c0 = 0; c0 < nc; c0 += 64) {
+                        const uint32_t ci = c0 + (uint32_t)lane;
+                        if (ci < nc) {
+                            const uint32_t m = cand[ci];
+                            uint32_t qq = 0;
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) {
+                                // bit 5 of popcount + 20 is set iff the count is >= 12
+                                const uint32_t cnt = __popc(__builtin_amdgcn_ubfe(m, k, 16)) + 20u;
+                                qq |= (k >= 5 ? (cnt << (k - 5)) : (cnt >> (5 - k))) & (1u << k);
+                            }
+                            cand[ci] = qq;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (cT) qT = cand[rkT];
+                    if (cA) qA = cand[rkA];
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
             qT &= range_mask16(-p0, L - 16 - p0);              // 0 <= p < L-16          (common.py:17,28)
             qA &= range_mask16(1 - p0, L - 16 - p0 + 1);       // reverse strand: 0 <= L-16-p < L-16
-            if (!worker) { qT = 0; qA = 0; hitF = 0; hitR = 0; }
 
             // polyT candidates of this lane
             int32_t valF = -1, valR = -1;
@@ -345,15 +435,15 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 unsigned long long idx = (fits ? nent : gbase) + excl;
                 if (hitF) {
                     const int k0 = __builtin_ctz(hitF);
-                    const QEnt e = make_uint4((uint32_t)r, (uint32_t)(p0 + k0) << 1, hitF >> k0, fits ? ring0 + j : 0u);
-                    if (fits) ent[idx] = e; else if (idx < qcap) qa[idx] = e;
+                    const QEnt e = make_uint4((uint32_t)r, (uint32_t)(p0 + k0) << 1, hitF >> k0, 0u);
+                    if (fits) ent[idx] = make_uint2(e.y, e.z | ((ring0 + j) << 16)); else if (idx < qcap) qa[idx] = e;
                     ++idx;
                 }
                 if (hitR) {
                     const int k1 = 31 - __builtin_clz(hitR);
                     const QEnt e = make_uint4((uint32_t)r, ((uint32_t)(L - KMER - (p0 + k1)) << 1) | 1u,
-                                              __brev(hitR) >> (31 - k1), fits ? ring0 + j : 0u);
-                    if (fits) ent[idx] = e; else if (idx < qcap) qa[idx] = e;
+                                              __brev(hitR) >> (31 - k1), 0u);
+                    if (fits) ent[idx] = make_uint2(e.y, e.z | ((ring0 + j) << 16)); else if (idx < qcap) qa[idx] = e;
                 }
                 if (fits) nent += total;
             }
