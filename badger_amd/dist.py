@@ -45,7 +45,8 @@ def all_max(value, device=None):
     """max over ranks of a python float"""
     if not dist.is_initialized():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    on_gpu = device is not None and device.type == "cuda" and dist.get_backend() == "nccl"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if on_gpu else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
 

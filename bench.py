@@ -70,9 +70,14 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    bdist.init(backend="nccl", device=dev)           # RCCL; only the barrier and the clock use it
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("BADGER_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 path with ranks sharing a GPU
+    if local_rank >= ndev and backend == "nccl":
+        raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, ndev))
+    local_dev = local_rank % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    bdist.init(backend=backend, device=dev)           # RCCL; only the barrier and the clock use it
 
     # ---- inputs, resident in HBM before the clock starts
     wl = synth.make_whitelist(args.whitelist)
@@ -88,7 +93,7 @@ def main():
     best_ed = torch.zeros(n, dtype=torch.uint8, device=dev)
     n_ties = torch.zeros(n, dtype=torch.int16, device=dev)
 
-    ctx = _native.Context(local_rank)
+    ctx = _native.Context(local_dev)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
     ctx.whitelist_load(wl)

@@ -35,7 +35,9 @@ def lib():
         return _LIB
     path = os.path.join(_HERE, "libbadger_oracle.so")
     src = os.path.join(_HERE, "badger_oracle.c")
-    if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+    if os.environ.get("BADGER_ORACLE_LIB"):          # e.g. the ASan/UBSan build (make -C oracle asan)
+        path = os.environ["BADGER_ORACLE_LIB"]
+    elif not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
         build()
     L = C.CDLL(path)
     i32p = C.POINTER(C.c_int32)

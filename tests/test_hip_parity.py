@@ -251,3 +251,101 @@ def test_graph_edge_cases(ctx):
     assert len(e) == 1 and tuple(e[0]) == (0, 1, 1)
     with pytest.raises(_native.BadgerHipError):
         ctx.graph_edges(np.array([3, 3], np.uint32), 1, 5)
+
+
+# --------------------------------------------------------------------------- fuzz
+def _fragment_reads(rng, n):
+    """Reads glued from adapter pieces, T/A runs, N and junk: many tiny reads, every branch boundary."""
+    R1 = "CTACACGACGCTCTTCCGATCT"
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))
+    rnd = lambda k: "".join("ACGT"[i] for i in rng.integers(0, 4, k))
+
+    def mutate(s, p):
+        out = []
+        for ch in s:
+            u = rng.random()
+            if u < p: out.append("ACGT"[int(rng.integers(0, 4))])
+            elif u < 1.5 * p: continue
+            elif u < 2 * p: out.append(ch + "ACGT"[int(rng.integers(0, 4))])
+            else: out.append(ch)
+        return "".join(out)
+
+    seqs = []
+    for _ in range(n):
+        parts = []
+        for _ in range(int(rng.integers(0, 7))):
+            kind = int(rng.integers(0, 8))
+            if kind == 0: parts.append(rnd(int(rng.integers(0, 60))))
+            elif kind == 1: parts.append(mutate(R1, float(rng.choice([0.0, 0.05, 0.15]))))
+            elif kind == 2: parts.append(R1[int(rng.integers(0, 10)):int(rng.integers(12, 23))])
+            elif kind == 3: parts.append(mutate("T" * int(rng.integers(3, 45)), float(rng.choice([0.0, 0.1, 0.3]))))
+            elif kind == 4: parts.append(mutate("A" * int(rng.integers(3, 45)), float(rng.choice([0.0, 0.1, 0.3]))))
+            elif kind == 5: parts.append("N" * int(rng.integers(1, 4)))
+            elif kind == 6: parts.append(rc(mutate(R1, 0.05)) + rnd(int(rng.integers(0, 30))))
+            else: parts.append(rnd(16) + rnd(12) + "T" * 30)
+        s = "".join(parts)
+        seqs.append(s if rng.random() < 0.5 else rc(s))
+    return seqs
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_extract_fuzz_fragments(ctx, orc, seed):
+    rng = np.random.default_rng(1000 + seed)
+    seqs = _fragment_reads(rng, 12000)
+    bases, off = synth.list_to_reads(seqs)
+    umi = 12 if seed != 2 else 10
+    got = ctx.extract_batch(bases, off, umi)
+    want = orc.extract_batch(bases, off, umi, threads=8)
+    assert (got == want).all(), _diff(got, want)
+    assert 0.02 < got["valid"].mean() < 0.9          # both outcomes are well represented
+
+
+def test_extract_long_reads_and_r1_repeats(ctx, orc):
+    """Reads spanning many steps of the scan kernel, adapter concatemers (every position a hit) and
+    homopolymers (every window T- or A-rich): exercises queue overflow paths and the candidate compaction."""
+    rng = np.random.default_rng(77)
+    R1 = "CTACACGACGCTCTTCCGATCT"
+    rnd = lambda k: "".join("ACGT"[i] for i in rng.integers(0, 4, k))
+    seqs = [rnd(100000), R1 * 3000, "T" * 50000, "A" * 50000, "AT" * 20000, "TTTA" * 10000,
+            rnd(30000) + R1 + rnd(16) + rnd(12) + "T" * 30 + rnd(30000), (R1 + rnd(20)) * 500]
+    seqs += [rnd(int(rng.integers(1, 40))) for _ in range(64)]
+    bases, off = synth.list_to_reads(seqs)
+    got = ctx.extract_batch(bases, off, 12)
+    want = orc.extract_batch(bases, off, 12, threads=8)
+    assert (got == want).all(), _diff(got, want)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_nearest16_and_graph_fuzz_clustered(ctx, orc, seed):
+    """Dense barcode neighbourhoods: many ties, multi-hit deletion variants, homopolymer-rich strings."""
+    rng = np.random.default_rng(seed)
+    seeds = [0, 0xFFFFFFFF, 0x55555555, 0x0F0F0F0F] + [int(x) for x in rng.integers(0, 1 << 32, 20, dtype=np.uint64)]
+    wl = set()
+    for s0 in seeds:
+        for _ in range(150):
+            s = list(synth.rank_to_str(s0))
+            for _ in range(int(rng.integers(0, 4))):
+                u = rng.random()
+                p = int(rng.integers(0, len(s)))
+                if u < 0.5: s[p] = "ACGT"[int(rng.integers(0, 4))]
+                elif u < 0.75 and len(s) > 1: del s[p]
+                else: s.insert(p, "ACGT"[int(rng.integers(0, 4))])
+            s = ("".join(s) + "ACGTACGT")[:16]
+            wl.add(synth.str_to_rank(s))
+    wl = np.array(sorted(wl), dtype=np.uint32)
+    rng.shuffle(wl)
+    q = np.concatenate([_near_queries(wl, rng, 3000), wl[:200]])
+    for algo in (1, 2):
+        ctx.nearest16_set_algo(algo)
+        gi, ge, gt = ctx.nearest16(q, wl, 2)
+        wi, we, wt = orc.nearest16(q, wl, 2, threads=8)
+        assert (ge == we).all() and (gi == wi).all() and (gt == wt).all(), (algo, _diff(gt, wt))
+    ctx.nearest16_set_algo(0)
+    ranks = np.unique(np.concatenate([wl, q]))
+    for algo, thr in ((1, 1), (2, 1), (1, 2)):
+        ctx.graph_set_algo(algo)
+        e = ctx.graph_edges(ranks, thr, orc.qgram_threshold(thr))
+        w = orc.graph_edges(ranks, thr, threads=8)
+        assert len(e) == len(w) and (e == w).all(), (algo, thr)
+    ctx.graph_set_algo(0)
