@@ -18,6 +18,7 @@ REC_DTYPE = np.dtype([
 EDGE_DTYPE = np.dtype([("a", "<u4"), ("b", "<u4"), ("dist", "<u4")])
 FLAG_REV = 1
 FLAG_RANK_OK = 2
+FLAG_BC16 = 4
 NONE_IDX = 0xFFFFFFFF
 
 E_ARG, E_HIP, E_NOMEM, E_CAPACITY, E_BADBASE = -1, -2, -3, -4, -5
@@ -27,7 +28,7 @@ EXPORTS = [
     "bdg_profile_enable", "bdg_profile_reset", "bdg_profile_read",
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_set_algo",
-    "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_set_algo",
+    "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
 ]
 
 
@@ -75,6 +76,7 @@ def load():
     L.bdg_graph_edges.argtypes = [vp, vp, u32, u32, i32, vp, u64, C.POINTER(u64)]
     L.bdg_graph_edges_dev.argtypes = [vp, vp, u32, u32, i32, vp, u64, vp]
     L.bdg_graph_set_algo.argtypes = [vp, C.c_int]
+    L.bdg_distinct_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("bdg_free",):
@@ -194,6 +196,10 @@ class Context:
 
     def graph_set_algo(self, algo):
         self._check(self.lib.bdg_graph_set_algo(self.h, algo))
+
+    def distinct_dev(self, d_recs, n, d_uniq, d_count, d_first, d_n):
+        self._check(self.lib.bdg_distinct_dev(self.h, d_recs.data_ptr(), n, d_uniq.data_ptr(), d_count.data_ptr(),
+                                              d_first.data_ptr(), d_n.data_ptr()))
 
 
 _DEFAULT = {}

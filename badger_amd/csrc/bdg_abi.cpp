@@ -11,6 +11,7 @@ int bdg_extract_status_impl(bdg_ctx*, uint64_t*, uint64_t*);
 int bdg_whitelist_load_impl(bdg_ctx*, const uint32_t*, uint32_t);
 int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
 int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*);
+int bdg_distinct_launch(bdg_ctx*, const bdg_extract_rec*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 
 static thread_local std::string g_err_noctx;
 
@@ -323,6 +324,15 @@ int bdg_graph_edges(bdg_ctx* ctx, const uint32_t* ranks, uint32_t n, uint32_t th
     if (w) memcpy(out, all.data(), sizeof(bdg_edge) * w);
     if (all.size() > cap) return bdg_fail(ctx, BDG_E_CAPACITY, "edge capacity too small");
     return BDG_OK;
+}
+
+int bdg_distinct_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
+                     uint32_t* d_uniq, uint32_t* d_count, uint32_t* d_first, uint32_t* d_n)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (!d_n || (n && (!d_recs || !d_uniq || !d_count || !d_first))) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bdg_distinct_launch(ctx, d_recs, n, d_uniq, d_count, d_first, d_n);
 }
 
 }  // extern "C"

@@ -1,0 +1,92 @@
+// Distinct-barcode counting on the device (reference BarcodeGraph.index_bc_single_thread,
+// barcode_graph.py:192-204): from the extraction records of a batch, the distinct 16-base
+// barcodes, how often each occurs and where it occurs first (the reference's `counts` dict is in
+// first-occurrence order, which get_cluster_centers depends on, barcode_graph.py:253-255).
+// Stable LSD radix sort of (33-bit key = unusable << 32 | rank, value = read index) + run-length
+// encode, both from hipCUB; the first element of each run is its first occurrence because the
+// sort is stable.
+#include "bdg_common.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+__global__ __launch_bounds__(256)
+void k_distinct_keys(const bdg_extract_rec* __restrict__ recs, uint32_t n,
+                     unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+                     uint32_t* __restrict__ out_n /* [0] n_uniq (later), [1] barcodes of 16 bases holding a non-ACGT base */)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const bdg_extract_rec r = recs[i];
+    const bool ok = r.valid && (r.flags & BDG_FLAG_RANK_OK);
+    keys[i] = ok ? (unsigned long long)r.bc_rank : (1ull << 32);
+    vals[i] = i;
+    if (r.valid && !ok && (r.flags & BDG_FLAG_BC16)) atomicAdd(&out_n[1], 1u);
+}
+
+__global__ __launch_bounds__(256)
+void k_distinct_finish(const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ ucounts,
+                       const uint32_t* __restrict__ uoffsets, const uint32_t* __restrict__ sorted_vals,
+                       const uint32_t* __restrict__ n_runs,
+                       uint32_t* __restrict__ uniq, uint32_t* __restrict__ count, uint32_t* __restrict__ first,
+                       uint32_t* __restrict__ out_n)
+{
+    const uint32_t nr = *n_runs;
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j == 0) out_n[0] = (nr && ukeys[nr - 1] >= (1ull << 32)) ? nr - 1 : nr;     // the unusable run sorts last
+    if (j >= nr || ukeys[j] >= (1ull << 32)) return;
+    uniq[j] = (uint32_t)ukeys[j];
+    count[j] = ucounts[j];
+    first[j] = sorted_vals[uoffsets[j]];
+}
+
+}  // namespace
+
+int bdg_distinct_launch(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
+                        uint32_t* d_uniq, uint32_t* d_count, uint32_t* d_first, uint32_t* d_n)
+{
+    hipStream_t st = ctx->stream;
+    BDG_HIP_TRY(ctx, hipMemsetAsync(d_n, 0, 8, st));
+    if (n == 0) return BDG_OK;
+    size_t t_sort = 0, t_rle = 0, t_scan = 0;
+    unsigned long long* kp = nullptr; uint32_t* vp = nullptr;
+    BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, kp, kp, vp, vp, (int)n, 0, 33, st));
+    BDG_HIP_TRY(ctx, hipcub::DeviceRunLengthEncode::Encode(nullptr, t_rle, kp, kp, vp, vp, (int)n, st));
+    BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, t_scan, vp, vp, (int)n, st));
+    const size_t t_max = std::max(t_sort, std::max(t_rle, t_scan));
+    // workspace: keys in/out (8n each), vals in/out (4n each), unique keys (8n), counts (4n), offsets (4n), n_runs, temp
+    const size_t need = 8ull * n * 3 + 4ull * n * 4 + 256 + t_max;
+    int rc;
+    if ((rc = bdg_reserve(ctx, ctx->g_tmp1, need))) return rc;
+    char* base = static_cast<char*>(ctx->g_tmp1.p);
+    auto* k_in = reinterpret_cast<unsigned long long*>(base);
+    auto* k_out = k_in + n;
+    auto* u_keys = k_out + n;
+    auto* v_in = reinterpret_cast<uint32_t*>(u_keys + n);
+    auto* v_out = v_in + n;
+    auto* u_cnt = v_out + n;
+    auto* u_off = u_cnt + n;
+    auto* n_runs = u_off + n;
+    void* temp = reinterpret_cast<char*>(n_runs) + 256;
+    {
+        ScopedKernelTimer tm(ctx, "k_distinct_keys");
+        hipLaunchKernelGGL(k_distinct_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_recs, n, k_in, v_in, d_n);
+    }
+    {
+        ScopedKernelTimer tm(ctx, "hipcub_sort_rle_scan");
+        size_t t = t_max;
+        BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(temp, t, k_in, k_out, v_in, v_out, (int)n, 0, 33, st));
+        t = t_max;
+        BDG_HIP_TRY(ctx, hipcub::DeviceRunLengthEncode::Encode(temp, t, k_out, u_keys, u_cnt, n_runs, (int)n, st));
+        t = t_max;
+        BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(temp, t, u_cnt, u_off, (int)n, st));
+    }
+    {
+        ScopedKernelTimer tm(ctx, "k_distinct_finish");
+        hipLaunchKernelGGL(k_distinct_finish, dim3((n + 255) / 256), dim3(256), 0, st, u_keys, u_cnt, u_off, v_out, n_runs,
+                           d_uniq, d_count, d_first, d_n);
+    }
+    BDG_HIP_TRY(ctx, hipGetLastError());
+    return BDG_OK;
+}

@@ -866,6 +866,7 @@ void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             if (use_rev) cd = 3u - cd;
             rk |= cd << (2 * i);
         }
+        rec.flags |= BDG_FLAG_BC16;
         if (ok) { rec.bc_rank = rk; rec.flags |= BDG_FLAG_RANK_OK; }
     }
     out[r] = rec;

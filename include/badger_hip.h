@@ -67,6 +67,7 @@ typedef struct bdg_extract_rec {
 
 #define BDG_FLAG_REV      1u  /* result comes from reverese_complement(read)          */
 #define BDG_FLAG_RANK_OK  2u  /* bc_rank is valid: 16 in-range ACGT bases             */
+#define BDG_FLAG_BC16     4u  /* the barcode slice holds 16 bases (some may be N)     */
 
 typedef struct bdg_edge {
     uint32_t a;          /* rank, a < b */
@@ -143,6 +144,15 @@ int  bdg_graph_edges(bdg_ctx* ctx, const uint32_t* ranks, uint32_t n, uint32_t t
 int  bdg_graph_edges_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
                          bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges);
 int  bdg_graph_set_algo(bdg_ctx* ctx, int algo);   /* 0 auto, 1 all-pairs scan, 2 neighbourhood probes (thr=1) */
+/* Distinct-barcode counting of a batch on the device (BarcodeGraph.index_bc_single_thread,
+ * barcode_graph.py:192-204): from n extraction records, the distinct barcodes of records with a
+ * full 16-base ACGT barcode, ascending in d_uniq, with their multiplicity (d_count) and the index of
+ * the first record showing them (d_first; sorting by it gives the reference's counts order).  The
+ * three outputs need room for n entries.  d_n[0] = number of distinct barcodes, d_n[1] = records
+ * whose 16-base barcode holds a non-ACGT base (the reference raises KeyError on those, common.py:21-25).
+ * Asynchronous. */
+int  bdg_distinct_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
+                      uint32_t* d_uniq, uint32_t* d_count, uint32_t* d_first, uint32_t* d_n);
 
 #ifdef __cplusplus
 }

@@ -280,6 +280,7 @@ int orc_extract_read(const char* seq, int len, int umi_len, orc_extract_rec* rec
             if (cd < 0) { ok = 0; break; }
             rk |= (uint32_t)cd << (2 * i);
         }
+        rec->flags |= ORC_FLAG_BC16;
         if (ok) { rec->bc_rank = rk; rec->flags |= ORC_FLAG_RANK_OK; }
     }
     free(rc); free(hits);

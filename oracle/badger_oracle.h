@@ -44,6 +44,7 @@ typedef struct orc_extract_rec {
 
 #define ORC_FLAG_REV      1u   /* result comes from the reverse-complement strand */
 #define ORC_FLAG_RANK_OK  2u   /* bc_rank holds rank() of a full 16-base ACGT barcode */
+#define ORC_FLAG_BC16     4u   /* the barcode slice holds 16 bases (some may be N) */
 
 typedef struct orc_edge {
     uint32_t a;      /* a < b (ranks) */

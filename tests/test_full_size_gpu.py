@@ -156,3 +156,27 @@ def test_config3_graph_probe_equals_scan_and_oracle_rows(world):
         assert set(want) <= set(mine)
         for b, d in mine:
             assert orc.dmin3(int(a), b) == d and orc.qgram_S(int(a), b) >= 5
+
+
+def test_config2_distinct_on_device_matches_host_counting(world):
+    """bdg_distinct_dev on the 1M records == numpy's unique/first-index/counts (barcode_graph.py:192-204)."""
+    ctx, dev = world["ctx"], world["dev"]
+    recs = world["recs"]
+    d_recs = torch.from_numpy(recs.view(np.int32).reshape(-1, 8).copy()).to(dev)
+    uniq = torch.zeros(N_READS, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(N_READS, dtype=torch.int32, device=dev)
+    first = torch.zeros(N_READS, dtype=torch.int32, device=dev)
+    dn = torch.zeros(2, dtype=torch.int32, device=dev)
+    ctx.distinct_dev(d_recs, N_READS, uniq, cnt, first, dn)
+    torch.cuda.synchronize()
+    nu = int(dn[0])
+    ok = (recs["valid"] == 1) & ((recs["flags"] & 2) != 0)
+    idx = np.nonzero(ok)[0]
+    wu, wf, wc = np.unique(recs["bc_rank"][ok], return_index=True, return_counts=True)
+    assert nu == len(wu) and int(dn[1]) == 0
+    assert (uniq[:nu].cpu().numpy().astype(np.uint32) == wu).all()
+    assert (cnt[:nu].cpu().numpy() == wc).all()
+    assert (first[:nu].cpu().numpy() == idx[wf]).all()
+    # first-occurrence order of the reference's counts dict
+    order = np.argsort(first[:nu].cpu().numpy(), kind="stable")
+    assert (np.diff(first[:nu].cpu().numpy()[order]) > 0).all()

@@ -349,3 +349,31 @@ def test_nearest16_and_graph_fuzz_clustered(ctx, orc, seed):
         w = orc.graph_edges(ranks, thr, threads=8)
         assert len(e) == len(w) and (e == w).all(), (algo, thr)
     ctx.graph_set_algo(0)
+
+
+def test_distinct_dev_small_and_edge_cases(ctx, orc):
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8)
+    seqs = _fragment_reads(rng, 3000)
+    bases, off = synth.list_to_reads(seqs)
+    recs = ctx.extract_batch(bases, off, 12)
+    n = len(recs)
+    d_recs = torch.from_numpy(recs.view(np.int32).reshape(-1, 8).copy()).to(dev)
+    uniq, cnt, first = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3))
+    dn = torch.zeros(2, dtype=torch.int32, device=dev)
+    ctx.set_stream(0)
+    ctx.distinct_dev(d_recs, n, uniq, cnt, first, dn)
+    torch.cuda.synchronize()
+    ok = (recs["valid"] == 1) & ((recs["flags"] & _native.FLAG_RANK_OK) != 0)
+    wu, wf, wc = np.unique(recs["bc_rank"][ok], return_index=True, return_counts=True)
+    nu = int(dn[0])
+    assert nu == len(wu) > 10
+    assert (uniq[:nu].cpu().numpy().astype(np.uint32) == wu).all() and (cnt[:nu].cpu().numpy() == wc).all()
+    assert (first[:nu].cpu().numpy() == np.nonzero(ok)[0][wf]).all()
+    # barcodes of 16 bases holding an N are counted separately (the reference raises KeyError on them)
+    n16 = ((recs["valid"] == 1) & ((recs["flags"] & _native.FLAG_BC16) != 0) & ((recs["flags"] & _native.FLAG_RANK_OK) == 0)).sum()
+    assert int(dn[1]) == int(n16)
+    ctx.distinct_dev(d_recs, 0, uniq, cnt, first, dn)
+    torch.cuda.synchronize()
+    assert int(dn[0]) == 0
