@@ -187,7 +187,7 @@ int bdg_extract_batch(bdg_ctx* ctx, const uint8_t* bases, const uint64_t* off, u
     for (uint32_t i = 0; i < n; ++i)
         if (off[i + 1] < off[i]) return bdg_fail(ctx, BDG_E_ARG, "offsets must be non-decreasing");
     for (uint32_t i = 0; i < n; ++i)
-        if (off[i + 1] - off[i] >= (1ull << 30)) return bdg_fail(ctx, BDG_E_ARG, "read longer than 2^30 bases");
+        if (off[i + 1] - off[i] >= (1ull << 26)) return bdg_fail(ctx, BDG_E_ARG, "read longer than 2^26 bases");
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // ship only the byte range the offsets reference, rebased to 0
     const uint64_t lo = off[0], hi = off[n], total = hi - lo;

@@ -75,8 +75,8 @@ __device__ __forceinline__ uint32_t range_mask16(int32_t lo, int32_t hi)
 // 64-bit reservation (A count | B count << 32) every few tasks.
 // ---------------------------------------------------------------------------
 constexpr int TASK_READS = 8;
-constexpr uint32_t WENT = 320;             // per-wave staging (2.5 KiB)
-constexpr uint32_t WFLUSH = 192;           // flush once this many clusters are staged
+constexpr uint32_t WENT = 256;             // per-wave staging (2 KiB)
+constexpr uint32_t WFLUSH = 128;           // flush once this many clusters are staged
 constexpr int TASK_SHARDS = 8;
 
 struct TaskTab {                           // per wave, double buffered
@@ -109,7 +109,9 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     __shared__ uint32_t s_ringr[4][32];  // read index of each ring slot
     __shared__ TaskTab s_tab[4][2];
     __shared__ int32_t s_pt[4][32][2];   // polyT of the reads of the wave's last 4 tasks (ring)
-    __shared__ uint32_t s_cand[4][128];  // T/A-rich window candidates of one step
+    __shared__ uint2 s_cand[4][192];     // pending T/A-rich window candidates {mask, (p0 + 16) << 6 | ring << 1 | type}
+    __shared__ uint32_t s_ptmin[4][32][2];  // per ring slot and strand: min of (window start << 5 | offset), 0xFFFFFFFF = none
+    __shared__ int32_t s_ringL[4][32];   // read length of each ring slot
     const int tid = threadIdx.x;
     for (int k = tid; k < 4096; k += 256) { const uint32_t t = tables[768 + k]; s_kmer[k] = (uint16_t)((t & 1u) | ((t >> 16) << 8)); }
     s_cls[tid] = reinterpret_cast<const uint2*>(tables + 256)[tid];
@@ -138,7 +140,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const uint64_t o1 = __shfl_down(o, 1);
         int64_t L = (uint32_t)lane < nr ? (int64_t)(o1 - o) : 0;
         bool bad = false;
-        if (L < 0 || L >= (1ll << 30) || o + (uint64_t)L > total_rounded) { bad = (uint32_t)lane < nr; L = 0; }
+        if (L < 0 || L >= (1ll << 26) || o + (uint64_t)L > total_rounded) { bad = (uint32_t)lane < nr; L = 0; }
         if (bad) atomicMin(&counters[C_BADREAD], (unsigned long long)(r0 + lane));      // corrupt offsets: report, never loop on them
         uint32_t nv = L > 0 ? (uint32_t)(((o & 15ull) + (uint64_t)L + 15ull) >> 4) : 0u;
         uint32_t incl = nv;
@@ -207,6 +209,43 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         nent = 0;
     };
 
+    // polyT: the forward strand wants the FIRST 16-window with >= 12 T, the reverse strand the LAST with >= 12 A
+    // (= the first T-window of the reverse complement).  Both are order-independent reductions, so candidate lanes
+    // only park their 32-base mask here; 64 parked masks are evaluated together (16 shifted popcounts each) and the
+    // result is reduced with one LDS atomic min on (window start << 5 | offset of the first TTT, common.py:31).
+    uint32_t ncand = 0;
+    auto eval_cands = [&](uint32_t first, uint32_t count) {
+        if ((uint32_t)lane < count) {
+            const uint2 c = s_cand[wv][first + lane];
+            const uint32_t m = c.x; const int32_t p0 = (int32_t)(c.y >> 6) - 16; const uint32_t ring = (c.y >> 1) & 31u, typ = c.y & 1u;
+            const int32_t L = s_ringL[wv][ring];
+            uint32_t q = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                // bit 5 of popcount + 20 is set iff the count is >= 12 (int(16 * 0.75), common.py:11)
+                const uint32_t cnt = __popc(__builtin_amdgcn_ubfe(m, k, 16)) + 20u;
+                q |= (k >= 5 ? (cnt << (k - 5)) : (cnt >> (5 - k))) & (1u << k);
+            }
+            const uint32_t m3 = m & (m >> 1) & (m >> 2);
+            if (typ == 0) {
+                q &= range_mask16(-p0, L - 16 - p0);                    // window starts 0 <= p < L-16 (common.py:17,28)
+                if (q) {
+                    const int k = __builtin_ctz(q);
+                    const uint32_t tt = m3 >> k;                            // 'TTT' starts, common.py:31
+                    atomicMin(&s_ptmin[wv][ring][0], ((uint32_t)(p0 + k) << 5) | (tt ? (uint32_t)__builtin_ctz(tt) : 0u));
+                }
+            } else {
+                q &= range_mask16(1 - p0, L - 16 - p0 + 1);             // reverse strand: 0 <= L-16-p < L-16
+                if (q) {
+                    const int k = 31 - __builtin_clz(q);
+                    const uint32_t mm = m3 & ((1u << (k + 14)) - 1u);
+                    const int j = mm ? 31 - __builtin_clz(mm) : k + 13;
+                    atomicMin(&s_ptmin[wv][ring][1], ((uint32_t)(L - 16 - (p0 + k)) << 5) | (uint32_t)(k + 13 - j));
+                }
+            }
+        }
+    };
+
     int cur = 0;
     uint32_t tseq = 0, since_flush = 0;     // ring slot of read j of the current task: (tseq & 3) * 8 + j
     uint32_t task = grab();
@@ -242,8 +281,8 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             return vv;
         };
         const uint32_t ring0 = (tseq & 3u) * TASK_READS;
-        if (lane < 2 * TASK_READS) s_pt[wv][ring0 + (lane >> 1)][lane & 1] = -1;
-        if (lane < TASK_READS) s_ringr[wv][ring0 + lane] = (uint32_t)(r0 + lane);
+        if (lane < 2 * TASK_READS) s_ptmin[wv][ring0 + (lane >> 1)][lane & 1] = 0xFFFFFFFFu;
+        if (lane < TASK_READS) { s_ringr[wv][ring0 + lane] = (uint32_t)(r0 + lane); s_ringL[wv][ring0 + lane] = tb.L[lane]; }
         __builtin_amdgcn_wave_barrier();
         if (!have_v) v = slot_vec(tb, (uint32_t)lane, nslots);
         have_v = false;
@@ -344,76 +383,18 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             uint32_t hitF = hits & valid, hitR = (hits >> 16) & valid;
             if (!worker) { hitF = 0; hitR = 0; }
 
-            // polyT windows.  A 16-window with >= 12 T (int(16 * 0.75), common.py:11) needs >= 12 T among the 31 bases a
-            // lane can see, which few lanes have: those lanes hand their mask to a compact set of lanes, so the 16-shift
-            // count loop runs once per wave for T and A candidates together instead of twice in every lane.
-            uint32_t qT = 0, qA = 0;
+            // polyT windows.  A 16-window with >= 12 T needs >= 12 T among the 31 bases a lane can see, which few lanes
+            // have: those lanes park their mask; evaluation happens 64 masks at a time (eval_cands).
             {
                 const bool cT = worker && __popc(T32 & 0x7FFFFFFFu) >= 12, cA = worker && __popc(A32 & 0x7FFFFFFFu) >= 12;
                 const unsigned long long bT = __ballot(cT), bA = __ballot(cA);
                 const uint32_t nT = (uint32_t)__popcll(bT), nc = nT + (uint32_t)__popcll(bA);
                 if (nc) {
                     const unsigned long long below = (1ull << lane) - 1ull;
-                    const uint32_t rkT = (uint32_t)__popcll(bT & below), rkA = nT + (uint32_t)__popcll(bA & below);
-                    uint32_t* cand = s_cand[wv];
-                    if (cT) cand[rkT] = T32;
-                    if (cA) cand[rkA] = A32;
-                    __builtin_amdgcn_wave_barrier();
-                    for (uint32_t c0 = 0; c0 < nc; c0 += 64) {
-                        const uint32_t ci = c0 + (uint32_t)lane;
-                        if (ci < nc) {
-                            const uint32_t m = cand[ci];
-                            uint32_t qq = 0;
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) {
-                                // bit 5 of popcount + 20 is set iff the count is >= 12
-                                const uint32_t cnt = __popc(__builtin_amdgcn_ubfe(m, k, 16)) + 20u;
-                                qq |= (k >= 5 ? (cnt << (k - 5)) : (cnt >> (5 - k))) & (1u << k);
-                            }
-                            cand[ci] = qq;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (cT) qT = cand[rkT];
-                    if (cA) qA = cand[rkA];
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            qT &= range_mask16(-p0, L - 16 - p0);              // 0 <= p < L-16          (common.py:17,28)
-            qA &= range_mask16(1 - p0, L - 16 - p0 + 1);       // reverse strand: 0 <= L-16-p < L-16
-
-            // polyT candidates of this lane
-            int32_t valF = -1, valR = -1;
-            if (qT) {
-                const int k = __builtin_ctz(qT);
-                const uint32_t tt = (T32 & (T32 >> 1) & (T32 >> 2)) >> k;         // 'TTT' starts, common.py:31
-                valF = (int32_t)(p0 + k + (tt ? __builtin_ctz(tt) : 0));
-            }
-            if (qA) {
-                const int k = 31 - __builtin_clz(qA);
-                const uint32_t aa = A32 & (A32 >> 1) & (A32 >> 2);
-                const uint32_t m = aa & ((1u << (k + 14)) - 1u);
-                const int jj = m ? 31 - __builtin_clz(m) : k + 13;
-                valR = (int32_t)((L - 16 - (p0 + k)) + (k + 13 - jj));
-            }
-            const unsigned long long balT = __ballot(qT != 0), balA = __ballot(qA != 0);
-            if (balT | balA) {
-                // per read present in this step: first T-rich window, last A-rich window
-                const unsigned long long wk = __ballot(worker);
-                const uint32_t j_lo = __shfl(j, 0), j_hi = __shfl(j, wk ? 63 - __builtin_clzll(wk) : 0);
-                for (uint32_t jj = j_lo; jj <= j_hi; ++jj) {
-                    const unsigned long long seg = __ballot(worker && j == jj);
-                    const uint32_t ring = ring0 + jj;
-                    const unsigned long long bt = balT & seg, ba = balA & seg;
-                    if (bt && s_pt[wv][ring][0] == -1) {
-                        const int32_t pv = __shfl(valF, __builtin_ctzll(bt));
-                        if (lane == 0) s_pt[wv][ring][0] = pv;
-                    }
-                    if (ba) {
-                        const int32_t pv = __shfl(valR, 63 - __builtin_clzll(ba));
-                        if (lane == 0) s_pt[wv][ring][1] = pv;
-                    }
-                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t info = ((uint32_t)(p0 + 16) << 6) | ((ring0 + j) << 1);
+                    if (cT) s_cand[wv][ncand + (uint32_t)__popcll(bT & below)] = make_uint2(T32, info);
+                    if (cA) s_cand[wv][ncand + nT + (uint32_t)__popcll(bA & below)] = make_uint2(A32, info | 1u);
+                    ncand += nc;
                 }
             }
             if (__ballot(bad != 0 && worker)) {
@@ -448,9 +429,19 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 if (fits) nent += total;
             }
             v = vn;
+            __builtin_amdgcn_wave_barrier();
+            while (ncand >= 64u) { ncand -= 64u; eval_cands(ncand, 64u); }
         }
         __builtin_amdgcn_wave_barrier();
-        if ((uint32_t)lane < 2 * nr) polyt[2 * r0 + lane] = s_pt[wv][ring0 + (lane >> 1)][lane & 1];
+        if (ncand) { eval_cands(0u, ncand); ncand = 0; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 2 * TASK_READS) {
+            const uint32_t pk = s_ptmin[wv][ring0 + (lane >> 1)][lane & 1];
+            const int32_t pv = pk == 0xFFFFFFFFu ? -1 : (int32_t)((pk >> 5) + (pk & 31u));
+            s_pt[wv][ring0 + (lane >> 1)][lane & 1] = pv;
+            if ((uint32_t)lane < 2 * nr) polyt[2 * r0 + lane] = pv;
+        }
+        __builtin_amdgcn_wave_barrier();
         ++tseq; ++since_flush;
         if (nent >= WFLUSH || since_flush >= 3) { flush(); since_flush = 0; }      // staged clusters never outlive the 4-task ring
         task = next_task;
