@@ -17,7 +17,7 @@
 //   k_strict_filter  queue B only matters if an alignment reaches score 17, which implies
 //                    semi-global edit distance <= 5: Myers' 22-bit search per hit; survivors
 //                    join queue A as single-hit clusters.
-//   k_sw_clusters    one lane per cluster: ONE 22-row Smith-Waterman pass over the union of the
+//   k_sw_clusters    two clusters per lane (packed 16-bit halves): ONE 22-row Smith-Waterman pass over the union of the
 //                    cluster's windows (all start at the first hit's window start, so the
 //                    first hit's strict and relaxed windows are column prefixes of the union:
 //                    their results are snapshots of the running key).  If the union cannot beat
@@ -563,6 +563,87 @@ __device__ __forceinline__ uint32_t sw_block(uint32_t (&w)[NW], int ndw, int n, 
     return (uint32_t)acc;
 }
 
+// ---------------------------------------------------------------------------
+// Packed form of sw_block for the forward pass: TWO clusters per lane, one per 16-bit half, so that
+// the half-rate integer max/add run as v_pk_max_u16 / v_pk_add_u16 on two cells at once.
+// Cells hold G = (H + 1) << 11 as unsigned 16-bit: H - 1 is never negative in that form
+// (G - 2048 >= 0), nothing exceeds 25 << 11 < 65536, and the SSW key  G | (63-col) << 5 | (31-row)
+// needs no shift.  A key k of this form is the sw_block key plus 2048 (k = 0: no cell seen).
+// ---------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+
+template <int NW, bool WITH_N>
+__device__ __forceinline__ uint32_t sw_block2(uint32_t (&wa)[NW], uint32_t (&wb)[NW], int ndw,
+                                              int nA, int nB, uint32_t compA, uint32_t compB,
+                                              int n1A, int n2A, int n1B, int n2B,
+                                              uint32_t& snap1, uint32_t& snap2)
+{
+    constexpr uint32_t ONE2 = 0x08000800u;       // 1 << 11 in both halves
+    uint32_t hs[R1_LEN];
+#pragma unroll
+    for (int i = 0; i < R1_LEN; ++i) hs[i] = ONE2;           // H = 0
+    uint32_t acc = 0, s1 = 0, s2 = 0;
+#pragma nounroll
+    for (int d = 0; d < ndw; ++d) {
+        const uint32_t curA = wa[0], curB = wb[0];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = d * 4 + b;
+            const uint32_t cA = (curA >> (8 * b)) & 0xFFu, cB = (curB >> (8 * b)) & 0xFFu;
+            const uint32_t kA = ((cA >> 1) & 3u) ^ (compA << 1), kB = ((cB >> 1) & 3u) ^ (compB << 1);
+            uint32_t eA = (kA & 2u) ? ((kA & 1u) ? EQ3 : EQ2) : ((kA & 1u) ? EQ1 : EQ0);
+            uint32_t eB = (kB & 2u) ? ((kB & 1u) ? EQ3 : EQ2) : ((kB & 1u) ? EQ1 : EQ0);
+            const bool liveA = j < nA, liveB = j < nB;
+            const bool isNA = WITH_N && cA == (uint32_t)'N', isNB = WITH_N && cB == (uint32_t)'N';
+            eA = (liveA && !isNA) ? eA : 0u;
+            eB = (liveB && !isNB) ? eB : 0u;
+            const uint32_t M0 = (eA & 0xFFFFu) | (eB << 16);                 // rows 0..15 of both
+            const uint32_t M1 = (eA >> 16) | ((eB >> 16) << 16);             // rows 16..21
+            const uint32_t dN = WITH_N ? (((isNA && liveA) ? 0x0800u : 0u) | ((isNB && liveB) ? 0x08000000u : 0u)) : 0u;
+            const uint32_t cj = (uint32_t)((63 - j) << 5) * 0x00010001u;
+            uint32_t diag_t = 0u;        // (H(-1, j-1) - 1) in offset form
+            uint32_t up = ONE2;          // H(-1, j) = 0
+#pragma unroll
+            for (int i = 0; i < R1_LEN; ++i) {
+                const uint32_t tl = pk_sub(hs[i], ONE2);                                 // H(i, j-1) - 1
+                const uint32_t src = i < 16 ? M0 : M1;
+                const int bitpos = i < 16 ? i : i - 16;
+                const uint32_t X = (bitpos <= 12 ? (src << (12 - bitpos)) : (src >> (bitpos - 12))) & 0x10001000u;   // 2 if match
+                uint32_t dg = pk_add(diag_t, X);                                         // H(i-1,j-1) +/- 1
+                if (WITH_N) dg = pk_add(dg, dN);
+                const uint32_t m = pk_max(pk_max(dg, tl), ONE2);                         // max(0, diag, left-1): independent of the row above
+                const uint32_t tu = pk_sub(up, ONE2);                                    // H(i-1, j) - 1
+                const uint32_t g = pk_max(m, tu);                                        // serial part: sub -> max
+                diag_t = tl;
+                hs[i] = g;
+                up = g;
+                acc = pk_max(acc, g | cj | ((uint32_t)(31 - i) * 0x00010001u));
+            }
+            const uint32_t m1 = ((j + 1 == n1A) ? 0xFFFFu : 0u) | ((j + 1 == n1B) ? 0xFFFF0000u : 0u);
+            const uint32_t m2 = ((j + 1 == n2A) ? 0xFFFFu : 0u) | ((j + 1 == n2B) ? 0xFFFF0000u : 0u);
+            s1 = (acc & m1) | (s1 & ~m1);
+            s2 = (acc & m2) | (s2 & ~m2);
+        }
+#pragma unroll
+        for (int i = 0; i < NW - 1; ++i) { wa[i] = wa[i + 1]; wb[i] = wb[i + 1]; }
+    }
+    snap1 = s1; snap2 = s2;
+    return acc;
+}
+
+// packed half -> sw_block key
+__device__ __forceinline__ uint32_t unpk(uint32_t packed, int half)
+{
+    const uint32_t k = half ? packed >> 16 : packed & 0xFFFFu;
+    return k >= (uint32_t)ONE ? k - (uint32_t)ONE : 0u;
+}
+
 __device__ __forceinline__ uint64_t make_key(uint32_t acc, uint32_t pos)
 {
     const uint64_t score = acc >> KEY_SHIFT;
@@ -657,6 +738,70 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
 // ---------------------------------------------------------------------------
 constexpr int CW = 14;                       // 56 columns: 16 + 15 + 23 = 54 at most
 
+struct ClusterJob {
+    bool active, relaxed;
+    uint32_t r, strand, mask;
+    int64_t pos, ws, L;
+    uint64_t rs;
+    int n_s, n_r, n_u;
+};
+
+__device__ __forceinline__ ClusterJob make_job(const QEnt* __restrict__ q, uint64_t g, uint64_t nq,
+                                               const uint64_t* __restrict__ off, const int32_t* __restrict__ polyt)
+{
+    ClusterJob jb;
+    QEnt e = make_uint4(HOLE_R, 0, 0, 0);
+    if (g < nq) e = q[g];
+    jb.active = e.x != HOLE_R;
+    jb.r = jb.active ? e.x : 0u; jb.strand = e.y & 1u; jb.mask = jb.active ? e.z : 0u;
+    jb.pos = jb.active ? (int64_t)(e.y >> 1) : 0;
+    jb.rs = 0; jb.L = 0; int32_t pt = -1;
+    if (jb.active) { jb.rs = off[jb.r]; jb.L = (int64_t)(off[jb.r + 1] - jb.rs); pt = polyt[2 * (uint64_t)jb.r + jb.strand]; }
+    jb.ws = jb.pos - (R1_LEN - KMER) > 0 ? jb.pos - (R1_LEN - KMER) : 0;                 // common.py:96-97
+    const int64_t we = jb.pos + R1_LEN + 1 < jb.L ? jb.pos + R1_LEN + 1 : jb.L;          // :98-99 (strict: end = len)
+    const int64_t last = jb.pos + (jb.mask ? 31 - __builtin_clz(jb.mask) : 0);
+    const int64_t wu = last + R1_LEN + 1 < jb.L ? last + R1_LEN + 1 : jb.L;              // end of the cluster's union
+    // relaxed search (barcode_callers.py:186-192): hits inside sequence[0:polyT+1], end = polyT+1
+    jb.relaxed = jb.active && pt >= 0 && jb.pos + KMER <= (int64_t)pt + 1;
+    const int64_t we_r = jb.pos + R1_LEN + 1 < (int64_t)pt + 1 ? jb.pos + R1_LEN + 1 : (int64_t)pt + 1;
+    jb.n_s = jb.active ? (int)(we - jb.ws) : 0;
+    jb.n_r = jb.relaxed ? (int)(we_r - jb.ws) : 0;
+    jb.n_u = jb.active ? (int)(wu - jb.ws) : 0;
+    return jb;
+}
+
+// keys of the first hit, and re-queue of the other hits when the union beats it
+__device__ __forceinline__ void finish_job(const ClusterJob& jb, uint32_t acc_s, uint32_t acc_r, uint32_t acc_u, int lane,
+                                           uint32_t n_reads, uint64_t qcap, QEnt* __restrict__ qc,
+                                           unsigned long long* __restrict__ counters, unsigned long long* __restrict__ keys)
+{
+    const uint32_t score_s = acc_s >> KEY_SHIFT;
+    if (jb.active && score_s >= 17u)                                                    // barcode_callers.py:200
+        atomicMax(&keys[2ull * n_reads + 2ull * jb.r + jb.strand], (unsigned long long)make_key(acc_s, (uint32_t)jb.pos));
+    if (jb.relaxed && (acc_r >> KEY_SHIFT) >= 9u)                                        // barcode_callers.py:191
+        atomicMax(&keys[2ull * jb.r + jb.strand], (unsigned long long)make_key(acc_r, (uint32_t)jb.pos));
+    // Every window of the cluster lies inside the union, so no later hit scores above the union.
+    // If the union does not beat the first hit, none of them can replace it (strictly greater is
+    // required, common.py:102); otherwise align them one by one (queue C, second launch).
+    uint32_t rest = (jb.active && (acc_u >> KEY_SHIFT) > score_s) ? (jb.mask & ~1u) : 0u;
+    if (__ballot(rest != 0)) {
+        const uint32_t cnt = __popc(rest);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        const uint32_t total = __shfl(incl, 63);
+        unsigned long long gb = 0;
+        if (lane == 63) gb = atomicAdd(&counters[C_NC], (unsigned long long)total);
+        gb = __shfl(gb, 63);
+        unsigned long long idx = gb + incl - cnt;
+        while (rest) {
+            const int j = __builtin_ctz(rest); rest &= rest - 1;
+            if (idx < qcap) qc[idx] = make_uint4(jb.r, ((uint32_t)(jb.pos + j) << 1) | jb.strand, 1u, 0u);
+            ++idx;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256)
 void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                    const uint64_t* __restrict__ off, uint32_t n_reads,
@@ -670,60 +815,22 @@ void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     if (count_idx == C_NAB) nq &= 0xFFFFFFFFull;
     if (nq > qcap) nq = qcap;
     const int lane = threadIdx.x & 63;
-    const uint64_t stride = (uint64_t)gridDim.x * 256ull;
+    const uint64_t stride = (uint64_t)gridDim.x * 512ull;           // two clusters per lane
     uint32_t nwin = 0;
-    for (uint64_t base = (uint64_t)blockIdx.x * 256ull + (threadIdx.x & ~63); base < nq; base += stride) {
-        const uint64_t g = base + lane;
-        QEnt e = make_uint4(HOLE_R, 0, 0, 0);
-        if (g < nq) e = q[g];
-        const bool active = e.x != HOLE_R;
-        const uint32_t r = active ? e.x : 0u, strand = e.y & 1u, mask = active ? e.z : 0u;
-        const int64_t pos = active ? (int64_t)(e.y >> 1) : 0;
-        uint64_t rs = 0; int64_t L = 0; int32_t pt = -1;
-        if (active) { rs = off[r]; L = (int64_t)(off[r + 1] - rs); pt = polyt[2 * (uint64_t)r + strand]; }
-        const int64_t ws = pos - (R1_LEN - KMER) > 0 ? pos - (R1_LEN - KMER) : 0;       // common.py:96-97
-        const int64_t we = pos + R1_LEN + 1 < L ? pos + R1_LEN + 1 : L;                 // :98-99 (strict: end = len)
-        const int64_t last = pos + (mask ? 31 - __builtin_clz(mask) : 0);
-        const int64_t wu = last + R1_LEN + 1 < L ? last + R1_LEN + 1 : L;               // end of the cluster's union
-        // relaxed search (barcode_callers.py:186-192): hits inside sequence[0:polyT+1], end = polyT+1
-        const bool relaxed = active && pt >= 0 && pos + KMER <= (int64_t)pt + 1;
-        const int64_t we_r = pos + R1_LEN + 1 < (int64_t)pt + 1 ? pos + R1_LEN + 1 : (int64_t)pt + 1;
-        const int n_s = active ? (int)(we - ws) : 0;
-        const int n_r = relaxed ? (int)(we_r - ws) : 0;
-        const int n_u = active ? (int)(wu - ws) : 0;
-        uint32_t w[CW];
-        load_block<CW>(bases, total_rounded, rs, L, (int)strand, ws, +1, w);
-        const bool anyN = __ballot(active && block_has_N<CW>(w)) != 0;
-        const int ndw = (wave_max(n_u) + 3) >> 2;
-        uint32_t acc_s = 0, acc_r = 0;
-        const uint32_t acc_u = anyN ? sw_block<CW, true, false>(w, ndw, n_u, strand, 0, n_s, n_r, acc_s, acc_r)
-                                    : sw_block<CW, false, false>(w, ndw, n_u, strand, 0, n_s, n_r, acc_s, acc_r);
-        nwin += active ? 1u : 0u;
-        const uint32_t score_s = acc_s >> KEY_SHIFT;
-        if (active && score_s >= 17u)                                                    // barcode_callers.py:200
-            atomicMax(&keys[2ull * n_reads + 2ull * r + strand], (unsigned long long)make_key(acc_s, (uint32_t)pos));
-        if (relaxed && (acc_r >> KEY_SHIFT) >= 9u)                                       // barcode_callers.py:191
-            atomicMax(&keys[2ull * r + strand], (unsigned long long)make_key(acc_r, (uint32_t)pos));
-        // Every window of the cluster lies inside the union, so no later hit scores above the union.
-        // If the union does not beat the first hit, none of them can replace it (strictly greater is
-        // required, common.py:102); otherwise align them one by one (queue C, second launch).
-        uint32_t rest = (active && (acc_u >> KEY_SHIFT) > score_s) ? (mask & ~1u) : 0u;
-        if (__ballot(rest != 0)) {
-            const uint32_t cnt = __popc(rest);
-            uint32_t incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-            const uint32_t total = __shfl(incl, 63);
-            unsigned long long gb = 0;
-            if (lane == 63) gb = atomicAdd(&counters[C_NC], (unsigned long long)total);
-            gb = __shfl(gb, 63);
-            unsigned long long idx = gb + incl - cnt;
-            while (rest) {
-                const int j = __builtin_ctz(rest); rest &= rest - 1;
-                if (idx < qcap) qc[idx] = make_uint4(r, ((uint32_t)(pos + j) << 1) | strand, 1u, 0u);
-                ++idx;
-            }
-        }
+    for (uint64_t base = (uint64_t)blockIdx.x * 512ull + 2ull * (threadIdx.x & ~63); base < nq; base += stride) {
+        const ClusterJob ja = make_job(q, base + 2ull * lane, nq, off, polyt);
+        const ClusterJob jb = make_job(q, base + 2ull * lane + 1, nq, off, polyt);
+        uint32_t wa[CW], wb[CW];
+        load_block<CW>(bases, total_rounded, ja.rs, ja.L, (int)ja.strand, ja.ws, +1, wa);
+        load_block<CW>(bases, total_rounded, jb.rs, jb.L, (int)jb.strand, jb.ws, +1, wb);
+        const bool anyN = __ballot((ja.active && block_has_N<CW>(wa)) || (jb.active && block_has_N<CW>(wb))) != 0;
+        const int ndw = (wave_max(ja.n_u > jb.n_u ? ja.n_u : jb.n_u) + 3) >> 2;
+        uint32_t sn_s = 0, sn_r = 0;
+        const uint32_t acc = anyN ? sw_block2<CW, true>(wa, wb, ndw, ja.n_u, jb.n_u, ja.strand, jb.strand, ja.n_s, ja.n_r, jb.n_s, jb.n_r, sn_s, sn_r)
+                                  : sw_block2<CW, false>(wa, wb, ndw, ja.n_u, jb.n_u, ja.strand, jb.strand, ja.n_s, ja.n_r, jb.n_s, jb.n_r, sn_s, sn_r);
+        nwin += (ja.active ? 1u : 0u) + (jb.active ? 1u : 0u);
+        finish_job(ja, unpk(sn_s, 0), unpk(sn_r, 0), unpk(acc, 0), lane, n_reads, qcap, qc, counters, keys);
+        finish_job(jb, unpk(sn_s, 1), unpk(sn_r, 1), unpk(acc, 1), lane, n_reads, qcap, qc, counters, keys);
     }
     // window count (statistics only)
 #pragma unroll
