@@ -4,7 +4,9 @@ The product path: there is NO CPU fallback.  If the HIP library is missing, or n
 MI355X is visible, every entry point raises.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -53,6 +55,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: build it with `make -C badger_amd/csrc` "
                           "(or `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+    # PyTorch-ROCm bundles its own HIP runtime and two HIP runtimes cannot both open the device: whichever
+    # initialises second sees no GPU.  If torch can end up in this process, load it first so that the library's HIP
+    # symbols bind to the runtime torch uses (stand-alone C/C++ hosts just link /opt/rocm's).
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
     L.bdg_init.argtypes = [C.c_int, C.POINTER(vp)]
