@@ -124,7 +124,8 @@ void k_nearest_scan(const uint32_t* __restrict__ q, const uint32_t* __restrict__
 // variants of the whitelist; only on a hit are the 64 re-insertions looked up.
 struct PairTables {
     const uint32_t* off;     // [6][65537]
-    const uint2* ent;        // [6][nw] {rank, caller index}
+    const uint32_t* rank;    // [6][stride] ranks sorted by pair key (stride = nw rounded up to 4: 16-byte aligned tables)
+    const uint32_t* idx;     // [6][stride] caller index of the same entry (read only on a hit)
     const uint32_t* delmap;  // 2^30 bits
     uint32_t nw;
 };
@@ -163,20 +164,23 @@ void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t nq, PairTables pt,
         const uint32_t* o = pt.off + (size_t)p * 65537u + pair_key(qq, p);
         lo[p] = o[0]; hi[p] = o[1];
     }
+    const size_t stride = ((size_t)pt.nw + 3) & ~size_t(3);
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
         if (p == 1 && best == 0u) break;               // an exact match sits in table 0 and nothing can tie with it
-        const uint2* e = pt.ent + (size_t)p * (((size_t)pt.nw + 1) & ~size_t(1));
-        // two entries per 16-byte load; the table base is 16-byte aligned, so even entry indices are too
-        for (uint32_t k = lo[p] & ~1u; k < hi[p]; k += 2) {
-            const uint4 w2 = *reinterpret_cast<const uint4*>(e + k);
+        const uint32_t* rk = pt.rank + (size_t)p * stride;
+        const uint32_t* ix = pt.idx + (size_t)p * stride;
+        // four ranks per 16-byte load (tables are 16-byte aligned); the caller index is fetched only for a hit
+        for (uint32_t k = lo[p] & ~3u; k < hi[p]; k += 4) {
+            const uint4 w4 = *reinterpret_cast<const uint4*>(rk + k);
+            const uint32_t wr[4] = { w4.x, w4.y, w4.z, w4.w };
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const uint32_t wr = half ? w2.z : w2.x, wo = half ? w2.w : w2.y;
-                const uint32_t kk = k + half;
-                const uint32_t x = qq ^ wr;
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t kk = k + u;
+                const uint32_t x = qq ^ wr[u];
                 const uint32_t h = hamming16(x);
                 if (kk >= lo[p] && kk < hi[p] && h <= 2u && h <= best && canonical_pair(x) == p) {
+                    const uint32_t wo = ix[kk];
                     if (h < best) { best = h; bidx = wo; ties = 1u; }
                     else { ties++; bidx = wo < bidx ? wo : bidx; }
                 }
@@ -337,8 +341,8 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
 
     // six block-pair tables (counting sort by the 16-bit pair key)
     std::vector<uint32_t> poff(6u * 65537u, 0u);
-    const size_t nwe = ((size_t)nw + 1) & ~size_t(1);          // table stride: even, so every table starts 16-byte aligned
-    std::vector<uint2> pent(6ull * nwe, make_uint2(0, 0));
+    const size_t nwe = ((size_t)nw + 3) & ~size_t(3);          // table stride: multiple of 4, so every table starts 16-byte aligned
+    std::vector<uint32_t> prank(6ull * nwe, 0u), pidx(6ull * nwe, 0u);
     for (int p = 0; p < 6; ++p) {
         const int bi = p < 3 ? 0 : (p < 5 ? 1 : 2);
         const int bj = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
@@ -347,14 +351,18 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
         for (uint32_t i = 0; i < nw; ++i) o[key(srt[i]) + 1]++;
         for (uint32_t k = 0; k < 65536u; ++k) o[k + 1] += o[k];
         std::vector<uint32_t> fill(o, o + 65536);
-        uint2* e = pent.data() + (size_t)p * nwe;
-        for (uint32_t i = 0; i < nw; ++i) { uint2 v; v.x = srt[i]; v.y = order[i]; e[fill[key(srt[i])]++] = v; }
+        for (uint32_t i = 0; i < nw; ++i) {
+            const uint32_t at = fill[key(srt[i])]++;
+            prank[(size_t)p * nwe + at] = srt[i];
+            pidx[(size_t)p * nwe + at] = order[i];
+        }
     }
     if ((rc = bdg_reserve(ctx, ctx->w_poff, sizeof(uint32_t) * poff.size()))) return rc;
-    if ((rc = bdg_reserve(ctx, ctx->w_pent, sizeof(uint2) * pent.size()))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->w_pent, sizeof(uint32_t) * (prank.size() + pidx.size())))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->w_delmap, size_t(1) << 27))) return rc;          // 2^30 bits
     BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_poff.p, poff.data(), sizeof(uint32_t) * poff.size(), hipMemcpyHostToDevice));
-    BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_pent.p, pent.data(), sizeof(uint2) * pent.size(), hipMemcpyHostToDevice));
+    BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_pent.p, prank.data(), sizeof(uint32_t) * prank.size(), hipMemcpyHostToDevice));
+    BDG_HIP_TRY(ctx, hipMemcpy(static_cast<uint32_t*>(ctx->w_pent.p) + prank.size(), pidx.data(), sizeof(uint32_t) * pidx.size(), hipMemcpyHostToDevice));
     BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->w_delmap.p, 0, size_t(1) << 27, ctx->stream));
     {
         const uint64_t threads = 16ull * nw;
@@ -391,7 +399,9 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_
     BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 16, st));
     WlIndex ix{ srt, org, static_cast<const uint32_t*>(ctx->w_prefix.p), static_cast<const uint32_t*>(ctx->w_bitmap.p),
                 ctx->w_n, 32 - ctx->w_pbits, 32 - ctx->w_bbits };
-    PairTables pt{ static_cast<const uint32_t*>(ctx->w_poff.p), static_cast<const uint2*>(ctx->w_pent.p),
+    const size_t pstride = ((size_t)ctx->w_n + 3) & ~size_t(3);
+    PairTables pt{ static_cast<const uint32_t*>(ctx->w_poff.p), static_cast<const uint32_t*>(ctx->w_pent.p),
+                   static_cast<const uint32_t*>(ctx->w_pent.p) + 6 * pstride,
                    static_cast<const uint32_t*>(ctx->w_delmap.p), ctx->w_n };
     {
         ScopedKernelTimer tm(ctx, "k_nearest_pairs");
