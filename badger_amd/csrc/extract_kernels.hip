@@ -458,6 +458,8 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
 // walking in direction dir, as raw forward bytes (char k = byte k of w[]).
 // Characters outside the read are garbage; the caller masks them (k >= n).
 // ---------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };
+
 template <int NW>
 __device__ __forceinline__ void load_block(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                                            uint64_t rs, int64_t L, int strand, int64_t x0, int dir,
@@ -468,12 +470,23 @@ __device__ __forceinline__ void load_block(const uint8_t* __restrict__ bases, ui
     const int64_t a = (int64_t)rs + (asc ? f0 : f0 - (4 * NW - 1));
     const int64_t a_al = a & ~3ll;
     const uint32_t sh = (uint32_t)(a - a_al);
-    uint32_t t[NW + 1];
+    // NW+1 dwords from a dword-aligned address: 16-byte loads (global_load_dwordx4 only needs dword alignment; one
+    // wide load per lane costs the address unit far less than four narrow ones), per-dword guarded loads at the buffer edges
+    constexpr int NQ = (NW + 1 + 3) / 4;
+    uint32_t t[4 * NQ];
+    if (a_al >= 0 && (uint64_t)a_al + 16ull * NQ <= total_rounded) {
 #pragma unroll
-    for (int i = 0; i < NW + 1; ++i) {
-        const int64_t idx = a_al + 4 * i;
-        t[i] = (idx >= 0 && (uint64_t)idx + 4 <= total_rounded)
-                   ? *reinterpret_cast<const uint32_t*>(bases + idx) : 0u;
+        for (int qd = 0; qd < NQ; ++qd) {
+            const U4 v4 = *reinterpret_cast<const U4*>(bases + a_al + 16 * qd);
+            t[4 * qd] = v4.x; t[4 * qd + 1] = v4.y; t[4 * qd + 2] = v4.z; t[4 * qd + 3] = v4.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW + 1; ++i) {
+            const int64_t idx = a_al + 4 * i;
+            t[i] = (idx >= 0 && (uint64_t)idx + 4 <= total_rounded)
+                       ? *reinterpret_cast<const uint32_t*>(bases + idx) : 0u;
+        }
     }
     uint32_t u[NW];
 #pragma unroll
