@@ -8,6 +8,7 @@
 // launchers in the kernel translation units
 int bdg_extract_launch(bdg_ctx*, const uint8_t*, const uint64_t*, uint32_t, uint64_t, uint32_t, bdg_extract_rec*);
 int bdg_extract_status_impl(bdg_ctx*, uint64_t*, uint64_t*);
+int bdg_extract_counters_impl(bdg_ctx*, uint64_t*);
 int bdg_whitelist_load_impl(bdg_ctx*, const uint32_t*, uint32_t);
 int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
 int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*);
@@ -175,6 +176,12 @@ int bdg_extract_status(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_windows)
 {
     if (!ctx) return BDG_E_ARG;
     return bdg_extract_status_impl(ctx, bad_read, n_windows);
+}
+
+int bdg_extract_counters(bdg_ctx* ctx, uint64_t out[8])
+{
+    if (!ctx || !out) return BDG_E_ARG;
+    return bdg_extract_counters_impl(ctx, out);
 }
 
 int bdg_extract_batch(bdg_ctx* ctx, const uint8_t* bases, const uint64_t* off, uint32_t n,

@@ -50,7 +50,7 @@ constexpr uint32_t EQ0 = eq_mask(0), EQ1 = eq_mask(1), EQ2 = eq_mask(2), EQ3 = e
 constexpr int KEY_SHIFT = 11;                 // score | (63-col) << 5 | (31-row)
 constexpr int32_t ONE = 1 << KEY_SHIFT;
 
-enum { C_NAB = 0 /* queue A count | queue B count << 32 */, C_BADREAD = 1, C_NWINDOWS = 2, C_NKEPT = 4, C_NC = 5, C_NHITS = 6 };
+enum { C_NAB = 0 /* queue A count | queue B count << 32 */, C_BADREAD = 1, C_NWINDOWS = 2, C_ND = 3, C_NKEPT = 4, C_NC = 5, C_NHITS = 6, C_NSKIPPED = 7 };
 
 constexpr uint32_t HOLE_R = 0xFFFFFFFFu;   // unused queue slot
 
@@ -706,23 +706,22 @@ __device__ __forceinline__ uint32_t myers_search(uint32_t (&w)[10], int n, uint3
 __global__ __launch_bounds__(256)
 void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                      const uint64_t* __restrict__ off,
-                     const QEnt* __restrict__ qb, QEnt* __restrict__ qa, uint64_t qcap,
-                     unsigned long long* __restrict__ counters)
+                     const QEnt* __restrict__ qb, QEnt* __restrict__ qd, uint64_t qcap,
+                     unsigned long long* __restrict__ counters,
+                     const unsigned long long* __restrict__ keys)
 {
+    __shared__ uint2 s_buf[4][128];          // live hits {read, (pos << 1) | strand}, compacted per wave
     unsigned long long nb = counters[C_NAB] >> 32;
     if (nb > qcap) nb = qcap;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t stride = (uint64_t)gridDim.x * 256ull;
-    uint32_t nkept = 0;
-    for (uint64_t base = (uint64_t)blockIdx.x * 256ull + (threadIdx.x & ~63); base < nb; base += stride) {
-        const uint64_t g = base + lane;
-        QEnt e = make_uint4(HOLE_R, 0, 0, 0);
-        if (g < nb) e = qb[g];
-        const bool active = e.x != HOLE_R;
+    uint32_t nkept = 0, nskip = 0, nbuf = 0;
+
+    auto process = [&](uint2 h, bool active) {
         uint64_t rs = 0; int64_t L = 0;
-        if (active) { rs = off[e.x]; L = (int64_t)(off[e.x + 1] - rs); }
-        const uint32_t strand = e.y & 1u;
-        const int64_t pos = (int64_t)(e.y >> 1);
+        if (active) { rs = off[h.x]; L = (int64_t)(off[h.x + 1] - rs); }
+        const uint32_t strand = h.y & 1u;
+        const int64_t pos = (int64_t)(h.y >> 1);
         const int64_t ws = pos - (R1_LEN - KMER) > 0 ? pos - (R1_LEN - KMER) : 0;
         const int64_t we = pos + R1_LEN + 1 < L ? pos + R1_LEN + 1 : L;
         uint32_t w[10];
@@ -733,16 +732,48 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         if (m) {
             unsigned long long gb = 0;
             const uint32_t cnt = (uint32_t)__popcll(m);
-            if (lane == 0) gb = atomicAdd(&counters[C_NAB], (unsigned long long)cnt) & 0xFFFFFFFFull;
+            if (lane == 0) gb = atomicAdd(&counters[C_ND], (unsigned long long)cnt);
             gb = __shfl(gb, 0);
             if (keep) {
                 const unsigned long long idx = gb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (idx < qcap) qa[idx] = make_uint4(e.x, e.y, 1u, 0u);
+                if (idx < qcap) qd[idx] = make_uint4(h.x, h.y, 1u, 0u);
             }
             nkept += lane == 0 ? cnt : 0u;
         }
+    };
+
+    for (uint64_t base = (uint64_t)blockIdx.x * 256ull + (threadIdx.x & ~63); base < nb; base += stride) {
+        const uint64_t g = base + lane;
+        QEnt e = make_uint4(HOLE_R, 0, 0, 0);
+        if (g < nb) e = qb[g];
+        bool active = e.x != HOLE_R;
+        if (active) {
+            // The strict search only runs when the relaxed one found nothing acceptable (barcode_callers.py:195).
+            // Every relaxed candidate of this read-strand has been aligned by now: if its winner passes
+            // end_delta = 4, the strict result is never looked at.
+            const unsigned long long kr = keys[2ull * e.x + (e.y & 1u)];
+            if (kr != 0 && (R1_LEN - 1 - (int)(kr & 31u)) <= 4) { active = false; ++nskip; }
+        }
+        const unsigned long long m = __ballot(active);
+        if (active) s_buf[wv][nbuf + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(e.x, e.y);
+        nbuf += (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (nbuf >= 64u) {
+            nbuf -= 64u;
+            const uint2 h = s_buf[wv][nbuf + lane];
+            __builtin_amdgcn_wave_barrier();
+            process(h, true);
+        }
+    }
+    if (nbuf) {
+        const bool on = (uint32_t)lane < nbuf;
+        const uint2 h = on ? s_buf[wv][lane] : make_uint2(0u, 0u);
+        process(h, on);
     }
     if (lane == 0 && nkept) atomicAdd(&counters[C_NKEPT], (unsigned long long)nkept);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nskip += __shfl_xor(nskip, d);
+    if (lane == 0 && nskip) atomicAdd(&counters[C_NSKIPPED], (unsigned long long)nskip);
 }
 
 // ---------------------------------------------------------------------------
@@ -1059,11 +1090,6 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
                            qa, qb, qcap, counters, reinterpret_cast<unsigned int*>(counters + 8));
     }
     {
-        ScopedKernelTimer tm(ctx, "k_strict_filter");
-        hipLaunchKernelGGL(k_strict_filter, dim3(256 * 8), dim3(256), 0, st, d_bases, total_rounded, d_off,
-                           qb, qa, qcap, counters);
-    }
-    {
         ScopedKernelTimer tm(ctx, "k_sw_clusters");
         hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 8), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,
                            qa, (int)C_NAB, qcap, qc, counters, keys);
@@ -1071,7 +1097,18 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     {
         ScopedKernelTimer tm(ctx, "k_sw_requeued");
         hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 2), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,
-                           qc, (int)C_NC, qcap, qb, counters, keys);      // single hits: nothing is re-queued
+                           qc, (int)C_NC, qcap, qa, counters, keys);      // single hits: nothing is re-queued
+    }
+    {
+        // every relaxed candidate is aligned now; queue A is consumed and its buffer receives the filter's survivors (queue D)
+        ScopedKernelTimer tm(ctx, "k_strict_filter");
+        hipLaunchKernelGGL(k_strict_filter, dim3(256 * 8), dim3(256), 0, st, d_bases, total_rounded, d_off,
+                           qb, qa, qcap, counters, keys);
+    }
+    {
+        ScopedKernelTimer tm(ctx, "k_sw_survivors");
+        hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 2), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,
+                           qa, (int)C_ND, qcap, qc, counters, keys);
     }
     {
         ScopedKernelTimer tm(ctx, "k_finalize_reads");
@@ -1094,11 +1131,23 @@ int bdg_extract_status_impl(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_window
     const uint64_t cA = c[C_NAB] & 0xFFFFFFFFull, cB = c[C_NAB] >> 32;
     if (cA > ctx->x_hits_cap || cB > ctx->x_hits_cap || c[C_NC] > ctx->x_hits_cap) {
         uint64_t want = cA > cB ? cA : cB;
-        want = (want > c[C_NC] ? want : c[C_NC]) + c[C_NKEPT] + 4096;
+        want = (want > c[C_NC] ? want : c[C_NC]) + 4096;   // queue D (filter survivors) never exceeds queue B
         ctx->x_hits_cap = want;            // next launch reserves this much
         return bdg_fail(ctx, BDG_E_CAPACITY, "window queue overflow: rerun the batch (workspace grown)");
     }
     if (c[C_BADREAD] != ~0ull)
         return bdg_fail(ctx, BDG_E_BADBASE, "read " + std::to_string(c[C_BADREAD]) + " holds a byte outside 'ACGTN'");
+    return BDG_OK;
+}
+
+int bdg_extract_counters_impl(bdg_ctx* ctx, uint64_t out[8])
+{
+    memset(out, 0, sizeof(uint64_t) * 8);
+    if (!ctx->x_counters.p) return BDG_OK;
+    uint64_t c[8];
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(c, ctx->x_counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out[0] = c[C_NHITS]; out[1] = c[C_NAB] & 0xFFFFFFFFull; out[2] = c[C_NAB] >> 32; out[3] = c[C_NSKIPPED];
+    out[4] = c[C_NKEPT]; out[5] = c[C_NC]; out[6] = c[C_NWINDOWS];
     return BDG_OK;
 }

@@ -111,6 +111,7 @@ def main():
         rc, bad, nwin = ctx.extract_status()
     if rc != 0:
         raise SystemExit("extract failed: rc=%d bad_read=%d" % (rc, bad))
+    stats = ctx.extract_counters()
     ctx.profile(True)
     ctx.profile_reset()
 
@@ -143,7 +144,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%d synthetic ONT reads per GPU (mean %.0f bp) vs %d-entry whitelist: K1 extract + K2 nearest16(max_ed=2)"
                                    % (n, total_bytes / n, len(wl)),
-                       "reads_per_gpu": n, "whitelist": len(wl), "sw_windows_per_step": int(nwin),
+                       "reads_per_gpu": n, "whitelist": len(wl), "sw_windows_per_step": int(nwin), "pipeline_counts": stats,
                        "parallelism": "reads sharded per GPU, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
