@@ -50,12 +50,67 @@ constexpr uint32_t EQ0 = eq_mask(0), EQ1 = eq_mask(1), EQ2 = eq_mask(2), EQ3 = e
 constexpr int KEY_SHIFT = 11;                 // score | (63-col) << 5 | (31-row)
 constexpr int32_t ONE = 1 << KEY_SHIFT;
 
-enum { C_NAB = 0 /* queue A count | queue B count << 32 */, C_BADREAD = 1, C_NWINDOWS = 2, C_ND = 3, C_NKEPT = 4, C_NC = 5, C_NHITS = 6, C_NSKIPPED = 7 };
+// Counters.  One returning atomic on a single address completes every ~11 ns on this part, whoever issues it, so every hot
+// counter exists NSH times (blocks use shard blockIdx % NSH) and each copy owns a 128-byte line.
+constexpr int NSH = 8;
+enum { K_TASK = 0,      // next task of the shard (k_scan_reads)
+       K_NAB = 1,       // queue A count | queue B count << 32
+       K_NC = 2, K_ND = 3,
+       K_STAT = 4,      // S_* words below
+       K_LINES = 5 };
+enum { S_BADREAD = 0 /* max of ~read index, 0 = none */, S_NWINDOWS = 1, S_NKEPT = 2, S_NHITS = 3, S_NSKIPPED = 4 };
+constexpr int SH_WORDS = K_LINES * 16;                       // 64-bit words per shard
+constexpr size_t COUNTER_BYTES = (size_t)NSH * SH_WORDS * 8;
+
+__device__ __forceinline__ unsigned long long* ctr(unsigned long long* c, uint32_t shard, int kind)
+{
+    return c + shard * SH_WORDS + kind * 16;
+}
 
 constexpr uint32_t HOLE_R = 0xFFFFFFFFu;   // unused queue slot
 
 // queue entry: {read, (pos << 1) | strand, offset mask of the hits (bit 0 = first hit), unused}
 typedef uint4 QEnt;
+
+// A queue is NSH segments of `seg` entries, one per counter shard.  Consumers walk a virtual index g: entry g / NSH of
+// segment g % NSH, a hole where that segment is shorter than the longest one.
+__device__ __forceinline__ uint64_t queue_counts(const unsigned long long* counters, int kind, int half, uint64_t seg,
+                                                 uint32_t* s_cnt /* [NSH], shared */)
+{
+    if (threadIdx.x < NSH) {
+        unsigned long long c = *ctr(const_cast<unsigned long long*>(counters), threadIdx.x, kind);
+        if (kind == K_NAB) c = half ? c >> 32 : c & 0xFFFFFFFFull;
+        s_cnt[threadIdx.x] = (uint32_t)(c < seg ? c : seg);
+    }
+    __syncthreads();
+    uint32_t mx = 0;
+#pragma unroll
+    for (int k = 0; k < NSH; ++k) mx = s_cnt[k] > mx ? s_cnt[k] : mx;
+    return (uint64_t)mx * NSH;
+}
+__device__ __forceinline__ QEnt queue_fetch(const QEnt* __restrict__ q, uint64_t seg, const uint32_t* s_cnt, uint64_t g, uint64_t nq)
+{
+    QEnt e = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+    const uint32_t sh = (uint32_t)g & (NSH - 1);
+    const uint64_t idx = g / NSH;
+    if (g < nq && idx < s_cnt[sh]) e = q[sh * seg + idx];
+    return e;
+}
+// per-wave LDS staging of {read, (pos << 1) | strand} single-hit entries: one reservation per flush
+__device__ __forceinline__ void stage_flush(uint2* buf, uint32_t& n, int lane, QEnt* __restrict__ q, uint64_t seg, uint32_t shard,
+                                            unsigned long long* cnt)
+{
+    if (n == 0) return;
+    unsigned long long gb = 0;
+    if (lane == 0) gb = atomicAdd(cnt, (unsigned long long)n);
+    gb = __shfl(gb, 0);
+    for (uint32_t i = (uint32_t)lane; i < n; i += 64u) {
+        const unsigned long long idx = gb + i;
+        if (idx < seg) { const uint2 e = buf[i]; q[shard * seg + idx] = make_uint4(e.x, e.y, 1u, 0u); }
+    }
+    n = 0;
+    __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ uint32_t range_mask16(int32_t lo, int32_t hi)
 {
@@ -77,11 +132,12 @@ __device__ __forceinline__ uint32_t range_mask16(int32_t lo, int32_t hi)
 constexpr int TASK_READS = 8;
 constexpr uint32_t WENT = 256;             // per-wave staging (2 KiB)
 constexpr uint32_t WFLUSH = 128;           // flush once this many clusters are staged
-constexpr int TASK_SHARDS = 8;
+constexpr int TASK_SHARDS = NSH;
+constexpr int TAB_KMER7 = 768 + 4096;      // word offset of the 7-mer table inside the device tables
 
 struct TaskTab {                           // per wave, double buffered
-    uint64_t s[TASK_READS];                // read start (byte index)
-    int32_t  L[TASK_READS];                // read length
+    uint4    rd[TASK_READS];               // per read {A lo, A hi, -B, L}: vector `slot` of the task lies at byte A + 16 * slot and
+                                           // starts at read position 16 * slot - B
     uint32_t pend[TASK_READS];             // vectors of reads 0..j inclusive
 };
 
@@ -94,39 +150,62 @@ __device__ __forceinline__ uint32_t find_read(const TaskTab& t, uint32_t slot)
     return j;
 }
 
-__global__ __launch_bounds__(256, 5)
+__device__ __forceinline__ uint32_t spread16(uint32_t x)      // bit k -> bit 2k
+{
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    return (x | (x << 1)) & 0x55555555u;
+}
+__device__ __forceinline__ uint32_t gather_even(uint32_t x)   // bit 2k -> bit k
+{
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    return (x | (x >> 8)) & 0x0000FFFFu;
+}
+
+__global__ __launch_bounds__(256, 4)
 void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                   const uint64_t* __restrict__ off, uint32_t n,
                   const uint32_t* __restrict__ tables,
                   int32_t* __restrict__ polyt,
-                  QEnt* __restrict__ qa, QEnt* __restrict__ qb, uint64_t qcap,
-                  unsigned long long* __restrict__ counters,
-                  unsigned int* __restrict__ task_ctr)
+                  QEnt* __restrict__ qa_all, QEnt* __restrict__ qb_all, uint64_t qcap /* per segment */,
+                  unsigned long long* __restrict__ counters)
 {
-    __shared__ uint16_t s_kmer[4096];    // 6-mer code -> bit0 R1 6-mer, bit8 reverse-complement of one
-    __shared__ uint2 s_cls[256];         // byte -> {isT | isA<<16, isN | bad<<16}
+    // 7-mer code (14 bits, base p in bits 0-1) -> bit0/1: bases p..p+5 / p+1..p+6 are an R1 6-mer, bit2/3: same for
+    // the reverse complement of one.  One probe answers two positions.
+    __shared__ __attribute__((aligned(16))) uint8_t s_kmer[16384];
     __shared__ uint2 s_ent[4][WENT];     // per-wave cluster staging {(pos << 1) | strand, mask | ring slot << 16}
     __shared__ uint32_t s_ringr[4][32];  // read index of each ring slot
     __shared__ TaskTab s_tab[4][2];
     __shared__ int32_t s_pt[4][32][2];   // polyT of the reads of the wave's last 4 tasks (ring)
-    __shared__ uint2 s_cand[4][192];     // pending T/A-rich window candidates {mask, (p0 + 16) << 6 | ring << 1 | type}
+    __shared__ uint2 s_cand[4][192];     // pending T/A-rich candidates: even bits of .x = flags of the lane's 16 bases, of .y = next 16
+    __shared__ uint32_t s_candi[4][192]; // (p0 + 16) << 6 | ring << 1 | type
     __shared__ uint32_t s_ptmin[4][32][2];  // per ring slot and strand: min of (window start << 5 | offset), 0xFFFFFFFF = none
     __shared__ int32_t s_ringL[4][32];   // read length of each ring slot
     const int tid = threadIdx.x;
-    for (int k = tid; k < 4096; k += 256) { const uint32_t t = tables[768 + k]; s_kmer[k] = (uint16_t)((t & 1u) | ((t >> 16) << 8)); }
-    s_cls[tid] = reinterpret_cast<const uint2*>(tables + 256)[tid];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        reinterpret_cast<uint4*>(s_kmer)[tid + 256 * k] = reinterpret_cast<const uint4*>(tables + TAB_KMER7)[tid + 256 * k];
     __syncthreads();
 
     const int lane = tid & 63, wv = tid >> 6;
     const uint32_t ntasks = (n + TASK_READS - 1) / TASK_READS;
     const uint32_t shard = blockIdx.x % TASK_SHARDS;
+    unsigned int* const task_ctr = reinterpret_cast<unsigned int*>(ctr(counters, shard, K_TASK));
+    unsigned long long* const nab = ctr(counters, shard, K_NAB);
+    unsigned long long* const stat = ctr(counters, shard, K_STAT);
+    QEnt* const qa = qa_all + shard * qcap;                 // this shard's segments
+    QEnt* const qb = qb_all + shard * qcap;
     uint2* ent = s_ent[wv];
     uint32_t nent = 0, nhits_stat = 0;
 
     // take a task: k-th grab of this shard is task k * TASK_SHARDS + shard
     auto grab = [&]() -> uint32_t {
         uint32_t k = 0;
-        if (lane == 0) k = atomicAdd(&task_ctr[shard * 32], 1u);
+        if (lane == 0) k = atomicAdd(task_ctr, 1u);
         k = __shfl(k, 0);
         const unsigned long long t = (unsigned long long)k * TASK_SHARDS + shard;
         return t < ntasks ? (uint32_t)t : 0xFFFFFFFFu;
@@ -141,22 +220,31 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         int64_t L = (uint32_t)lane < nr ? (int64_t)(o1 - o) : 0;
         bool bad = false;
         if (L < 0 || L >= (1ll << 26) || o + (uint64_t)L > total_rounded) { bad = (uint32_t)lane < nr; L = 0; }
-        if (bad) atomicMin(&counters[C_BADREAD], (unsigned long long)(r0 + lane));      // corrupt offsets: report, never loop on them
+        if (bad) atomicMax(&stat[S_BADREAD], ~(unsigned long long)(r0 + lane));        // corrupt offsets: report, never loop on them
+        // every vector of a validated read lies inside [0, total_rounded): no bounds checks on the loads below
         uint32_t nv = L > 0 ? (uint32_t)(((o & 15ull) + (uint64_t)L + 15ull) >> 4) : 0u;
         uint32_t incl = nv;
 #pragma unroll
         for (int d = 1; d < TASK_READS; d <<= 1) { const uint32_t x = __shfl_up(incl, d); if (lane >= d) incl += x; }
-        if (lane < TASK_READS) { tb.s[lane] = o; tb.L[lane] = (int32_t)L; tb.pend[lane] = incl; }
+        if (lane < TASK_READS) {
+            const uint32_t excl = incl - nv;
+            const uint64_t A = (o & ~15ull) - 16ull * excl;
+            tb.rd[lane] = make_uint4((uint32_t)A, (uint32_t)(A >> 32), (uint32_t)(-(int32_t)(16u * excl + (uint32_t)(o & 15ull))), (uint32_t)L);
+            tb.pend[lane] = incl;
+        }
+    };
+    auto vec_at = [&](const TaskTab& tb, uint32_t j, uint32_t slot) -> uint4 {
+        const uint2 a = *reinterpret_cast<const uint2*>(&tb.rd[j]);
+        const uint64_t g0 = (((uint64_t)a.y << 32) | a.x) + 16ull * slot;
+        return *reinterpret_cast<const uint4*>(bases + g0);
     };
     auto slot_vec = [&](const TaskTab& tb, uint32_t slot, uint32_t nslots) -> uint4 {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (slot < nslots) {
-            const uint32_t j = find_read(tb, slot);
-            const uint32_t vidx = slot - (j ? tb.pend[j - 1] : 0u);
-            const uint64_t g0 = (tb.s[j] & ~15ull) + 16ull * vidx;
-            if (g0 < total_rounded) v = *reinterpret_cast<const uint4*>(bases + g0);
+        uint4 vv = make_uint4(0, 0, 0, 0);
+        if (nslots) {                                               // (an all-empty task may come with an empty buffer)
+            vv = *reinterpret_cast<const uint4*>(bases);           // idle lanes: valid letters (zeros would force the exact path)
+            if (slot < nslots) vv = vec_at(tb, find_read(tb, slot), slot);
         }
-        return v;
+        return vv;
     };
     // flush the wave's staged clusters: queue A (first hit left of polyT) / queue B (single hits for the filter)
     auto flush = [&]() {
@@ -176,7 +264,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             tA += a; tB += b;
         }
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&counters[C_NAB], (unsigned long long)tA | ((unsigned long long)tB << 32));
+        if (lane == 0) base = atomicAdd(nab, (unsigned long long)tA | ((unsigned long long)tB << 32));
         base = __shfl(base, 0);
         unsigned long long gA = base & 0xFFFFFFFFull, gB = base >> 32;
         for (uint32_t h0 = 0; h0 < nent; h0 += 64) {
@@ -211,13 +299,15 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
 
     // polyT: the forward strand wants the FIRST 16-window with >= 12 T, the reverse strand the LAST with >= 12 A
     // (= the first T-window of the reverse complement).  Both are order-independent reductions, so candidate lanes
-    // only park their 32-base mask here; 64 parked masks are evaluated together (16 shifted popcounts each) and the
+    // only park their flags here; 64 parked lanes are evaluated together (16 shifted popcounts each) and the
     // result is reduced with one LDS atomic min on (window start << 5 | offset of the first TTT, common.py:31).
     uint32_t ncand = 0;
     auto eval_cands = [&](uint32_t first, uint32_t count) {
         if ((uint32_t)lane < count) {
             const uint2 c = s_cand[wv][first + lane];
-            const uint32_t m = c.x; const int32_t p0 = (int32_t)(c.y >> 6) - 16; const uint32_t ring = (c.y >> 1) & 31u, typ = c.y & 1u;
+            const uint32_t info = s_candi[wv][first + lane];
+            const uint32_t m = gather_even(c.x) | (gather_even(c.y) << 16);
+            const int32_t p0 = (int32_t)(info >> 6) - 16; const uint32_t ring = (info >> 1) & 31u, typ = info & 1u;
             const int32_t L = s_ringL[wv][ring];
             uint32_t q = 0;
 #pragma unroll
@@ -264,141 +354,143 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         for (int k = 0; k < TASK_READS; ++k) P[k] = __builtin_amdgcn_readfirstlane(tb.pend[k]);
         const uint32_t nslots = P[TASK_READS - 1];
         const uint32_t niter = (nslots + 62u) / 63u;
-        // slot -> (read j, first slot of read j): compares against scalars, no dependent LDS search
-        auto map_slot = [&](uint32_t slot, uint32_t& jj, uint32_t& base) {
-            jj = 0; base = 0;
+        // read of a slot: boundaries at or below the step's first slot are counted on the scalar unit, only the few inside the
+        // step cost vector compares
+        auto map_j = [&](uint32_t slot_lo, uint32_t slot) -> uint32_t {
+            uint32_t js = 0;
 #pragma unroll
-            for (int k = 0; k < TASK_READS - 1; ++k) { const bool ge = P[k] <= slot; jj += ge ? 1u : 0u; base = ge ? P[k] : base; }
-        };
-        auto slot_vec_cur = [&](uint32_t slot) -> uint4 {
-            uint4 vv = make_uint4(0, 0, 0, 0);
-            if (slot < nslots) {
-                uint32_t jj, base;
-                map_slot(slot, jj, base);
-                const uint64_t g0 = (tb.s[jj] & ~15ull) + 16ull * (slot - base);
-                if (g0 < total_rounded) vv = *reinterpret_cast<const uint4*>(bases + g0);
-            }
-            return vv;
+            for (int k = 0; k < TASK_READS - 1; ++k) js += P[k] <= slot_lo ? 1u : 0u;
+            uint32_t jv = js;
+#pragma unroll
+            for (int k = 0; k < TASK_READS - 1; ++k)
+                if (P[k] > slot_lo && P[k] <= slot_lo + 63u) jv += P[k] <= slot ? 1u : 0u;
+            return jv;
         };
         const uint32_t ring0 = (tseq & 3u) * TASK_READS;
         if (lane < 2 * TASK_READS) s_ptmin[wv][ring0 + (lane >> 1)][lane & 1] = 0xFFFFFFFFu;
-        if (lane < TASK_READS) { s_ringr[wv][ring0 + lane] = (uint32_t)(r0 + lane); s_ringL[wv][ring0 + lane] = tb.L[lane]; }
+        if (lane < TASK_READS) { s_ringr[wv][ring0 + lane] = (uint32_t)(r0 + lane); s_ringL[wv][ring0 + lane] = (int32_t)tb.rd[lane].w; }
         __builtin_amdgcn_wave_barrier();
         if (!have_v) v = slot_vec(tb, (uint32_t)lane, nslots);
         have_v = false;
+        uint32_t j = map_j(0u, (uint32_t)lane);
 
         for (uint32_t it = 0; it < niter; ++it) {
-            const uint32_t slot = it * 63u + (uint32_t)lane;
-            // next step's vector first (or the next task's first vectors)
-            uint4 vn = make_uint4(0, 0, 0, 0);
-            if (it + 1 < niter) vn = slot_vec_cur(slot + 63u);
-            else if (next_task != 0xFFFFFFFFu) {
-                const TaskTab& tn = s_tab[wv][cur ^ 1];
-                vn = slot_vec(tn, (uint32_t)lane, tn.pend[TASK_READS - 1]);
-                have_v = true;
+            const uint32_t slot_lo = it * 63u;
+            const uint32_t slot = slot_lo + (uint32_t)lane;
+            // next step's vector first (or the next task's first vectors).  Exactly one load, issued by every lane on every
+            // path (idle lanes re-read the buffer's first vector), so that it stays in flight across this step's work.
+            uint32_t jn = 0, pj = 0, pslot = slot + 63u;
+            const TaskTab* ptab = &tb;
+            bool pvalid;
+            if (it + 1 < niter) {
+                jn = pj = map_j(slot_lo + 63u, pslot);
+                pvalid = pslot < nslots;
+            } else {
+                ptab = &s_tab[wv][cur ^ 1];
+                pslot = (uint32_t)lane;
+                pvalid = next_task != 0xFFFFFFFFu && pslot < ptab->pend[TASK_READS - 1];
+                pj = pvalid ? find_read(*ptab, pslot) : 0u;
+                have_v = next_task != 0xFFFFFFFFu;
             }
+            const uint2 pa = *reinterpret_cast<const uint2*>(&ptab->rd[pj]);
+            const uint64_t pg = pvalid ? (((uint64_t)pa.y << 32) | pa.x) + 16ull * pslot : 0ull;
+            const uint4 vn = *reinterpret_cast<const uint4*>(bases + pg);
             const bool act = slot < nslots;
-            uint32_t j, jbase;
-            map_slot(act ? slot : nslots - 1u, j, jbase);
-            const uint32_t vidx = slot - jbase;
-            const uint64_t s = tb.s[j];
-            const int32_t L = act ? tb.L[j] : 0;
-            const int32_t p0 = 16 * (int32_t)vidx - (int32_t)(s & 15ull);
+            const uint4 rd = tb.rd[j];
+            const int32_t L = act ? (int32_t)rd.w : 0;
+            const int32_t p0 = (int32_t)(slot << 4) + (int32_t)rd.z;
             const uint64_t r = r0 + j;
+            const bool same_next = lane < 63 && p0 + 16 < L;      // the next lane holds the next 16 bases of the same read
+            const bool worker = act && lane < 63;                  // lane 63 only feeds lane 62's look-ahead
 
-            // byte classes.  Fast path: (byte >> 1) & 7 is a perfect hash of "ACTG" (0..3) and 'N' (7); v_perm maps it
-            // to the expected letter and to the T / A / N flags, v_dot4 packs four flags into a nibble.  Any byte that
-            // is not its expected letter (bad base, or the zero padding behind the last read) sends the wave through
-            // the exact per-byte table instead.
+            // 2-bit codes.  (byte >> 1) & 7 is a perfect hash of "ACTG" (0..3); v_perm maps it back to the expected letter,
+            // v_dot4 packs four codes into a byte.  A byte that is not its expected letter (N, a bad base, the zero padding
+            // behind the last read) sends the whole wave through the exact per-byte path.
             const uint32_t words[4] = { v.x, v.y, v.z, v.w };
-            uint32_t T, A, N, bad = 0, codes;
             uint32_t sel[4], diff = 0;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 sel[d] = (words[d] >> 1) & 0x07070707u;
-                diff |= __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, sel[d]) ^ words[d];
+                diff |= __builtin_amdgcn_perm(0u, 0x47544341u, sel[d]) ^ words[d];
             }
-            const uint32_t rm = range_mask16(-p0, L - p0);
-            if (__ballot(diff != 0) == 0) {
-                uint32_t t01 = 0, t23 = 0, a01 = 0, a23 = 0, n01 = 0, n23 = 0, c[4];
+            const int32_t lo = max(-p0, 0);                                     // read bases of this vector: [lo, hi)
+            const int32_t hi = min(max(L - p0, 1), 16);           // (inactive lanes: anything, never used)
+            uint32_t rm_s = (0xFFFFFFFFu >> (32 - 2 * hi)) & (0xFFFFFFFFu << (2 * lo)) & 0x55555555u;
+            const int32_t hv = min(max(L - (KMER - 1) - p0, 0), 16);
+            uint32_t valid = ((1u << hv) - 1u) & (0xFFFFFFFFu << lo);          // 6-mer starts whose 6 bases lie in the read
+            uint32_t codes, bad = 0;
+            const bool exact = __ballot(diff != 0) != 0;
+            if (!exact) {
+                uint32_t c[4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const uint32_t wgt = (d & 1) ? 0x80402010u : 0x08040201u;
-                    const uint32_t fT = __builtin_amdgcn_perm(0u, 0x00010000u, sel[d]);
-                    const uint32_t fA = __builtin_amdgcn_perm(0u, 0x00000001u, sel[d]);
-                    const uint32_t fN = __builtin_amdgcn_perm(0x01000000u, 0u, sel[d]);
-                    if (d < 2) { t01 = __builtin_amdgcn_udot4(fT, wgt, t01, false); a01 = __builtin_amdgcn_udot4(fA, wgt, a01, false);
-                                 n01 = __builtin_amdgcn_udot4(fN, wgt, n01, false); }
-                    else       { t23 = __builtin_amdgcn_udot4(fT, wgt, t23, false); a23 = __builtin_amdgcn_udot4(fA, wgt, a23, false);
-                                 n23 = __builtin_amdgcn_udot4(fN, wgt, n23, false); }
-                    c[d] = __builtin_amdgcn_udot4(sel[d] & 0x03030303u, 0x40100401u, 0u, false);
-                }
-                T = (t01 | (t23 << 8)) & rm;
-                A = (a01 | (a23 << 8)) & rm;
-                N = ((n01 | (n23 << 8)) | ~rm) & 0xFFFFu;       // out-of-read behaves like N
+                for (int d = 0; d < 4; ++d) c[d] = __builtin_amdgcn_udot4(sel[d], 0x40100401u, 0u, false);
                 codes = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
             } else {
-                uint32_t ta = 0, nb = 0;
+                uint32_t nN = 0, nbad = 0;
                 codes = 0;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const uint32_t b = (words[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                    const uint2 cc = s_cls[b];
-                    ta |= cc.x << k;
-                    nb |= cc.y << k;
+                    const bool isN = b == 'N';
+                    const bool ok = b == 'A' || b == 'C' || b == 'G' || b == 'T';
+                    nN |= (isN ? 1u : 0u) << k;
+                    nbad |= ((isN || ok) ? 0u : 1u) << k;
                     codes |= ((b >> 1) & 3u) << (2 * k);
                 }
-                T = ta & 0xFFFFu & rm;
-                A = (ta >> 16) & rm;
-                N = ((nb & 0xFFFFu) | ~rm) & 0xFFFFu;
-                bad = (nb >> 16) & rm;
+                const uint32_t rm16 = (0xFFFFu >> (16 - hi)) & (0xFFFFu << lo);
+                bad = nbad & rm16;
+                nN = (nN | ~rm16) & 0xFFFFu;                                     // out-of-read behaves like N
+                rm_s &= ~spread16(nN | nbad);                                    // neither T nor A
+                uint32_t N1 = __shfl_down(nN, 1);
+                if (!same_next) N1 = 0xFFFFu;
+                const uint32_t N32 = nN | (N1 << 16);
+                uint32_t nvm = N32 | (N32 >> 1);
+                nvm |= nvm >> 2;
+                nvm |= N32 >> 4; nvm |= N32 >> 5;
+                valid &= ~nvm;                                                   // 6-mers touching an N never match
             }
+            // T = code 2, A = code 0: flags on the even bits
+            const uint32_t T_s = (codes >> 1) & ~codes & rm_s;
+            const uint32_t A_s = ~((codes >> 1) | codes) & rm_s;
 
-            // look-ahead from the next lane, unless that lane belongs to another read
-            const uint32_t j_next = __shfl_down(act ? j : 0xFFu, 1);     // all lanes must take part: an inactive source lane reads as 0
-            const bool same_next = lane < 63 && j_next == j;
-            uint32_t TA1 = __shfl_down(T | (A << 16), 1);
-            uint32_t N1 = __shfl_down(N, 1);
+            // look-ahead from the next lane (all lanes take part in the shuffles: an inactive source lane reads as 0)
+            uint32_t TA1 = __shfl_down(T_s | (A_s << 1), 1);
             const uint32_t codes1 = __shfl_down(codes, 1);
-            if (!same_next) { TA1 = 0; N1 = 0xFFFFu; }
-            const uint32_t T32 = T | (TA1 << 16);
-            const uint32_t A32 = A | (TA1 & 0xFFFF0000u);
-            const uint32_t N32 = N | (N1 << 16);
-            const bool worker = act && lane < 63;
+            if (!same_next) TA1 = 0;
 
-            // R1 6-mer hits of both strands: 16 table probes
-            uint32_t hlo = 0, hhi = 0;          // probes of bases 0..7 / 8..15: F bits 0..7, R bits 8..15 of each
+            // R1 6-mer hits of both strands: 8 probes of the 7-mer table, two positions each
+            uint32_t accA = 0, accB = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                // byte offset of the 6-mer code in the table: code * 2
-                const uint32_t ko = (k == 0 ? (codes << 1) : __builtin_amdgcn_alignbit(codes1, codes, 2 * k - 1)) & 0x1FFEu;
-                const uint32_t e = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(s_kmer) + ko);
-                if (k < 8) hlo |= e << k; else hhi |= e << (k - 8);
+            for (int k = 0; k < 16; k += 2) {
+                const uint32_t idx = k <= 8 ? __builtin_amdgcn_ubfe(codes, 2 * k, 14)
+                                            : (__builtin_amdgcn_alignbit(codes1, codes, 2 * k) & 0x3FFFu);
+                const uint32_t e = s_kmer[idx];
+                if (k & 2) accB |= e << k; else accA |= e << k;
             }
-            const uint32_t hits = (hlo & 0xFFu) | ((hhi & 0xFFu) << 8) | ((hlo & 0xFF00u) << 8) | ((hhi & 0xFF00u) << 16);
-            uint32_t nv = N32 | (N32 >> 1);
-            nv |= nv >> 2;
-            nv |= N32 >> 4; nv |= N32 >> 5;
-            const uint32_t valid = ~nv & 0xFFFFu;               // 6-mers touching an N or leaving the read never match
-            uint32_t hitF = hits & valid, hitR = (hits >> 16) & valid;
+            // accA: probes 0,4,8,12 -> forward flags on bits = 0,1 (mod 4), reverse flags two bits above; accB: probes 2,6,10,14
+            uint32_t hitF = ((accA & 0x3333u) | (accB & 0xCCCCu)) & valid;
+            uint32_t hitR = (((accA & 0xCCCCu) | (accB & 0x33330u)) >> 2) & valid;
             if (!worker) { hitF = 0; hitR = 0; }
 
             // polyT windows.  A 16-window with >= 12 T needs >= 12 T among the 31 bases a lane can see, which few lanes
-            // have: those lanes park their mask; evaluation happens 64 masks at a time (eval_cands).
+            // have: those lanes park their flags; evaluation happens 64 lanes at a time (eval_cands).
             {
-                const bool cT = worker && __popc(T32 & 0x7FFFFFFFu) >= 12, cA = worker && __popc(A32 & 0x7FFFFFFFu) >= 12;
+                const bool cT = worker && __popc(T_s) + __popc(TA1 & 0x15555555u) >= 12;
+                const bool cA = worker && __popc(A_s) + __popc(TA1 & 0x2AAAAAAAu) >= 12;
                 const unsigned long long bT = __ballot(cT), bA = __ballot(cA);
                 const uint32_t nT = (uint32_t)__popcll(bT), nc = nT + (uint32_t)__popcll(bA);
                 if (nc) {
                     const unsigned long long below = (1ull << lane) - 1ull;
                     const uint32_t info = ((uint32_t)(p0 + 16) << 6) | ((ring0 + j) << 1);
-                    if (cT) s_cand[wv][ncand + (uint32_t)__popcll(bT & below)] = make_uint2(T32, info);
-                    if (cA) s_cand[wv][ncand + nT + (uint32_t)__popcll(bA & below)] = make_uint2(A32, info | 1u);
+                    if (cT) { const uint32_t at = ncand + (uint32_t)__popcll(bT & below);
+                              s_cand[wv][at] = make_uint2(T_s, TA1); s_candi[wv][at] = info; }
+                    if (cA) { const uint32_t at = ncand + nT + (uint32_t)__popcll(bA & below);
+                              s_cand[wv][at] = make_uint2(A_s, TA1 >> 1); s_candi[wv][at] = info | 1u; }
                     ncand += nc;
                 }
             }
-            if (__ballot(bad != 0 && worker)) {
-                if (bad != 0 && worker) atomicMin(&counters[C_BADREAD], (unsigned long long)r);
+            if (exact && __ballot(bad != 0 && worker)) {
+                if (bad != 0 && worker) atomicMax(&stat[S_BADREAD], ~(unsigned long long)r);
             }
             // one cluster per lane and strand: first hit + offsets of the others
             nhits_stat += __popc(hitF) + __popc(hitR);
@@ -410,7 +502,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 const bool fits = nent + total <= WENT;
                 unsigned long long gbase = 0;
                 if (!fits) {            // staging full (pathological reads): this step goes straight to queue A
-                    if (lane == 0) gbase = atomicAdd(&counters[C_NAB], (unsigned long long)total) & 0xFFFFFFFFull;
+                    if (lane == 0) gbase = atomicAdd(nab, (unsigned long long)total) & 0xFFFFFFFFull;
                     gbase = __shfl(gbase, 0);
                 }
                 unsigned long long idx = (fits ? nent : gbase) + excl;
@@ -429,6 +521,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 if (fits) nent += total;
             }
             v = vn;
+            j = jn;
             __builtin_amdgcn_wave_barrier();
             while (ncand >= 64u) { ncand -= 64u; eval_cands(ncand, 64u); }
         }
@@ -450,7 +543,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     flush();
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) nhits_stat += __shfl_xor(nhits_stat, d);
-    if (lane == 0 && nhits_stat) atomicAdd(&counters[C_NHITS], (unsigned long long)nhits_stat);
+    if (lane == 0 && nhits_stat) atomicAdd(&stat[S_NHITS], (unsigned long long)nhits_stat);
 }
 
 // ---------------------------------------------------------------------------
@@ -706,16 +799,18 @@ __device__ __forceinline__ uint32_t myers_search(uint32_t (&w)[10], int n, uint3
 __global__ __launch_bounds__(256)
 void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                      const uint64_t* __restrict__ off,
-                     const QEnt* __restrict__ qb, QEnt* __restrict__ qd, uint64_t qcap,
+                     const QEnt* __restrict__ qb, QEnt* __restrict__ qd, uint64_t seg,
                      unsigned long long* __restrict__ counters,
                      const unsigned long long* __restrict__ keys)
 {
     __shared__ uint2 s_buf[4][128];          // live hits {read, (pos << 1) | strand}, compacted per wave
-    unsigned long long nb = counters[C_NAB] >> 32;
-    if (nb > qcap) nb = qcap;
+    __shared__ uint2 s_out[4][128];          // survivors, flushed with one reservation
+    __shared__ uint32_t s_cnt[NSH];
+    const uint64_t nb = queue_counts(counters, K_NAB, 1, seg, s_cnt);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t shard = blockIdx.x % NSH;
     const uint64_t stride = (uint64_t)gridDim.x * 256ull;
-    uint32_t nkept = 0, nskip = 0, nbuf = 0;
+    uint32_t nkept = 0, nskip = 0, nbuf = 0, nout = 0;
 
     auto process = [&](uint2 h, bool active) {
         uint64_t rs = 0; int64_t L = 0;
@@ -730,22 +825,15 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const bool keep = active && k <= 5u;
         const unsigned long long m = __ballot(keep);
         if (m) {
-            unsigned long long gb = 0;
             const uint32_t cnt = (uint32_t)__popcll(m);
-            if (lane == 0) gb = atomicAdd(&counters[C_ND], (unsigned long long)cnt);
-            gb = __shfl(gb, 0);
-            if (keep) {
-                const unsigned long long idx = gb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (idx < qcap) qd[idx] = make_uint4(h.x, h.y, 1u, 0u);
-            }
-            nkept += lane == 0 ? cnt : 0u;
+            if (nout + cnt > 128u) stage_flush(s_out[wv], nout, lane, qd, seg, shard, ctr(counters, shard, K_ND));
+            if (keep) s_out[wv][nout + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = h;
+            nout += cnt; nkept += cnt;
         }
     };
 
     for (uint64_t base = (uint64_t)blockIdx.x * 256ull + (threadIdx.x & ~63); base < nb; base += stride) {
-        const uint64_t g = base + lane;
-        QEnt e = make_uint4(HOLE_R, 0, 0, 0);
-        if (g < nb) e = qb[g];
+        const QEnt e = queue_fetch(qb, seg, s_cnt, base + lane, nb);
         bool active = e.x != HOLE_R;
         if (active) {
             // The strict search only runs when the relaxed one found nothing acceptable (barcode_callers.py:195).
@@ -770,10 +858,13 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const uint2 h = on ? s_buf[wv][lane] : make_uint2(0u, 0u);
         process(h, on);
     }
-    if (lane == 0 && nkept) atomicAdd(&counters[C_NKEPT], (unsigned long long)nkept);
+    __builtin_amdgcn_wave_barrier();
+    stage_flush(s_out[wv], nout, lane, qd, seg, shard, ctr(counters, shard, K_ND));
+    unsigned long long* const stat = ctr(counters, shard, K_STAT);
+    if (lane == 0 && nkept) atomicAdd(&stat[S_NKEPT], (unsigned long long)nkept);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) nskip += __shfl_xor(nskip, d);
-    if (lane == 0 && nskip) atomicAdd(&counters[C_NSKIPPED], (unsigned long long)nskip);
+    if (lane == 0 && nskip) atomicAdd(&stat[S_NSKIPPED], (unsigned long long)nskip);
 }
 
 // ---------------------------------------------------------------------------
@@ -790,12 +881,10 @@ struct ClusterJob {
     int n_s, n_r, n_u;
 };
 
-__device__ __forceinline__ ClusterJob make_job(const QEnt* __restrict__ q, uint64_t g, uint64_t nq,
+__device__ __forceinline__ ClusterJob make_job(const QEnt e,
                                                const uint64_t* __restrict__ off, const int32_t* __restrict__ polyt)
 {
     ClusterJob jb;
-    QEnt e = make_uint4(HOLE_R, 0, 0, 0);
-    if (g < nq) e = q[g];
     jb.active = e.x != HOLE_R;
     jb.r = jb.active ? e.x : 0u; jb.strand = e.y & 1u; jb.mask = jb.active ? e.z : 0u;
     jb.pos = jb.active ? (int64_t)(e.y >> 1) : 0;
@@ -814,10 +903,9 @@ __device__ __forceinline__ ClusterJob make_job(const QEnt* __restrict__ q, uint6
     return jb;
 }
 
-// keys of the first hit, and re-queue of the other hits when the union beats it
-__device__ __forceinline__ void finish_job(const ClusterJob& jb, uint32_t acc_s, uint32_t acc_r, uint32_t acc_u, int lane,
-                                           uint32_t n_reads, uint64_t qcap, QEnt* __restrict__ qc,
-                                           unsigned long long* __restrict__ counters, unsigned long long* __restrict__ keys)
+// keys of the first hit; returns the other hits of the cluster when the union beats it (they must be aligned one by one)
+__device__ __forceinline__ uint32_t finish_job(const ClusterJob& jb, uint32_t acc_s, uint32_t acc_r, uint32_t acc_u,
+                                               uint32_t n_reads, unsigned long long* __restrict__ keys)
 {
     const uint32_t score_s = acc_s >> KEY_SHIFT;
     if (jb.active && score_s >= 17u)                                                    // barcode_callers.py:200
@@ -827,43 +915,31 @@ __device__ __forceinline__ void finish_job(const ClusterJob& jb, uint32_t acc_s,
     // Every window of the cluster lies inside the union, so no later hit scores above the union.
     // If the union does not beat the first hit, none of them can replace it (strictly greater is
     // required, common.py:102); otherwise align them one by one (queue C, second launch).
-    uint32_t rest = (jb.active && (acc_u >> KEY_SHIFT) > score_s) ? (jb.mask & ~1u) : 0u;
-    if (__ballot(rest != 0)) {
-        const uint32_t cnt = __popc(rest);
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-        const uint32_t total = __shfl(incl, 63);
-        unsigned long long gb = 0;
-        if (lane == 63) gb = atomicAdd(&counters[C_NC], (unsigned long long)total);
-        gb = __shfl(gb, 63);
-        unsigned long long idx = gb + incl - cnt;
-        while (rest) {
-            const int j = __builtin_ctz(rest); rest &= rest - 1;
-            if (idx < qcap) qc[idx] = make_uint4(jb.r, ((uint32_t)(jb.pos + j) << 1) | jb.strand, 1u, 0u);
-            ++idx;
-        }
-    }
+    return (jb.active && (acc_u >> KEY_SHIFT) > score_s) ? (jb.mask & ~1u) : 0u;
 }
+
+constexpr uint32_t REQ_CAP = 256;            // per-wave staging of re-queued hits
 
 __global__ __launch_bounds__(256)
 void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                    const uint64_t* __restrict__ off, uint32_t n_reads,
                    const int32_t* __restrict__ polyt,
-                   const QEnt* __restrict__ q, int count_idx, uint64_t qcap,
+                   const QEnt* __restrict__ q, int kind, uint64_t seg,
                    QEnt* __restrict__ qc,
                    unsigned long long* __restrict__ counters,
                    unsigned long long* __restrict__ keys)
 {
-    unsigned long long nq = counters[count_idx];
-    if (count_idx == C_NAB) nq &= 0xFFFFFFFFull;
-    if (nq > qcap) nq = qcap;
-    const int lane = threadIdx.x & 63;
+    __shared__ uint2 s_out[4][REQ_CAP];
+    __shared__ uint32_t s_cnt[NSH];
+    const uint64_t nq = queue_counts(counters, kind, 0, seg, s_cnt);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t shard = blockIdx.x % NSH;
+    unsigned long long* const nc = ctr(counters, shard, K_NC);
     const uint64_t stride = (uint64_t)gridDim.x * 512ull;           // two clusters per lane
-    uint32_t nwin = 0;
+    uint32_t nwin = 0, nout = 0;
     for (uint64_t base = (uint64_t)blockIdx.x * 512ull + 2ull * (threadIdx.x & ~63); base < nq; base += stride) {
-        const ClusterJob ja = make_job(q, base + 2ull * lane, nq, off, polyt);
-        const ClusterJob jb = make_job(q, base + 2ull * lane + 1, nq, off, polyt);
+        const ClusterJob ja = make_job(queue_fetch(q, seg, s_cnt, base + 2ull * lane, nq), off, polyt);
+        const ClusterJob jb = make_job(queue_fetch(q, seg, s_cnt, base + 2ull * lane + 1, nq), off, polyt);
         uint32_t wa[CW], wb[CW];
         load_block<CW>(bases, total_rounded, ja.rs, ja.L, (int)ja.strand, ja.ws, +1, wa);
         load_block<CW>(bases, total_rounded, jb.rs, jb.L, (int)jb.strand, jb.ws, +1, wb);
@@ -873,13 +949,51 @@ void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const uint32_t acc = anyN ? sw_block2<CW, true>(wa, wb, ndw, ja.n_u, jb.n_u, ja.strand, jb.strand, ja.n_s, ja.n_r, jb.n_s, jb.n_r, sn_s, sn_r)
                                   : sw_block2<CW, false>(wa, wb, ndw, ja.n_u, jb.n_u, ja.strand, jb.strand, ja.n_s, ja.n_r, jb.n_s, jb.n_r, sn_s, sn_r);
         nwin += (ja.active ? 1u : 0u) + (jb.active ? 1u : 0u);
-        finish_job(ja, unpk(sn_s, 0), unpk(sn_r, 0), unpk(acc, 0), lane, n_reads, qcap, qc, counters, keys);
-        finish_job(jb, unpk(sn_s, 1), unpk(sn_r, 1), unpk(acc, 1), lane, n_reads, qcap, qc, counters, keys);
+        uint32_t rest_a = finish_job(ja, unpk(sn_s, 0), unpk(sn_r, 0), unpk(acc, 0), n_reads, keys);
+        uint32_t rest_b = finish_job(jb, unpk(sn_s, 1), unpk(sn_r, 1), unpk(acc, 1), n_reads, keys);
+        if (__ballot((rest_a | rest_b) != 0)) {
+            const uint32_t cnt = __popc(rest_a) + __popc(rest_b);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            const uint32_t total = __shfl(incl, 63);
+            if (nout + total > REQ_CAP) stage_flush(s_out[wv], nout, lane, qc, seg, shard, nc);
+            if (total <= REQ_CAP) {
+                uint32_t idx = nout + incl - cnt;
+                while (rest_a) {
+                    const int j = __builtin_ctz(rest_a); rest_a &= rest_a - 1;
+                    s_out[wv][idx++] = make_uint2(ja.r, ((uint32_t)(ja.pos + j) << 1) | ja.strand);
+                }
+                while (rest_b) {
+                    const int j = __builtin_ctz(rest_b); rest_b &= rest_b - 1;
+                    s_out[wv][idx++] = make_uint2(jb.r, ((uint32_t)(jb.pos + j) << 1) | jb.strand);
+                }
+                nout += total;
+                __builtin_amdgcn_wave_barrier();
+            } else {                       // more than the staging holds (dense repeats): straight to the queue
+                unsigned long long gb = 0;
+                if (lane == 63) gb = atomicAdd(nc, (unsigned long long)total);
+                gb = __shfl(gb, 63);
+                unsigned long long idx = gb + incl - cnt;
+                while (rest_a) {
+                    const int j = __builtin_ctz(rest_a); rest_a &= rest_a - 1;
+                    if (idx < seg) qc[shard * seg + idx] = make_uint4(ja.r, ((uint32_t)(ja.pos + j) << 1) | ja.strand, 1u, 0u);
+                    ++idx;
+                }
+                while (rest_b) {
+                    const int j = __builtin_ctz(rest_b); rest_b &= rest_b - 1;
+                    if (idx < seg) qc[shard * seg + idx] = make_uint4(jb.r, ((uint32_t)(jb.pos + j) << 1) | jb.strand, 1u, 0u);
+                    ++idx;
+                }
+            }
+        }
     }
+    __builtin_amdgcn_wave_barrier();
+    stage_flush(s_out[wv], nout, lane, qc, seg, shard, nc);
     // window count (statistics only)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) nwin += __shfl_xor(nwin, d);
-    if (lane == 0 && nwin) atomicAdd(&counters[C_NWINDOWS], (unsigned long long)nwin);
+    if (lane == 0 && nwin) atomicAdd(&ctr(counters, shard, K_STAT)[S_NWINDOWS], (unsigned long long)nwin);
 }
 
 // ---------------------------------------------------------------------------
@@ -1015,7 +1129,7 @@ void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
 }
 
 // host-side tables -------------------------------------------------------------
-constexpr int TABLE_WORDS = 768 + 4096;
+constexpr int TABLE_WORDS = 768 + 4096 + 4096;
 
 void build_tables(uint32_t* t /* 256 (packed 2-bit LUT, unused by the kernels) + 512 (byte classes) + 4096 (direct 6-mer table) */)
 {
@@ -1031,6 +1145,11 @@ void build_tables(uint32_t* t /* 256 (packed 2-bit LUT, unused by the kernels) +
         t[kr >> 4] |= 2u << ((kr & 15u) * 2u);
         t[768 + kf] |= 1u;
         t[768 + kr] |= 1u << 16;
+    }
+    uint8_t* k7 = reinterpret_cast<uint8_t*>(t + TAB_KMER7);
+    for (uint32_t idx = 0; idx < 16384u; ++idx) {
+        const uint32_t e0 = t[768 + (idx & 4095u)], e1 = t[768 + (idx >> 2)];
+        k7[idx] = (uint8_t)((e0 & 1u) | ((e1 & 1u) << 1) | (((e0 >> 16) & 1u) << 2) | (((e1 >> 16) & 1u) << 3));
     }
     for (int b = 0; b < 256; ++b) {
         const bool isA = b == 'A', isC = b == 'C', isG = b == 'G', isT = b == 'T', isN = b == 'N';
@@ -1060,44 +1179,44 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     }
     if ((rc = bdg_reserve(ctx, ctx->x_polyt, sizeof(int32_t) * 2ull * n))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->x_keys, sizeof(uint64_t) * 4ull * n))) return rc;
-    if ((rc = bdg_reserve(ctx, ctx->x_counters, 64 + TASK_SHARDS * 128))) return rc;     // counters | task counters (one 128-B line each)
-    // three cluster queues (A: aligned, B: filtered first, C: re-queued hits of a cluster), 16 B per entry
-    uint64_t want = total_bytes / 48 + 4096;
+    if ((rc = bdg_reserve(ctx, ctx->x_counters, COUNTER_BYTES))) return rc;
+    // three cluster queues (A: aligned, B: filtered first, C: re-queued hits of a cluster; D, the filter's survivors, reuses A),
+    // 16 B per entry, each made of NSH segments of x_hits_cap entries
+    uint64_t want = (total_bytes / 48 + 4096 + NSH - 1) / NSH;
     if (want < ctx->x_hits_cap) want = ctx->x_hits_cap;
-    if ((rc = bdg_reserve(ctx, ctx->x_hits, sizeof(QEnt) * 3ull * want))) return rc;
-    ctx->x_hits_cap = ctx->x_hits.bytes / sizeof(QEnt) / 3;
-    const uint64_t qcap = ctx->x_hits_cap;
+    if ((rc = bdg_reserve(ctx, ctx->x_hits, sizeof(QEnt) * 3ull * NSH * want))) return rc;
+    ctx->x_hits_cap = ctx->x_hits.bytes / sizeof(QEnt) / (3 * NSH);
+    const uint64_t qcap = ctx->x_hits_cap;                     // per segment
     QEnt* qa = static_cast<QEnt*>(ctx->x_hits.p);
-    QEnt* qb = qa + qcap;
-    QEnt* qc = qb + qcap;
+    QEnt* qb = qa + NSH * qcap;
+    QEnt* qc = qb + NSH * qcap;
 
     hipStream_t st = ctx->stream;
     const uint64_t total_rounded = (total_bytes + 15ull) & ~15ull;
     auto* counters = static_cast<unsigned long long*>(ctx->x_counters.p);
     auto* keys = static_cast<unsigned long long*>(ctx->x_keys.p);
     const auto* pt = static_cast<const int32_t*>(ctx->x_polyt.p);
-    BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64 + TASK_SHARDS * 128, st));
-    BDG_HIP_TRY(ctx, hipMemsetAsync(counters + C_BADREAD, 0xFF, 8, st));
+    BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, COUNTER_BYTES, st));
     BDG_HIP_TRY(ctx, hipMemsetAsync(keys, 0, sizeof(uint64_t) * 4ull * n, st));
     {
         ScopedKernelTimer tm(ctx, "k_scan_reads");
         const uint32_t ntasks = (n + TASK_READS - 1) / TASK_READS;
         uint32_t grid = (ntasks + 3) / 4;
-        if (grid > 256u * 5u) grid = 256u * 5u;                                  // persistent: 5 blocks per CU
+        if (grid > 256u * 4u) grid = 256u * 4u;                                  // persistent: 4 blocks per CU (LDS)
         grid = (grid + TASK_SHARDS - 1) / TASK_SHARDS * TASK_SHARDS;            // every shard has a block
         hipLaunchKernelGGL(k_scan_reads, dim3(grid), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
                            static_cast<const uint32_t*>(ctx->x_lut.p), static_cast<int32_t*>(ctx->x_polyt.p),
-                           qa, qb, qcap, counters, reinterpret_cast<unsigned int*>(counters + 8));
+                           qa, qb, qcap, counters);
     }
     {
         ScopedKernelTimer tm(ctx, "k_sw_clusters");
         hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 8), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,
-                           qa, (int)C_NAB, qcap, qc, counters, keys);
+                           qa, (int)K_NAB, qcap, qc, counters, keys);
     }
     {
         ScopedKernelTimer tm(ctx, "k_sw_requeued");
         hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 2), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,
-                           qc, (int)C_NC, qcap, qa, counters, keys);      // single hits: nothing is re-queued
+                           qc, (int)K_NC, qcap, qa, counters, keys);      // single hits: nothing is re-queued
     }
     {
         // every relaxed candidate is aligned now; queue A is consumed and its buffer receives the filter's survivors (queue D)
@@ -1108,7 +1227,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     {
         ScopedKernelTimer tm(ctx, "k_sw_survivors");
         hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 2), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,
-                           qa, (int)C_ND, qcap, qc, counters, keys);
+                           qa, (int)K_ND, qcap, qc, counters, keys);
     }
     {
         ScopedKernelTimer tm(ctx, "k_finalize_reads");
@@ -1120,23 +1239,45 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     return BDG_OK;
 }
 
+namespace {
+struct CounterSums { uint64_t a_max, b_max, c_max, a, b, c, d, bad, stat[5]; };
+
+int read_counters(bdg_ctx* ctx, CounterSums& cs)
+{
+    std::vector<uint64_t> c(COUNTER_BYTES / 8);
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(c.data(), ctx->x_counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memset(&cs, 0, sizeof(cs));
+    for (int sh = 0; sh < NSH; ++sh) {
+        const uint64_t* w = c.data() + (size_t)sh * SH_WORDS;
+        const uint64_t a = w[K_NAB * 16] & 0xFFFFFFFFull, b = w[K_NAB * 16] >> 32, cc = w[K_NC * 16];
+        cs.a += a; cs.b += b; cs.c += cc; cs.d += w[K_ND * 16];
+        cs.a_max = a > cs.a_max ? a : cs.a_max; cs.b_max = b > cs.b_max ? b : cs.b_max; cs.c_max = cc > cs.c_max ? cc : cs.c_max;
+        const uint64_t* st = w + K_STAT * 16;
+        cs.bad = st[S_BADREAD] > cs.bad ? st[S_BADREAD] : cs.bad;                 // max of ~index = smallest index
+        for (int k = 1; k < 5; ++k) cs.stat[k] += st[k];
+    }
+    return BDG_OK;
+}
+}  // namespace
+
 int bdg_extract_status_impl(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_windows)
 {
     if (!ctx->x_counters.p) { if (bad_read) *bad_read = ~0ull; if (n_windows) *n_windows = 0; return BDG_OK; }
-    uint64_t c[8];
-    BDG_HIP_TRY(ctx, hipMemcpyAsync(c, ctx->x_counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
-    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (bad_read) *bad_read = c[C_BADREAD];
-    if (n_windows) *n_windows = c[C_NWINDOWS];
-    const uint64_t cA = c[C_NAB] & 0xFFFFFFFFull, cB = c[C_NAB] >> 32;
-    if (cA > ctx->x_hits_cap || cB > ctx->x_hits_cap || c[C_NC] > ctx->x_hits_cap) {
-        uint64_t want = cA > cB ? cA : cB;
-        want = (want > c[C_NC] ? want : c[C_NC]) + 4096;   // queue D (filter survivors) never exceeds queue B
-        ctx->x_hits_cap = want;            // next launch reserves this much
+    CounterSums cs;
+    int rc;
+    if ((rc = read_counters(ctx, cs))) return rc;
+    const uint64_t bad = cs.bad ? ~cs.bad : ~0ull;
+    if (bad_read) *bad_read = bad;
+    if (n_windows) *n_windows = cs.stat[S_NWINDOWS];
+    if (cs.a_max > ctx->x_hits_cap || cs.b_max > ctx->x_hits_cap || cs.c_max > ctx->x_hits_cap) {
+        uint64_t want = cs.a_max > cs.b_max ? cs.a_max : cs.b_max;
+        want = (want > cs.c_max ? want : cs.c_max) + 4096;    // queue D (filter survivors) never exceeds queue B
+        ctx->x_hits_cap = want;            // next launch reserves this much per segment
         return bdg_fail(ctx, BDG_E_CAPACITY, "window queue overflow: rerun the batch (workspace grown)");
     }
-    if (c[C_BADREAD] != ~0ull)
-        return bdg_fail(ctx, BDG_E_BADBASE, "read " + std::to_string(c[C_BADREAD]) + " holds a byte outside 'ACGTN'");
+    if (bad != ~0ull)
+        return bdg_fail(ctx, BDG_E_BADBASE, "read " + std::to_string(bad) + " holds a byte outside 'ACGTN'");
     return BDG_OK;
 }
 
@@ -1144,10 +1285,10 @@ int bdg_extract_counters_impl(bdg_ctx* ctx, uint64_t out[8])
 {
     memset(out, 0, sizeof(uint64_t) * 8);
     if (!ctx->x_counters.p) return BDG_OK;
-    uint64_t c[8];
-    BDG_HIP_TRY(ctx, hipMemcpyAsync(c, ctx->x_counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
-    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    out[0] = c[C_NHITS]; out[1] = c[C_NAB] & 0xFFFFFFFFull; out[2] = c[C_NAB] >> 32; out[3] = c[C_NSKIPPED];
-    out[4] = c[C_NKEPT]; out[5] = c[C_NC]; out[6] = c[C_NWINDOWS];
+    CounterSums cs;
+    int rc;
+    if ((rc = read_counters(ctx, cs))) return rc;
+    out[0] = cs.stat[S_NHITS]; out[1] = cs.a; out[2] = cs.b; out[3] = cs.stat[S_NSKIPPED];
+    out[4] = cs.stat[S_NKEPT]; out[5] = cs.c; out[6] = cs.stat[S_NWINDOWS];
     return BDG_OK;
 }
