@@ -57,8 +57,8 @@ struct bdg_ctx {
     int w_pbits = 0, w_bbits = 0;
     bool w_identity = false;
     int n16_algo = 0;
-    DevBuf n_list;       // uint32 [nq] level-2 query list
-    DevBuf n_counters;   // uint32 [4]
+    DevBuf n_list;       // uint32 [(8 + 1) * nq] level-2 query list (8 segments) + overflow list
+    DevBuf n_counters;   // one 128-byte line per list segment + one for the overflow list
 
     // ---- graph workspace (graph_kernels.hip)
     int graph_algo = 0;

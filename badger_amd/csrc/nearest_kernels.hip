@@ -149,48 +149,74 @@ __device__ __forceinline__ uint32_t hamming16(uint32_t x)
     return __popc((x | (x >> 1)) & 0x55555555u);
 }
 
+// list of the queries pass 2 must look at: LSH segments of nq slots, one counter (own 128-byte line) per segment; a block
+// reserves its slots with ONE atomic (same-address atomics complete ~11 ns apart, whoever issues them)
+constexpr int LSH = 8;
+constexpr int CTR_N3 = LSH * 32;           // uint32 index of the overflow-list counter
+constexpr size_t NCTR_BYTES = (LSH + 1) * 128;
+
 __global__ __launch_bounds__(256)
 void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t nq, PairTables pt, uint32_t max_ed,
                      uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
                      uint32_t* __restrict__ list2, uint32_t* __restrict__ counters)
 {
+    __shared__ uint32_t s_wcnt[4], s_base;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= nq) return;
-    const uint32_t qq = q[i];
-    uint32_t best = 3u, bidx = NONE_IDX, ties = 0u;
-    uint32_t lo[6], hi[6];
+    const bool on = i < nq;
+    bool need2 = false;
+    if (on) {
+        const uint32_t qq = q[i];
+        uint32_t best = 3u, bidx = NONE_IDX, ties = 0u;
+        uint32_t lo[6], hi[6];
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {                      // all six bucket bounds first: independent loads
-        const uint32_t* o = pt.off + (size_t)p * 65537u + pair_key(qq, p);
-        lo[p] = o[0]; hi[p] = o[1];
-    }
-    const size_t stride = ((size_t)pt.nw + 3) & ~size_t(3);
+        for (int p = 0; p < 6; ++p) {                      // all six bucket bounds first: independent loads
+            const uint32_t* o = pt.off + (size_t)p * 65537u + pair_key(qq, p);
+            lo[p] = o[0]; hi[p] = o[1];
+        }
+        const size_t stride = ((size_t)pt.nw + 3) & ~size_t(3);
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {
-        if (p == 1 && best == 0u) break;               // an exact match sits in table 0 and nothing can tie with it
-        const uint32_t* rk = pt.rank + (size_t)p * stride;
-        const uint32_t* ix = pt.idx + (size_t)p * stride;
-        // four ranks per 16-byte load (tables are 16-byte aligned); the caller index is fetched only for a hit
-        for (uint32_t k = lo[p] & ~3u; k < hi[p]; k += 4) {
-            const uint4 w4 = *reinterpret_cast<const uint4*>(rk + k);
-            const uint32_t wr[4] = { w4.x, w4.y, w4.z, w4.w };
+        for (int p = 0; p < 6; ++p) {
+            if (p == 1 && best == 0u) break;               // an exact match sits in table 0 and nothing can tie with it
+            const uint32_t* rk = pt.rank + (size_t)p * stride;
+            const uint32_t* ix = pt.idx + (size_t)p * stride;
+            // four ranks per 16-byte load (tables are 16-byte aligned); the caller index is fetched only for a hit
+            for (uint32_t k = lo[p] & ~3u; k < hi[p]; k += 4) {
+                const uint4 w4 = *reinterpret_cast<const uint4*>(rk + k);
+                const uint32_t wr[4] = { w4.x, w4.y, w4.z, w4.w };
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t kk = k + u;
-                const uint32_t x = qq ^ wr[u];
-                const uint32_t h = hamming16(x);
-                if (kk >= lo[p] && kk < hi[p] && h <= 2u && h <= best && canonical_pair(x) == p) {
-                    const uint32_t wo = ix[kk];
-                    if (h < best) { best = h; bidx = wo; ties = 1u; }
-                    else { ties++; bidx = wo < bidx ? wo : bidx; }
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t kk = k + u;
+                    const uint32_t x = qq ^ wr[u];
+                    const uint32_t h = hamming16(x);
+                    if (kk >= lo[p] && kk < hi[p] && h <= 2u && h <= best && canonical_pair(x) == p) {
+                        const uint32_t wo = ix[kk];
+                        if (h < best) { best = h; bidx = wo; ties = 1u; }
+                        else { ties++; bidx = wo < bidx ? wo : bidx; }
+                    }
                 }
             }
         }
+        if (best > max_ed) { best = 255u; bidx = NONE_IDX; ties = 0u; }
+        best_idx[i] = bidx; best_ed[i] = (uint8_t)(best == 3u ? 255u : best);
+        n_ties[i] = (uint16_t)(ties > 0xFFFFu ? 0xFFFFu : ties);
+        need2 = max_ed >= 2u && (best == 2u || best == 3u || best == 255u);
     }
-    if (best > max_ed) { best = 255u; bidx = NONE_IDX; ties = 0u; }
-    best_idx[i] = bidx; best_ed[i] = (uint8_t)(best == 3u ? 255u : best);
-    n_ties[i] = (uint16_t)(ties > 0xFFFFu ? 0xFFFFu : ties);
-    if (max_ed >= 2u && (best == 2u || best == 3u || best == 255u)) list2[atomicAdd(&counters[0], 1u)] = i;
+    // block-wide reservation in this block's list segment
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(need2);
+    if (lane == 0) s_wcnt[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    const uint32_t seg = blockIdx.x % LSH;
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        s_base = tot ? atomicAdd(&counters[seg * 32], tot) : 0u;
+    }
+    __syncthreads();
+    if (need2) {
+        uint32_t at = s_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wv; ++w) at += s_wcnt[w];
+        list2[(size_t)seg * nq + at] = i;
+    }
 }
 
 __device__ __forceinline__ uint32_t low_mask(int bases) { return bases >= 16 ? 0xFFFFFFFFu : ((1u << (2 * bases)) - 1u); }
@@ -209,19 +235,22 @@ void k_build_delmap(const uint32_t* __restrict__ wl, uint32_t nw, uint32_t* __re
 
 __global__ __launch_bounds__(256)
 void k_nearest_delins(const uint32_t* __restrict__ q, const uint32_t* __restrict__ list2,
-                      const uint32_t* counters, WlIndex ix, const uint32_t* __restrict__ delmap,
+                      uint32_t nq, const uint32_t* counters, WlIndex ix, const uint32_t* __restrict__ delmap,
                       uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
                       uint32_t* __restrict__ list3, uint32_t* counters_out)
 {
-    const uint32_t n2 = counters[0];
+    uint32_t n2 = 0;                                                              // virtual length: LSH * longest segment
+#pragma unroll
+    for (int k = 0; k < LSH; ++k) { const uint32_t c = counters[k * 32]; n2 = c > n2 ? c : n2; }
+    n2 *= LSH;
     const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
     const uint32_t wave_slot0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u;     // first query slot of this wave
     const uint32_t ngroups = gridDim.x * 16u;
     const unsigned long long gmask = 0xFFFFull << (16 * grp);
     for (uint32_t s0 = wave_slot0; s0 < n2; s0 += ngroups) {                      // wave-uniform loop bound
-        const uint32_t s = s0 + (uint32_t)grp;
-        const bool on = s < n2;
-        const uint32_t qi = on ? list2[s] : 0u;
+        const uint32_t s = s0 + (uint32_t)grp;                                     // entry s / LSH of segment s % LSH
+        const bool on = s < n2 && s / LSH < counters[(s % LSH) * 32];
+        const uint32_t qi = on ? list2[(size_t)(s % LSH) * nq + s / LSH] : 0u;
         const uint32_t qq = on ? q[qi] : 0u;
         // lane i of the group: deletion variant i (equal neighbours give equal variants: keep the first of a run)
         const uint32_t lm = low_mask(sub);
@@ -291,7 +320,7 @@ void k_nearest_delins(const uint32_t* __restrict__ q, const uint32_t* __restrict
             }
         }
         if (on && sub == 0) {
-            if (any_over) list3[atomicAdd(&counters_out[1], 1u)] = qi;
+            if (any_over) list3[atomicAdd(&counters_out[CTR_N3], 1u)] = qi;
             else if (add) {
                 const uint32_t cur_ed = best_ed[qi];
                 uint32_t t = add, bi = midx;
@@ -391,12 +420,12 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_
         return BDG_OK;
     }
     int rc;
-    if ((rc = bdg_reserve(ctx, ctx->n_list, sizeof(uint32_t) * 2ull * nq))) return rc;
-    if ((rc = bdg_reserve(ctx, ctx->n_counters, 16))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->n_list, sizeof(uint32_t) * (LSH + 1ull) * nq))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->n_counters, NCTR_BYTES))) return rc;
     auto* list2 = static_cast<uint32_t*>(ctx->n_list.p);
-    auto* list3 = list2 + nq;
+    auto* list3 = list2 + (size_t)LSH * nq;
     auto* counters = static_cast<uint32_t*>(ctx->n_counters.p);
-    BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 16, st));
+    BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, NCTR_BYTES, st));
     WlIndex ix{ srt, org, static_cast<const uint32_t*>(ctx->w_prefix.p), static_cast<const uint32_t*>(ctx->w_bitmap.p),
                 ctx->w_n, 32 - ctx->w_pbits, 32 - ctx->w_bbits };
     const size_t pstride = ((size_t)ctx->w_n + 3) & ~size_t(3);
@@ -412,14 +441,14 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_
         {
             ScopedKernelTimer tm(ctx, "k_nearest_delins");
             const uint32_t grid = std::min<uint32_t>((nq + 15) / 16, 256u * 8u);
-            hipLaunchKernelGGL(k_nearest_delins, dim3(grid), dim3(256), 0, st, d_q, list2, counters, ix, pt.delmap,
+            hipLaunchKernelGGL(k_nearest_delins, dim3(grid), dim3(256), 0, st, d_q, list2, nq, counters, ix, pt.delmap,
                                d_best_idx, d_best_ed, d_n_ties, list3, counters);
         }
         // queries whose hit list overflowed (one lane found more than 4 distinct entries): exhaustive
         // scan of just those; the list length stays on the device, so no host round trip
         {
             ScopedKernelTimer tm(ctx, "k_nearest_scan_overflow");
-            hipLaunchKernelGGL(k_nearest_scan, dim3(64), dim3(256), 0, st, d_q, list3, 0u, counters + 1,
+            hipLaunchKernelGGL(k_nearest_scan, dim3(64), dim3(256), 0, st, d_q, list3, 0u, counters + CTR_N3,
                                srt, org, ctx->w_n, max_ed, d_best_idx, d_best_ed, d_n_ties);
         }
     }
