@@ -96,3 +96,23 @@ static inline int bdg_fail(bdg_ctx* ctx, int code, const std::string& msg)
     if (ctx) ctx->err = msg;
     return code;
 }
+
+// ---- wave-wide data movement through DPP (gfx9 controls; behaviour on gfx950 checked by tools/ubench/dpp_check.hip) ----
+#if defined(__HIPCC__)
+// lane i <- lane i + 1; lane 63 and lanes whose source is inactive read 0
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+}
+// inclusive prefix sum over the wave, six VALU instructions (row_shr 1,2,4,8 then row_bcast 15 / 31); all lanes active
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true);
+    return x;
+}
+#endif

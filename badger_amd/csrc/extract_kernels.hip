@@ -177,7 +177,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     // 7-mer code (14 bits, base p in bits 0-1) -> bit0/1: bases p..p+5 / p+1..p+6 are an R1 6-mer, bit2/3: same for
     // the reverse complement of one.  One probe answers two positions.
     __shared__ __attribute__((aligned(16))) uint8_t s_kmer[16384];
-    __shared__ uint2 s_ent[4][WENT];     // per-wave cluster staging {(pos << 1) | strand, mask | ring slot << 16}
+    __shared__ uint2 s_ent[4][WENT];     // per-wave staging of lane-vectors with hits (see emit)
     __shared__ uint32_t s_ringr[4][32];  // read index of each ring slot
     __shared__ TaskTab s_tab[4][2];
     __shared__ int32_t s_pt[4][32][2];   // polyT of the reads of the wave's last 4 tasks (ring)
@@ -246,54 +246,73 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         }
         return vv;
     };
-    // flush the wave's staged clusters: queue A (first hit left of polyT) / queue B (single hits for the filter)
-    auto flush = [&]() {
-        if (nent == 0) return;
-        uint32_t tA = 0, tB = 0;
-        for (uint32_t h0 = 0; h0 < nent; h0 += 64) {
-            const uint32_t h = h0 + lane;
-            uint32_t a = 0, b = 0;
-            if (h < nent) {
-                const uint2 e = ent[h];
-                const int32_t pt = s_pt[wv][e.y >> 16][e.x & 1u];
-                const bool isA = pt >= 0 && (int64_t)(e.x >> 1) + KMER <= (int64_t)pt + 1;
-                a = isA ? 1u : 0u; b = isA ? 0u : __popc(e.y & 0xFFFFu);
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
-            tA += a; tB += b;
+    // Staged item: one lane-vector with hits, {forward hit mask | reverse hit mask << 16, (p0 + 16) << 5 | ring slot}.
+    // Items become queue entries 64 at a time once the polyT of their reads is known: per strand one cluster
+    // {read, (first hit << 1) | strand, offset mask}; a cluster whose first hit lies left of polyT goes to queue A
+    // (relaxed search applies), any other is split into single hits for the filter (queue B).  One packed reservation
+    // (A count | B count << 32) per call.  force_a: polyT not known yet (staging overflow), everything to queue A.
+    auto emit = [&](bool from_lds, uint2 mine, bool mine_on, uint32_t n_items, bool force_a) {
+        struct Cl { QEnt f, r; bool af, ar; uint32_t nbf, nbr; };
+        auto clusters = [&](uint32_t c) -> Cl {
+            uint2 it = mine; bool on = mine_on;
+            if (from_lds) { const uint32_t h = c * 64u + (uint32_t)lane; on = h < n_items; it = on ? ent[h] : make_uint2(0u, 0u); }
+            const uint32_t hF = on ? it.x & 0xFFFFu : 0u, hR = on ? it.x >> 16 : 0u;
+            const uint32_t ring = it.y & 31u;
+            const int32_t p0 = (int32_t)(it.y >> 5) - 16;
+            const uint32_t r = s_ringr[wv][ring];
+            const int32_t L = s_ringL[wv][ring];
+            const int32_t ptF = s_pt[wv][ring][0], ptR = s_pt[wv][ring][1];
+            Cl cl;
+            const int k0 = hF ? __builtin_ctz(hF) : 0;
+            const int32_t posF = p0 + k0;
+            cl.f = make_uint4(r, (uint32_t)posF << 1, hF >> k0, 0u);
+            cl.af = hF != 0 && (force_a || (ptF >= 0 && posF + KMER <= ptF + 1));
+            cl.nbf = (hF != 0 && !cl.af) ? __popc(hF) : 0u;
+            const int k1 = hR ? 31 - __builtin_clz(hR) : 0;
+            const int32_t posR = L - KMER - (p0 + k1);
+            cl.r = make_uint4(r, ((uint32_t)posR << 1) | 1u, __brev(hR) >> (31 - k1), 0u);
+            cl.ar = hR != 0 && (force_a || (ptR >= 0 && posR + KMER <= ptR + 1));
+            cl.nbr = (hR != 0 && !cl.ar) ? __popc(hR) : 0u;
+            return cl;
+        };
+        const uint32_t nchunk = from_lds ? (n_items + 63u) / 64u : 1u;
+        uint32_t acc = 0;
+        for (uint32_t c = 0; c < nchunk; ++c) {
+            const Cl cl = clusters(c);
+            acc += (cl.af ? 1u : 0u) + (cl.ar ? 1u : 0u) + ((cl.nbf + cl.nbr) << 16);
         }
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(acc), 63);
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(nab, (unsigned long long)tA | ((unsigned long long)tB << 32));
+        if (lane == 0) base = atomicAdd(nab, (unsigned long long)(tot & 0xFFFFu) | ((unsigned long long)(tot >> 16) << 32));
         base = __shfl(base, 0);
         unsigned long long gA = base & 0xFFFFFFFFull, gB = base >> 32;
-        for (uint32_t h0 = 0; h0 < nent; h0 += 64) {
-            const uint32_t h = h0 + lane;
-            QEnt e = make_uint4(0, 0, 0, 0);
-            bool isA = false; uint32_t nb = 0;
-            if (h < nent) {
-                const uint2 st = ent[h];
-                e = make_uint4(s_ringr[wv][st.y >> 16], st.x, st.y & 0xFFFFu, 0u);
-                const int32_t pt = s_pt[wv][st.y >> 16][st.x & 1u];
-                isA = pt >= 0 && (int64_t)(st.x >> 1) + KMER <= (int64_t)pt + 1;
-                nb = isA ? 0u : __popc(e.z);
-            }
-            const unsigned long long balA = __ballot(isA);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (isA) { const unsigned long long g = gA + (uint32_t)__popcll(balA & below); if (g < qcap) qa[g] = e; }
-            gA += (uint32_t)__popcll(balA);
-            uint32_t incl = nb;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d); if (lane >= d) incl += x; }
-            unsigned long long g = gB + incl - nb;
-            uint32_t m = nb ? e.z : 0u;
+        for (uint32_t c = 0; c < nchunk; ++c) {
+            const Cl cl = clusters(c);
+            const uint32_t mine_cnt = (cl.af ? 1u : 0u) + (cl.ar ? 1u : 0u) + ((cl.nbf + cl.nbr) << 16);
+            const uint32_t incl = wave_incl_scan(mine_cnt);
+            const uint32_t excl = incl - mine_cnt;
+            unsigned long long ga = gA + (excl & 0xFFFFu), gb = gB + (excl >> 16);
+            if (cl.af) { if (ga < qcap) qa[ga] = cl.f; ++ga; }
+            if (cl.ar) { if (ga < qcap) qa[ga] = cl.r; }
+            uint32_t m = cl.nbf ? cl.f.z : 0u;
             while (m) {
-                const int j = __builtin_ctz(m); m &= m - 1;
-                if (g < qcap) qb[g] = make_uint4(e.x, e.y + ((uint32_t)j << 1), 1u, 0u);
-                ++g;
+                const int jb = __builtin_ctz(m); m &= m - 1;
+                if (gb < qcap) qb[gb] = make_uint4(cl.f.x, cl.f.y + ((uint32_t)jb << 1), 1u, 0u);
+                ++gb;
             }
-            gB += __shfl(incl, 63);
+            m = cl.nbr ? cl.r.z : 0u;
+            while (m) {
+                const int jb = __builtin_ctz(m); m &= m - 1;
+                if (gb < qcap) qb[gb] = make_uint4(cl.r.x, cl.r.y + ((uint32_t)jb << 1), 1u, 0u);
+                ++gb;
+            }
+            const uint32_t ctot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            gA += ctot & 0xFFFFu; gB += ctot >> 16;
         }
+    };
+    auto flush = [&]() {
+        if (nent == 0) return;
+        emit(true, make_uint2(0u, 0u), false, nent, false);
         nent = 0;
     };
 
@@ -354,16 +373,11 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         for (int k = 0; k < TASK_READS; ++k) P[k] = __builtin_amdgcn_readfirstlane(tb.pend[k]);
         const uint32_t nslots = P[TASK_READS - 1];
         const uint32_t niter = (nslots + 62u) / 63u;
-        // read of a slot: boundaries at or below the step's first slot are counted on the scalar unit, only the few inside the
-        // step cost vector compares
-        auto map_j = [&](uint32_t slot_lo, uint32_t slot) -> uint32_t {
-            uint32_t js = 0;
+        // read of a slot = number of boundaries at or below it (compare + add-with-carry per boundary, P[] in scalar registers)
+        auto map_j = [&](uint32_t slot) -> uint32_t {
+            uint32_t jv = 0;
 #pragma unroll
-            for (int k = 0; k < TASK_READS - 1; ++k) js += P[k] <= slot_lo ? 1u : 0u;
-            uint32_t jv = js;
-#pragma unroll
-            for (int k = 0; k < TASK_READS - 1; ++k)
-                if (P[k] > slot_lo && P[k] <= slot_lo + 63u) jv += P[k] <= slot ? 1u : 0u;
+            for (int k = 0; k < TASK_READS - 1; ++k) jv += P[k] <= slot ? 1u : 0u;
             return jv;
         };
         const uint32_t ring0 = (tseq & 3u) * TASK_READS;
@@ -372,7 +386,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         __builtin_amdgcn_wave_barrier();
         if (!have_v) v = slot_vec(tb, (uint32_t)lane, nslots);
         have_v = false;
-        uint32_t j = map_j(0u, (uint32_t)lane);
+        uint32_t j = map_j((uint32_t)lane);
 
         for (uint32_t it = 0; it < niter; ++it) {
             const uint32_t slot_lo = it * 63u;
@@ -383,7 +397,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             const TaskTab* ptab = &tb;
             bool pvalid;
             if (it + 1 < niter) {
-                jn = pj = map_j(slot_lo + 63u, pslot);
+                jn = pj = map_j(pslot);
                 pvalid = pslot < nslots;
             } else {
                 ptab = &s_tab[wv][cur ^ 1];
@@ -441,7 +455,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 bad = nbad & rm16;
                 nN = (nN | ~rm16) & 0xFFFFu;                                     // out-of-read behaves like N
                 rm_s &= ~spread16(nN | nbad);                                    // neither T nor A
-                uint32_t N1 = __shfl_down(nN, 1);
+                uint32_t N1 = wave_shl1(nN);
                 if (!same_next) N1 = 0xFFFFu;
                 const uint32_t N32 = nN | (N1 << 16);
                 uint32_t nvm = N32 | (N32 >> 1);
@@ -453,9 +467,9 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             const uint32_t T_s = (codes >> 1) & ~codes & rm_s;
             const uint32_t A_s = ~((codes >> 1) | codes) & rm_s;
 
-            // look-ahead from the next lane (all lanes take part in the shuffles: an inactive source lane reads as 0)
-            uint32_t TA1 = __shfl_down(T_s | (A_s << 1), 1);
-            const uint32_t codes1 = __shfl_down(codes, 1);
+            // look-ahead from the next lane (one DPP move each)
+            uint32_t TA1 = wave_shl1(T_s | (A_s << 1));
+            const uint32_t codes1 = wave_shl1(codes);
             if (!same_next) TA1 = 0;
 
             // R1 6-mer hits of both strands: 8 probes of the 7-mer table, two positions each
@@ -492,33 +506,21 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             if (exact && __ballot(bad != 0 && worker)) {
                 if (bad != 0 && worker) atomicMax(&stat[S_BADREAD], ~(unsigned long long)r);
             }
-            // one cluster per lane and strand: first hit + offsets of the others
-            nhits_stat += __popc(hitF) + __popc(hitR);
-            const unsigned long long balF = __ballot(hitF != 0), balR = __ballot(hitR != 0);
-            const uint32_t total = (uint32_t)(__popcll(balF) + __popcll(balR));
-            if (total) {
-                const unsigned long long below = (1ull << lane) - 1ull;
-                const uint32_t excl = (uint32_t)(__popcll(balF & below) + __popcll(balR & below));
-                const bool fits = nent + total <= WENT;
-                unsigned long long gbase = 0;
-                if (!fits) {            // staging full (pathological reads): this step goes straight to queue A
-                    if (lane == 0) gbase = atomicAdd(nab, (unsigned long long)total) & 0xFFFFFFFFull;
-                    gbase = __shfl(gbase, 0);
+            // lanes with hits stage {masks, position, ring slot}; they become queue entries at the next flush
+            {
+                const uint32_t hw = hitF | (hitR << 16);
+                nhits_stat += __popc(hw);
+                const unsigned long long bal = __ballot(hw != 0);
+                if (bal) {
+                    const uint32_t cnt = (uint32_t)__popcll(bal);
+                    const uint2 item = make_uint2(hw, ((uint32_t)(p0 + 16) << 5) | (ring0 + j));
+                    if (nent + cnt <= WENT) {
+                        if (hw) ent[nent + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = item;
+                        nent += cnt;
+                    } else {
+                        emit(false, item, hw != 0, 0u, true);      // staging full (pathological reads): straight to queue A
+                    }
                 }
-                unsigned long long idx = (fits ? nent : gbase) + excl;
-                if (hitF) {
-                    const int k0 = __builtin_ctz(hitF);
-                    const QEnt e = make_uint4((uint32_t)r, (uint32_t)(p0 + k0) << 1, hitF >> k0, 0u);
-                    if (fits) ent[idx] = make_uint2(e.y, e.z | ((ring0 + j) << 16)); else if (idx < qcap) qa[idx] = e;
-                    ++idx;
-                }
-                if (hitR) {
-                    const int k1 = 31 - __builtin_clz(hitR);
-                    const QEnt e = make_uint4((uint32_t)r, ((uint32_t)(L - KMER - (p0 + k1)) << 1) | 1u,
-                                              __brev(hitR) >> (31 - k1), 0u);
-                    if (fits) ent[idx] = make_uint2(e.y, e.z | ((ring0 + j) << 16)); else if (idx < qcap) qa[idx] = e;
-                }
-                if (fits) nent += total;
             }
             v = vn;
             j = jn;
