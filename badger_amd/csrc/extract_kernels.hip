@@ -1007,13 +1007,13 @@ __device__ __forceinline__ uint32_t strand_byte(const uint8_t* __restrict__ rd, 
     return rd[strand ? (L - 1 - x) : x];
 }
 
-struct StrandRes { int32_t valid, polyT, r1, score, bc_start, umi_start, umi_end; };
+struct StrandRes { int32_t valid, polyT, r1, score, bc_start, umi_start, umi_end; uint32_t bc[4]; /* 16 barcode characters, strand order, forward bytes */ };
 
 __device__ StrandRes finalize_strand(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                                      uint64_t rs, int64_t L, int strand, int32_t pt,
                                      uint64_t kr, uint64_t ks, int umi_len, bool active)
 {
-    StrandRes res = { 0, pt, -1, 0, -1, -1, -1 };
+    StrandRes res = { 0, pt, -1, 0, -1, -1, -1, { 0, 0, 0, 0 } };
     bool found = false;
     int64_t r1_end = 0; int32_t r1_score = 0;
     if (active && pt != -1 && kr != 0) {                       // relaxed: min_score 9, end_delta 4
@@ -1052,23 +1052,29 @@ __device__ StrandRes finalize_strand(const uint8_t* __restrict__ bases, uint64_t
     }
     if (!found) return res;                                                        // barcode_callers.py:204-205
     if (pt != -1 && (int64_t)pt - r1_end < BC_LEN) return res;                     // :208-209
-    const uint8_t* rd = bases + rs;
+    // barcode characters and the polyT re-search window, loaded together (wide loads, one latency)
+    const int64_t barcode_start = r1_end + 1;
+    const bool research = pt == -1 || (int64_t)pt - r1_end > BC_LEN + umi_len + 10;   // :211-218
+    const int64_t presumable = r1_end + BC_LEN + umi_len;
+    const int64_t ss = presumable - 4;
+    const int64_t se = presumable + 10 < L ? presumable + 10 : L;
+    const int64_t sl = (research && ss < L && se > ss) ? se - ss : 0;
+    load_block<4>(bases, total_rounded, rs, L, strand, barcode_start, +1, res.bc);
     int64_t polyt = pt;
-    if (pt == -1 || (int64_t)pt - r1_end > BC_LEN + umi_len + 10) {                // :211-218
-        const int64_t presumable = r1_end + BC_LEN + umi_len;
-        const int64_t ss = presumable - 4;
-        const int64_t se = presumable + 10 < L ? presumable + 10 : L;
-        const int64_t sl = (ss < L && se > ss) ? se - ss : 0;
+    if (research) {
+        uint32_t w[4];
+        load_block<4>(bases, total_rounded, rs, L, strand, ss, +1, w);             // sl <= 14 characters
         polyt = -1;
         const uint32_t tchar = strand ? (uint32_t)'A' : (uint32_t)'T';
         int run = 0;
-        for (int64_t x = 0; x < sl; ++x) {          // first all-T window of 5 starting at i < sl-5
-            run = strand_byte(rd, L, strand, ss + x) == tchar ? run + 1 : 0;
+#pragma unroll
+        for (int x = 0; x < 14; ++x) {              // first all-T window of 5 starting at i < sl-5
+            const uint32_t b = (w[x >> 2] >> (8 * (x & 3))) & 0xFFu;
+            run = (x < sl && b == tchar) ? run + 1 : 0;
             const int64_t i = x - 4;
-            if (run >= 5 && i < sl - 5) { polyt = ss + i; break; }
+            if (polyt == -1 && run >= 5 && i < sl - 5) polyt = ss + i;
         }
     }
-    const int64_t barcode_start = r1_end + 1;
     const int64_t umi_start = r1_end + BC_LEN + 1;
     int64_t umi_end = polyt - 1;
     if (umi_end - umi_start <= 5) umi_end = umi_start + umi_len - 1;               // :226-227
@@ -1111,16 +1117,13 @@ void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     rec.flags = use_rev ? BDG_FLAG_REV : 0;
     rec.reserved = 0;
     if (c.valid && (int64_t)c.bc_start + BC_LEN <= L) {
-        const uint8_t* rd = bases + rs;
         uint32_t rk = 0; bool ok = true;
+#pragma unroll
         for (int i = 0; i < BC_LEN; ++i) {
-            const uint32_t b = strand_byte(rd, L, use_rev ? 1 : 0, (int64_t)c.bc_start + i);
-            uint32_t cd;
-            switch (b) {                                             // rank codes A0 C1 G2 T3 (common.py:11-14)
-            case 'A': cd = 0; break; case 'C': cd = 1; break;
-            case 'G': cd = 2; break; case 'T': cd = 3; break;
-            default: cd = 0; ok = false;
-            }
+            const uint32_t b = (c.bc[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            // rank codes A0 C1 G2 T3 (common.py:11-14); the strand's letter is the complement of a reverse-strand byte
+            uint32_t cd = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : 3u;
+            ok = ok && (b == 'A' || b == 'C' || b == 'G' || b == 'T');
             if (use_rev) cd = 3u - cd;
             rk |= cd << (2 * i);
         }
