@@ -93,21 +93,67 @@ void k_graph_sig(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t* __res
     if (i < n) sig[i] = letter_sig(ranks[i]);
 }
 
-__device__ __forceinline__ void emit_edge(uint32_t a, uint32_t b, uint32_t d, bdg_edge* out, uint64_t cap,
-                                          unsigned long long* n_edges)
+// Edge output.  Edges are staged per wave in LDS; a block reserves output slots with ONE atomic when it ends (returning
+// atomics on one address complete ~11 ns apart device-wide, so one per edge - or per wave step - would bound the kernel).
+constexpr uint32_t ECAP = 256;                   // staged edges per wave
+
+struct EdgeStage { uint32_t a[ECAP], b[ECAP]; uint8_t d[ECAP]; };
+
+__device__ __forceinline__ void edge_copy_out(const EdgeStage& st, uint32_t n, unsigned long long base, int lane,
+                                              bdg_edge* __restrict__ out, uint64_t cap)
 {
-    const unsigned long long k = atomicAdd(n_edges, 1ull);
-    if (k < cap) { out[k].a = a; out[k].b = b; out[k].dist = d; }
+    for (uint32_t i = (uint32_t)lane; i < n; i += 64u) {
+        const unsigned long long k = base + i;
+        if (k < cap) { out[k].a = st.a[i]; out[k].b = st.b[i]; out[k].dist = st.d[i]; }
+    }
+}
+// wave-wide: lanes with `want` append their edge; a full stage is written out with the wave's own reservation
+__device__ __forceinline__ void edge_push(bool want, uint32_t a, uint32_t b, uint32_t d, EdgeStage& st, uint32_t& n, int lane,
+                                          bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* n_edges)
+{
+    const unsigned long long m = __ballot(want);
+    if (!m) return;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    if (n + cnt > ECAP) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(n_edges, (unsigned long long)n);
+        base = __shfl(base, 0);
+        edge_copy_out(st, n, base, lane, out, cap);
+        n = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (want) {
+        const uint32_t at = n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        st.a[at] = a; st.b[at] = b; st.d[at] = (uint8_t)d;
+    }
+    n += cnt;
+}
+// block-wide, every thread: one reservation for the four waves' stages
+__device__ __forceinline__ void edge_finish(EdgeStage* stages, uint32_t n, uint32_t* s_cnt, unsigned long long* s_base,
+                                            bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* n_edges)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wv] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        *s_base = tot ? atomicAdd(n_edges, (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long base = *s_base;
+    for (int w = 0; w < wv; ++w) base += s_cnt[w];
+    edge_copy_out(stages[wv], n, base, lane, out, cap);
 }
 
 __device__ __forceinline__ void verify_pair(bool on, uint32_t a, uint32_t b, uint32_t thr, int32_t T,
+                                            EdgeStage& st, uint32_t& ne, int lane,
                                             bdg_edge* out, uint64_t cap, unsigned long long* n_edges)
 {
     const uint32_t d = on ? dmin3(a, b) : 99u;
     const bool close = d <= thr;
     if (__ballot(close)) {
         const bool edge = close && (int32_t)qgram_S(a, b) >= T;
-        if (edge) emit_edge(a, b, d, out, cap, n_edges);
+        edge_push(edge, a, b, d, st, ne, lane, out, cap, n_edges);
     }
 }
 
@@ -118,7 +164,11 @@ void k_graph_scan(const uint32_t* __restrict__ ranks, const uint32_t* __restrict
 {
     __shared__ uint32_t s_r[GT], s_s[GT];
     __shared__ uint32_t s_qa[4][128], s_qb[4][128];
+    __shared__ EdgeStage s_edges[4];
+    __shared__ uint32_t s_ecnt[4];
+    __shared__ unsigned long long s_ebase;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t ne = 0;
     // triangular load balance: block k takes row tile k from the front and the matching one from the back
     const uint32_t ntiles = (n + 255u) / 256u;
     const uint32_t lim = 2u * thr + 1u;
@@ -150,7 +200,7 @@ void k_graph_scan(const uint32_t* __restrict__ ranks, const uint32_t* __restrict
                         qn -= 64u;
                         const uint32_t pa = s_qa[wv][qn + lane], pb = s_qb[wv][qn + lane];
                         __builtin_amdgcn_wave_barrier();
-                        verify_pair(true, pa, pb, thr, T, out, cap, n_edges);
+                        verify_pair(true, pa, pb, thr, T, s_edges[wv], ne, lane, out, cap, n_edges);
                     }
                 }
             }
@@ -159,10 +209,11 @@ void k_graph_scan(const uint32_t* __restrict__ ranks, const uint32_t* __restrict
         if (qn) {
             const bool on = (uint32_t)lane < qn;
             const uint32_t pa = on ? s_qa[wv][lane] : 0u, pb = on ? s_qb[wv][lane] : 0u;
-            verify_pair(on, pa, pb, thr, T, out, cap, n_edges);
+            verify_pair(on, pa, pb, thr, T, s_edges[wv], ne, lane, out, cap, n_edges);
         }
         __syncthreads();
     }
+    edge_finish(s_edges, ne, s_ecnt, &s_ebase, out, cap, n_edges);
 }
 
 // ---------------------------------------------------------------------------
@@ -202,6 +253,33 @@ __device__ __forceinline__ uint32_t graph_probe_candidate(uint32_t a, int t)
     }
 }
 
+// Is t the lowest slot whose candidate equals b = graph_probe_candidate(a, t)?  (closed form of "no u < t yields b")
+//   substitutions (t < 48) are pairwise distinct and come first;
+//   any later candidate at Hamming distance 1 from a repeats a substitution;
+//   inserting c at slot sl repeats slot sl-1 iff the base before the slot is c (and only then: equal strings force c' = c
+//   and a run of c between the two slots);
+//   deleting base i repeats i-1 iff a[i] == a[i-1]; a deletion candidate also repeats an insertion candidate iff
+//   removing one base of b yields a[:15].
+__device__ __forceinline__ bool graph_probe_first(uint32_t a, uint32_t b, int t)
+{
+    if (t < 48) return true;
+    const uint32_t x = a ^ b;
+    if (__popc((x | (x >> 1)) & 0x55555555u) == 1) return false;
+    if (t < 112) {
+        const int u = t - 48, sl = u >> 2; const uint32_t c = (uint32_t)u & 3u;
+        return sl == 0 || ((a >> (2 * (sl - 1))) & 3u) != c;
+    }
+    const int i = (t - 112) >> 2;
+    if (i > 0 && (((a >> (2 * i)) ^ (a >> (2 * i - 2))) & 3u) == 0u) return false;
+    const uint32_t a15 = a & lowm(15);
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) {
+        const uint32_t lm = lowm(sl);
+        if ((((b & lm) | ((b >> 2) & ~lm)) & lowm(15)) == a15) return false;
+    }
+    return true;
+}
+
 __device__ __forceinline__ bool sorted_find(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t key)
 {
     uint32_t lo = 0, hi = n;
@@ -213,25 +291,41 @@ __device__ __forceinline__ bool sorted_find(const uint32_t* __restrict__ ranks, 
     return lo < n && ranks[lo] == key;
 }
 
+// membership bitmap over the top `32 - shift` bits of the ranks: most candidates die here on one L2 hit instead of a binary search
+__global__ __launch_bounds__(256)
+void k_graph_bitmap(const uint32_t* __restrict__ ranks, uint32_t n, int shift, uint32_t* __restrict__ bitmap)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = ranks[i] >> shift;
+    atomicOr(&bitmap[b >> 5], 1u << (b & 31u));
+}
+
 __global__ __launch_bounds__(256)
 void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, int32_t T,
+                   const uint32_t* __restrict__ bitmap, int shift,
                    bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges)
 {
+    __shared__ EdgeStage s_edges[4];
+    __shared__ uint32_t s_ecnt[4];
+    __shared__ unsigned long long s_ebase;
     // 4 lanes per barcode: lane sub-index s takes candidates s, s+4, ...
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t i = gid >> 2; const int sub = (int)(gid & 3u);
-    if (i >= n) return;
-    const uint32_t a = ranks[i];
-    for (int t = sub; t < NPROBE; t += 4) {
+    const bool on = i < n;
+    const uint32_t a = on ? ranks[i] : 0u;
+    uint32_t ne = 0;
+    for (int t = sub; t < NPROBE; t += 4) {                 // same trip count in every lane
         const uint32_t b = graph_probe_candidate(a, t);
-        if (b <= a) continue;
-        if (!sorted_find(ranks, n, b)) continue;
-        bool first = true;                       // de-duplicate: only the lowest slot producing b emits
-        for (int u = 0; u < t; ++u) if (graph_probe_candidate(a, u) == b) { first = false; break; }
-        if (!first) continue;
-        const uint32_t d = dmin3(a, b);
-        if (d <= 1u && (int32_t)qgram_S(a, b) >= T) emit_edge(a, b, d, out, cap, n_edges);
+        const uint32_t bb = b >> shift;
+        bool edge = on && b > a && ((bitmap[bb >> 5] >> (bb & 31u)) & 1u) != 0 && sorted_find(ranks, n, b);
+        if (edge) edge = graph_probe_first(a, b, t);         // de-duplicate: only the lowest slot producing b emits
+        uint32_t d = 0;
+        if (edge) { d = dmin3(a, b); edge = d <= 1u && (int32_t)qgram_S(a, b) >= T; }
+        edge_push(edge, a, b, d, s_edges[wv], ne, lane, out, cap, n_edges);
     }
+    edge_finish(s_edges, ne, s_ecnt, &s_ebase, out, cap, n_edges);
 }
 
 }  // namespace
@@ -247,15 +341,25 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
     if (qgram_T < 1) return bdg_fail(ctx, BDG_E_ARG, "qgram_T must be >= 1 (index.py:22-24 never yields less)");
     const bool probe = ctx->graph_algo == 2 || (ctx->graph_algo == 0 && thr == 1);
     if (ctx->graph_algo == 2 && thr != 1) return bdg_fail(ctx, BDG_E_ARG, "probe path needs thr == 1");
+    int rc;
     if (probe) {
+        int bbits = 16;
+        while (bbits < 27 && (1u << (bbits - 4)) < n) ++bbits;           // ~16 bits per barcode
+        const size_t bm_bytes = (size_t(1) << bbits) / 8;
+        if ((rc = bdg_reserve(ctx, ctx->g_sig, bm_bytes))) return rc;       // (the scan path's signature buffer is free here)
+        auto* bitmap = static_cast<uint32_t*>(ctx->g_sig.p);
+        BDG_HIP_TRY(ctx, hipMemsetAsync(bitmap, 0, bm_bytes, st));
+        {
+            ScopedKernelTimer tm(ctx, "k_graph_bitmap");
+            hipLaunchKernelGGL(k_graph_bitmap, dim3((n + 255) / 256), dim3(256), 0, st, d_ranks, n, 32 - bbits, bitmap);
+        }
         ScopedKernelTimer tm(ctx, "k_graph_probe");
         const uint64_t threads = 4ull * n;
         hipLaunchKernelGGL(k_graph_probe, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st, d_ranks, n, qgram_T,
-                           d_out, cap, reinterpret_cast<unsigned long long*>(d_n_edges));
+                           bitmap, 32 - bbits, d_out, cap, reinterpret_cast<unsigned long long*>(d_n_edges));
         BDG_HIP_TRY(ctx, hipGetLastError());
         return BDG_OK;
     }
-    int rc;
     if ((rc = bdg_reserve(ctx, ctx->g_sig, sizeof(uint32_t) * (size_t)n))) return rc;
     auto* sig = static_cast<uint32_t*>(ctx->g_sig.p);
     {
