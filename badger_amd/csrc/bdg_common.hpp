@@ -104,6 +104,11 @@ __device__ __forceinline__ uint32_t wave_shl1(uint32_t x)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
 }
+// lane i <- lane i - 1; lane 0 and lanes whose source is inactive read 0
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+}
 // inclusive prefix sum over the wave, six VALU instructions (row_shr 1,2,4,8 then row_bcast 15 / 31); all lanes active
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
 {

@@ -253,12 +253,36 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     // (A count | B count << 32) per call.  force_a: polyT not known yet (staging overflow), everything to queue A.
     auto emit = [&](bool from_lds, uint2 mine, bool mine_on, uint32_t n_items, bool force_a) {
         struct Cl { QEnt f, r; bool af, ar; uint32_t nbf, nbr; };
+        // Two items that are neighbouring vectors of one read and whose hits of a strand span at most 17 positions (one
+        // adapter copy cut by the vector boundary) form ONE cluster: its union window still fits the 56 columns of
+        // k_sw_clusters and one alignment serves both.  The item holding the cluster's first hit in strand order
+        // absorbs the other; an item takes part in one merge only (cond(h,h+1) && !cond(h-1,h) - a missed merge
+        // costs time, never correctness).
+        auto span_ok = [](uint2 a, uint2 b, int sh) -> bool {
+            const uint32_t ha = (a.x >> sh) & 0xFFFFu, hb = (b.x >> sh) & 0xFFFFu;
+            const uint32_t M = ha | (hb << 16);
+            return ha != 0 && hb != 0 && b.y - a.y == (16u << 5) && (31 - __builtin_clz(M)) - __builtin_ctz(M) <= 17;
+        };
         auto clusters = [&](uint32_t c) -> Cl {
             uint2 it = mine; bool on = mine_on;
             if (from_lds) { const uint32_t h = c * 64u + (uint32_t)lane; on = h < n_items; it = on ? ent[h] : make_uint2(0u, 0u); }
-            const uint32_t hF = on ? it.x & 0xFFFFu : 0u, hR = on ? it.x >> 16 : 0u;
+            uint32_t hF = on ? it.x & 0xFFFFu : 0u, hR = on ? it.x >> 16 : 0u;
             const uint32_t ring = it.y & 31u;
             const int32_t p0 = (int32_t)(it.y >> 5) - 16;
+            int32_t p0r = p0;
+            if (from_lds) {
+                // neighbours inside the 64-item chunk by DPP (a pair cut by the chunk boundary is simply not merged)
+                const uint2 nx = make_uint2(wave_shl1(it.x), wave_shl1(it.y));
+                const uint32_t cF = span_ok(it, nx, 0) ? 1u : 0u, cR = span_ok(it, nx, 16) ? 1u : 0u;     // cond(h, h+1)
+                const uint32_t cFp = wave_shr1(cF), cFp2 = wave_shr1(cFp), cRp = wave_shr1(cR), cRn = wave_shl1(cR);
+                const uint32_t xp = wave_shr1(it.x);
+                // forward strand: the earlier item leads
+                if (cFp && !cFp2) hF = 0;                                                // absorbed by h-1
+                else if (cF && !cFp) hF |= (nx.x & 0xFFFFu) << 16;                      // absorbs h+1
+                // reverse strand: the later item leads
+                if (cR && !cRn) hR = 0;                                                  // absorbed by h+1
+                else if (cRp && !cR) { hR = (xp >> 16) | (hR << 16); p0r = p0 - 16; }   // absorbs h-1
+            }
             const uint32_t r = s_ringr[wv][ring];
             const int32_t L = s_ringL[wv][ring];
             const int32_t ptF = s_pt[wv][ring][0], ptR = s_pt[wv][ring][1];
@@ -269,7 +293,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             cl.af = hF != 0 && (force_a || (ptF >= 0 && posF + KMER <= ptF + 1));
             cl.nbf = (hF != 0 && !cl.af) ? __popc(hF) : 0u;
             const int k1 = hR ? 31 - __builtin_clz(hR) : 0;
-            const int32_t posR = L - KMER - (p0 + k1);
+            const int32_t posR = L - KMER - (p0r + k1);
             cl.r = make_uint4(r, ((uint32_t)posR << 1) | 1u, __brev(hR) >> (31 - k1), 0u);
             cl.ar = hR != 0 && (force_a || (ptR >= 0 && posR + KMER <= ptR + 1));
             cl.nbr = (hR != 0 && !cl.ar) ? __popc(hR) : 0u;
@@ -873,7 +897,7 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
 // k_sw_clusters: one lane per cluster (detect_exact_positions loop body,
 // barcode_extraction/common.py:91-103, for the relaxed and the strict search at once).
 // ---------------------------------------------------------------------------
-constexpr int CW = 14;                       // 56 columns: 16 + 15 + 23 = 54 at most
+constexpr int CW = 14;                       // 56 columns: window start 16 before the first hit, hits spanning <= 17 positions, 23 after the last
 
 struct ClusterJob {
     bool active, relaxed;
