@@ -35,7 +35,7 @@ struct bdg_ctx {
     std::vector<hipEvent_t> event_pool;
 
     // ---- extraction workspace (extract_kernels.hip)
-    DevBuf x_lut;        // k-mer LUT (1 KiB) + byte-class table (2 KiB)
+    DevBuf x_lut;        // 7-mer probe table of k_scan_reads (16 KiB)
     DevBuf x_polyt;      // int32 [2n]
     DevBuf x_keys;       // uint64 [4n]  relaxed[2n] | strict[2n]
     DevBuf x_hits;       // uint64 [hits_cap]

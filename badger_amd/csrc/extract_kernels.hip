@@ -7,25 +7,24 @@
 // alignment behind align_pattern_ssw (:42-51).
 //
 // Launches per batch, no host round trip in between:
-//   k_scan_reads     one wave per read, 16 B/lane coalesced loads straight from the ASCII
-//                    buffer: polyT start of both strands (T-windows of the reverse complement
-//                    are A-windows of the read) and every R1 6-mer hit of both strands
-//                    (4096-entry 2-bit LUT in LDS).  The <=16 hits a lane finds in its vector
-//                    form one CLUSTER {read, strand, first hit, 16-bit offset mask}; clusters
-//                    are staged in LDS and flushed with one global reservation per block into
-//                    queue A (first hit left of polyT: relaxed search applies) or queue B.
-//   k_strict_filter  queue B only matters if an alignment reaches score 17, which implies
-//                    semi-global edit distance <= 5: Myers' 22-bit search per hit; survivors
-//                    join queue A as single-hit clusters.
-//   k_sw_clusters    two clusters per lane (packed 16-bit halves): ONE 22-row Smith-Waterman pass over the union of the
-//                    cluster's windows (all start at the first hit's window start, so the
-//                    first hit's strict and relaxed windows are column prefixes of the union:
-//                    their results are snapshots of the running key).  If the union cannot beat
-//                    the first hit, no later hit of the cluster can replace it as "first
-//                    strictly best" (common.py:102-103) and they are skipped; otherwise they
-//                    are re-queued (queue C) and aligned one by one by a second launch.
-//   k_finalize_reads one lane per read: delta checks, reverse pass for strict hits,
-//                    polyT re-search, barcode/UMI slicing, strand choice, 32-byte record.
+//   k_scan_reads     persistent waves take tasks of 8 reads and stream them as 16-byte vectors, 63 per step, straight from
+//                    the ASCII buffer: polyT start of both strands (T-windows of the reverse complement are A-windows of
+//                    the read) and every R1 6-mer hit of both strands (7-mer probe table in LDS).  The hits of a vector -
+//                    or of two neighbouring vectors cut through one adapter copy - form one CLUSTER
+//                    {read, (first hit << 1) | strand, offset mask}; queue A takes clusters whose first hit lies left of
+//                    polyT (relaxed search applies), queue B the other hits one by one.
+//   k_sw_clusters    queue A, two clusters per lane (packed 16-bit halves): ONE 22-row Smith-Waterman pass over the union
+//                    of the cluster's windows (all start at the first hit's window start, so the first hit's strict and
+//                    relaxed windows are column prefixes of the union: their results are snapshots of the running key).
+//                    If the union cannot beat the first hit, no later hit of the cluster can replace it as "first
+//                    strictly best" (common.py:102-103) and they are skipped; otherwise they are re-queued (queue C) and
+//                    aligned one by one by a second launch (k_sw_requeued).
+//   k_strict_filter  queue B only matters if an alignment reaches score 17, which implies semi-global edit distance <= 5:
+//                    Myers' 22-bit search per hit, after dropping read-strands the relaxed search has already decided;
+//                    survivors (queue D) are aligned by a third launch of k_sw_clusters (k_sw_survivors).
+//   k_finalize_reads one lane per read: delta checks, reverse pass for strict hits, polyT re-search, barcode/UMI
+//                    slicing, strand choice, 32-byte record.
+// Every queue and every hot counter exists NSH times (see "Counters" below).
 //
 // Integer-only; bit-exact to oracle/badger_oracle.c.
 #include "bdg_common.hpp"
@@ -133,7 +132,6 @@ constexpr int TASK_READS = 8;
 constexpr uint32_t WENT = 256;             // per-wave staging (2 KiB)
 constexpr uint32_t WFLUSH = 128;           // flush once this many clusters are staged
 constexpr int TASK_SHARDS = NSH;
-constexpr int TAB_KMER7 = 768 + 4096;      // word offset of the 7-mer table inside the device tables
 
 struct TaskTab {                           // per wave, double buffered
     uint4    rd[TASK_READS];               // per read {A lo, A hi, -B, L}: vector `slot` of the task lies at byte A + 16 * slot and
@@ -169,7 +167,7 @@ __device__ __forceinline__ uint32_t gather_even(uint32_t x)   // bit 2k -> bit k
 __global__ __launch_bounds__(256, 4)
 void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                   const uint64_t* __restrict__ off, uint32_t n,
-                  const uint32_t* __restrict__ tables,
+                  const uint8_t* __restrict__ kmer7,
                   int32_t* __restrict__ polyt,
                   QEnt* __restrict__ qa_all, QEnt* __restrict__ qb_all, uint64_t qcap /* per segment */,
                   unsigned long long* __restrict__ counters)
@@ -188,7 +186,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     const int tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        reinterpret_cast<uint4*>(s_kmer)[tid + 256 * k] = reinterpret_cast<const uint4*>(tables + TAB_KMER7)[tid + 256 * k];
+        reinterpret_cast<uint4*>(s_kmer)[tid + 256 * k] = reinterpret_cast<const uint4*>(kmer7)[tid + 256 * k];
     __syncthreads();
 
     const int lane = tid & 63, wv = tid >> 6;
@@ -1157,12 +1155,14 @@ void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     out[r] = rec;
 }
 
-// host-side tables -------------------------------------------------------------
-constexpr int TABLE_WORDS = 768 + 4096 + 4096;
-
-void build_tables(uint32_t* t /* 256 (packed 2-bit LUT, unused by the kernels) + 512 (byte classes) + 4096 (direct 6-mer table) */)
+// host-side table -------------------------------------------------------------
+// 7-mer probe table of k_scan_reads: index = 2-bit codes of 7 consecutive bases (base p in bits 0-1), entry bit 0 / 1:
+// bases p..p+5 / p+1..p+6 spell a 6-mer of R1, bit 2 / 3: the same for the reverse complement of a 6-mer of R1
+// (KmerIndexer over [R1] with k = 6, kmer_indexer.py:20-27, applied to the read and to its reverse complement).
+void build_kmer7_table(uint8_t* k7 /* [16384] */)
 {
-    memset(t, 0, sizeof(uint32_t) * TABLE_WORDS);
+    static uint8_t six[4096];                       // bit 0: forward 6-mer, bit 1: reverse-complement 6-mer
+    memset(six, 0, sizeof(six));
     auto comp = [](char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; };
     for (int q = 0; q + KMER <= R1_LEN; ++q) {
         uint32_t kf = 0, kr = 0;
@@ -1170,21 +1170,12 @@ void build_tables(uint32_t* t /* 256 (packed 2-bit LUT, unused by the kernels) +
             kf |= icode(R1[q + u]) << (2 * u);
             kr |= icode(comp(R1[q + KMER - 1 - u])) << (2 * u);
         }
-        t[kf >> 4] |= 1u << ((kf & 15u) * 2u);
-        t[kr >> 4] |= 2u << ((kr & 15u) * 2u);
-        t[768 + kf] |= 1u;
-        t[768 + kr] |= 1u << 16;
+        six[kf] |= 1u;
+        six[kr] |= 2u;
     }
-    uint8_t* k7 = reinterpret_cast<uint8_t*>(t + TAB_KMER7);
     for (uint32_t idx = 0; idx < 16384u; ++idx) {
-        const uint32_t e0 = t[768 + (idx & 4095u)], e1 = t[768 + (idx >> 2)];
-        k7[idx] = (uint8_t)((e0 & 1u) | ((e1 & 1u) << 1) | (((e0 >> 16) & 1u) << 2) | (((e1 >> 16) & 1u) << 3));
-    }
-    for (int b = 0; b < 256; ++b) {
-        const bool isA = b == 'A', isC = b == 'C', isG = b == 'G', isT = b == 'T', isN = b == 'N';
-        const bool badb = !(isA || isC || isG || isT || isN);
-        t[256 + 2 * b] = (isT ? 1u : 0u) | (isA ? 1u << 16 : 0u);
-        t[256 + 2 * b + 1] = (isN ? 1u : 0u) | (badb ? 1u << 16 : 0u);
+        const uint32_t e0 = six[idx & 4095u], e1 = six[idx >> 2];
+        k7[idx] = (uint8_t)((e0 & 1u) | ((e1 & 1u) << 1) | (((e0 >> 1) & 1u) << 2) | (((e1 >> 1) & 1u) << 3));
     }
 }
 
@@ -1201,8 +1192,8 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     if (total_bytes >= (1ull << 62)) return bdg_fail(ctx, BDG_E_ARG, "total_bytes too large");
     int rc;
     if (!ctx->x_lut.p) {
-        uint32_t t[TABLE_WORDS];
-        build_tables(t);
+        static uint8_t t[16384];
+        build_kmer7_table(t);
         if ((rc = bdg_reserve(ctx, ctx->x_lut, sizeof(t)))) return rc;
         BDG_HIP_TRY(ctx, hipMemcpy(ctx->x_lut.p, t, sizeof(t), hipMemcpyHostToDevice));
     }
@@ -1234,7 +1225,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
         if (grid > 256u * 4u) grid = 256u * 4u;                                  // persistent: 4 blocks per CU (LDS)
         grid = (grid + TASK_SHARDS - 1) / TASK_SHARDS * TASK_SHARDS;            // every shard has a block
         hipLaunchKernelGGL(k_scan_reads, dim3(grid), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
-                           static_cast<const uint32_t*>(ctx->x_lut.p), static_cast<int32_t*>(ctx->x_polyt.p),
+                           static_cast<const uint8_t*>(ctx->x_lut.p), static_cast<int32_t*>(ctx->x_polyt.p),
                            qa, qb, qcap, counters);
     }
     {
