@@ -170,7 +170,8 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                   const uint8_t* __restrict__ kmer7,
                   int32_t* __restrict__ polyt,
                   QEnt* __restrict__ qa_all, QEnt* __restrict__ qb_all, uint64_t qcap /* per segment */,
-                  unsigned long long* __restrict__ counters)
+                  unsigned long long* __restrict__ counters,
+                  unsigned long long* __restrict__ keys)
 {
     // 7-mer code (14 bits, base p in bits 0-1) -> bit0/1: bases p..p+5 / p+1..p+6 are an R1 6-mer, bit2/3: same for
     // the reverse complement of one.  One probe answers two positions.
@@ -556,7 +557,11 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             const uint32_t pk = s_ptmin[wv][ring0 + (lane >> 1)][lane & 1];
             const int32_t pv = pk == 0xFFFFFFFFu ? -1 : (int32_t)((pk >> 5) + (pk & 31u));
             s_pt[wv][ring0 + (lane >> 1)][lane & 1] = pv;
-            if ((uint32_t)lane < 2 * nr) polyt[2 * r0 + lane] = pv;
+            if ((uint32_t)lane < 2 * nr) {
+                polyt[2 * r0 + lane] = pv;
+                keys[2 * r0 + lane] = 0ull;                              // best relaxed / strict alignment of the read-strand:
+                keys[2ull * n + 2 * r0 + lane] = 0ull;                   // none yet (k_sw_clusters runs after this kernel)
+            }
         }
         __builtin_amdgcn_wave_barrier();
         ++tseq; ++since_flush;
@@ -1217,7 +1222,6 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     auto* keys = static_cast<unsigned long long*>(ctx->x_keys.p);
     const auto* pt = static_cast<const int32_t*>(ctx->x_polyt.p);
     BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, COUNTER_BYTES, st));
-    BDG_HIP_TRY(ctx, hipMemsetAsync(keys, 0, sizeof(uint64_t) * 4ull * n, st));
     {
         ScopedKernelTimer tm(ctx, "k_scan_reads");
         const uint32_t ntasks = (n + TASK_READS - 1) / TASK_READS;
@@ -1226,7 +1230,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
         grid = (grid + TASK_SHARDS - 1) / TASK_SHARDS * TASK_SHARDS;            // every shard has a block
         hipLaunchKernelGGL(k_scan_reads, dim3(grid), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
                            static_cast<const uint8_t*>(ctx->x_lut.p), static_cast<int32_t*>(ctx->x_polyt.p),
-                           qa, qb, qcap, counters);
+                           qa, qb, qcap, counters, keys);
     }
     {
         ScopedKernelTimer tm(ctx, "k_sw_clusters");
