@@ -708,6 +708,10 @@ __device__ __forceinline__ uint32_t sw_block(uint32_t (&w)[NW], int ndw, int n, 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)); }
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)); }
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b)      // v_pk_sub_u16 clamp: max(a - b, 0) per half
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
@@ -720,9 +724,13 @@ __device__ __forceinline__ uint32_t sw_block2(uint32_t (&wa)[NW], uint32_t (&wb)
                                               uint32_t& snap1, uint32_t& snap2)
 {
     constexpr uint32_t ONE2 = 0x08000800u;       // 1 << 11 in both halves
-    uint32_t hs[R1_LEN];
+    // Cells are kept as G - 1 = H in offset form, floored at 0 by the saturating subtract: every consumer of a cell (the
+    // cell to its right, below it, and diagonally below) needs exactly that, so one v_pk_sub_u16 clamp per cell replaces
+    // two subtractions and the max with 0.  (An unfloored cell only ever reaches the running key with score <= 0, where
+    // the key is never used.)
+    uint32_t hm[R1_LEN];
 #pragma unroll
-    for (int i = 0; i < R1_LEN; ++i) hs[i] = ONE2;           // H = 0
+    for (int i = 0; i < R1_LEN; ++i) hm[i] = 0u;             // H = 0
     uint32_t acc = 0, s1 = 0, s2 = 0;
 #pragma nounroll
     for (int d = 0; d < ndw; ++d) {
@@ -743,22 +751,21 @@ __device__ __forceinline__ uint32_t sw_block2(uint32_t (&wa)[NW], uint32_t (&wb)
             const uint32_t dN = WITH_N ? (((isNA && liveA) ? 0x0800u : 0u) | ((isNB && liveB) ? 0x08000000u : 0u)) : 0u;
             const uint32_t cj = (uint32_t)((63 - j) << 5) * 0x00010001u;
             uint32_t diag_t = 0u;        // (H(-1, j-1) - 1) in offset form
-            uint32_t up = ONE2;          // H(-1, j) = 0
+            uint32_t upm = 0u;           // (H(-1, j) - 1) likewise
 #pragma unroll
             for (int i = 0; i < R1_LEN; ++i) {
-                const uint32_t tl = pk_sub(hs[i], ONE2);                                 // H(i, j-1) - 1
+                const uint32_t tl = hm[i];                                               // H(i, j-1) - 1
                 const uint32_t src = i < 16 ? M0 : M1;
                 const int bitpos = i < 16 ? i : i - 16;
                 const uint32_t X = (bitpos <= 12 ? (src << (12 - bitpos)) : (src >> (bitpos - 12))) & 0x10001000u;   // 2 if match
                 uint32_t dg = pk_add(diag_t, X);                                         // H(i-1,j-1) +/- 1
                 if (WITH_N) dg = pk_add(dg, dN);
-                const uint32_t m = pk_max(pk_max(dg, tl), ONE2);                         // max(0, diag, left-1): independent of the row above
-                const uint32_t tu = pk_sub(up, ONE2);                                    // H(i-1, j) - 1
-                const uint32_t g = pk_max(m, tu);                                        // serial part: sub -> max
+                const uint32_t g = pk_max(pk_max(dg, tl), upm);                          // max(diag, left-1, up-1); the floor comes next
+                const uint32_t gm = pk_sub_sat(g, ONE2);                                 // max(H, 0) - 1 in offset form
                 diag_t = tl;
-                hs[i] = g;
-                up = g;
-                acc = pk_max(acc, g | cj | ((uint32_t)(31 - i) * 0x00010001u));
+                hm[i] = gm;
+                upm = gm;
+                acc = pk_max(acc, __builtin_amdgcn_bitop3_b32(g, cj, (uint32_t)(31 - i) * 0x00010001u, 0xFE));      // g | cj | row: one v_bitop3
             }
             const uint32_t m1 = ((j + 1 == n1A) ? 0xFFFFu : 0u) | ((j + 1 == n1B) ? 0xFFFF0000u : 0u);
             const uint32_t m2 = ((j + 1 == n2A) ? 0xFFFFu : 0u) | ((j + 1 == n2B) ? 0xFFFF0000u : 0u);
