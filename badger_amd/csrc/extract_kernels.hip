@@ -800,20 +800,31 @@ __device__ __forceinline__ uint64_t make_key(uint32_t acc, uint32_t pos)
 // occurs in the window with semi-global edit distance <= 5.  Myers' 22-bit search decides that
 // at about a tenth of the cost of the alignment; only surviving hits join queue A.
 // ---------------------------------------------------------------------------
+constexpr uint32_t code_plane(int bit)
+{
+    uint32_t m = 0;
+    for (int i = 0; i < R1_LEN; ++i) if ((icode(R1[i]) >> bit) & 1u) m |= 1u << i;
+    return m;
+}
+constexpr uint32_t R1_P0 = code_plane(0), R1_P1 = code_plane(1);
+
 __device__ __forceinline__ uint32_t myers_search(uint32_t (&w)[10], int n, uint32_t comp)
 {
+    // Only bit 21 of the vectors is ever read and carries only move upwards, so bits 22..31 are left to hold anything.
     uint32_t pv = 0x3FFFFFu, mv = 0u, score = R1_LEN, best = R1_LEN;
+    const uint32_t flip = comp ? 0x04040404u : 0u;           // complement = 2-bit code ^ 2 = ASCII bit 2
 #pragma nounroll
-    for (int d = 0; d < 10; ++d) {
-        const uint32_t cur = w[0];
+    for (int d = 0; d < 10; ++d) {                           // rolled: keeps the kernel at 8 waves per SIMD, which the gathers need
+        const uint32_t raw = w[0], cur = raw ^ flip;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int j = d * 4 + b;
-            const uint32_t c = (cur >> (8 * b)) & 0xFFu;
-            const uint32_t code = ((c >> 1) & 3u) ^ (comp << 1);
-            uint32_t eq = (code & 2u) ? ((code & 1u) ? EQ3 : EQ2) : ((code & 1u) ? EQ1 : EQ0);
-            const bool live = j < n;
-            eq = (live && c != (uint32_t)'N') ? eq : 0u;
+            // equality mask of the base against R1 from the two bit planes of R1's codes: bit i set iff both code bits agree
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)cur, 8 * b + 1, 1);      // 0 or ~0
+            const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)cur, 8 * b + 2, 1);
+            uint32_t eq = ~((R1_P1 ^ m1) | (R1_P0 ^ m0));
+            const bool use = j < n && ((raw >> (8 * b)) & 0xFFu) != (uint32_t)'N';
+            eq = use ? eq : 0u;
             const uint32_t xv = eq | mv;
             const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
             uint32_t ph = mv | ~(xh | pv);
@@ -824,7 +835,8 @@ __device__ __forceinline__ uint32_t myers_search(uint32_t (&w)[10], int n, uint3
             mh <<= 1;
             pv = mh | ~(xv | ph);
             mv = ph & xv;
-            best = (live && score < best) ? score : best;
+            // columns past the window have eq = 0, where the score cannot go down: no need to exclude them here
+            best = score < best ? score : best;
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) w[i] = w[i + 1];
