@@ -138,10 +138,14 @@ __device__ __forceinline__ uint32_t pair_key(uint32_t r, int p)
     return ((r >> (8 * bi)) & 0xFFu) | (((r >> (8 * bj)) & 0xFFu) << 8);
 }
 
+// Scan order of the six pair tables: (0,1) = table 0 and (2,3) = table 5 first.  An entry within Hamming distance 1 agrees with
+// the query on three blocks, and every three of the four blocks contain (0,1) or (2,3): after those two tables every
+// distance-0/1 entry has been seen, and a query that found one needs nothing else.
+// canonical_pair: first table, in scan order, whose two blocks agree (x = query ^ entry); an entry is counted there only.
 __device__ __forceinline__ int canonical_pair(uint32_t x)
 {
     const bool c0 = (x & 0xFFu) == 0, c1 = (x & 0xFF00u) == 0, c2 = (x & 0xFF0000u) == 0, c3 = (x & 0xFF000000u) == 0;
-    return (c0 && c1) ? 0 : (c0 && c2) ? 1 : (c0 && c3) ? 2 : (c1 && c2) ? 3 : (c1 && c3) ? 4 : 5;
+    return (c0 && c1) ? 0 : (c2 && c3) ? 5 : (c0 && c2) ? 1 : (c0 && c3) ? 2 : (c1 && c2) ? 3 : 4;
 }
 
 __device__ __forceinline__ uint32_t hamming16(uint32_t x)
@@ -167,33 +171,42 @@ void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t nq, PairTables pt,
     if (on) {
         const uint32_t qq = q[i];
         uint32_t best = 3u, bidx = NONE_IDX, ties = 0u;
-        uint32_t lo[6], hi[6];
-#pragma unroll
-        for (int p = 0; p < 6; ++p) {                      // all six bucket bounds first: independent loads
-            const uint32_t* o = pt.off + (size_t)p * 65537u + pair_key(qq, p);
-            lo[p] = o[0]; hi[p] = o[1];
-        }
         const size_t stride = ((size_t)pt.nw + 3) & ~size_t(3);
-#pragma unroll
-        for (int p = 0; p < 6; ++p) {
-            if (p == 1 && best == 0u) break;               // an exact match sits in table 0 and nothing can tie with it
+        auto bounds = [&](int p, uint32_t& lo, uint32_t& hi) {
+            const uint32_t* o = pt.off + (size_t)p * 65537u + pair_key(qq, p);
+            lo = o[0]; hi = o[1];
+        };
+        auto scan_bucket = [&](int p, uint32_t lo, uint32_t hi) {
             const uint32_t* rk = pt.rank + (size_t)p * stride;
             const uint32_t* ix = pt.idx + (size_t)p * stride;
             // four ranks per 16-byte load (tables are 16-byte aligned); the caller index is fetched only for a hit
-            for (uint32_t k = lo[p] & ~3u; k < hi[p]; k += 4) {
-                const uint4 w4 = *reinterpret_cast<const uint4*>(rk + k);
+            for (uint32_t e0 = lo & ~3u; e0 < hi; e0 += 4) {
+                const uint4 w4 = *reinterpret_cast<const uint4*>(rk + e0);
                 const uint32_t wr[4] = { w4.x, w4.y, w4.z, w4.w };
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const uint32_t kk = k + u;
+                    const uint32_t kk = e0 + u;
                     const uint32_t x = qq ^ wr[u];
                     const uint32_t h = hamming16(x);
-                    if (kk >= lo[p] && kk < hi[p] && h <= 2u && h <= best && canonical_pair(x) == p) {
+                    if (kk >= lo && kk < hi && h <= 2u && h <= best && canonical_pair(x) == p) {
                         const uint32_t wo = ix[kk];
                         if (h < best) { best = h; bidx = wo; ties = 1u; }
                         else { ties++; bidx = wo < bidx ? wo : bidx; }
                     }
                 }
+            }
+        };
+        uint32_t lo0, hi0, lo5, hi5;
+        bounds(0, lo0, hi0); bounds(5, lo5, hi5);          // both bucket bounds first: independent loads
+        scan_bucket(0, lo0, hi0);
+        if (best != 0u) {                                  // an exact match sits in table (0,1) and nothing can tie with it
+            scan_bucket(5, lo5, hi5);
+            if (best > 1u) {                               // otherwise all entries within distance 1 have been seen
+                uint32_t lo[4], hi[4];
+#pragma unroll
+                for (int p = 1; p <= 4; ++p) bounds(p, lo[p - 1], hi[p - 1]);
+#pragma unroll
+                for (int p = 1; p <= 4; ++p) scan_bucket(p, lo[p - 1], hi[p - 1]);
             }
         }
         if (best > max_ed) { best = 255u; bidx = NONE_IDX; ties = 0u; }
