@@ -50,8 +50,8 @@ struct bdg_ctx {
     DevBuf w_orig;       // uint32 [nw] caller index of sorted entry
     DevBuf w_prefix;     // uint32 [2^pbits + 1] offsets by top bits
     DevBuf w_bitmap;     // uint32 [2^bbits / 32] membership of top bbits
-    DevBuf w_poff;       // uint32 [6][65537] block-pair bucket offsets
-    DevBuf w_pent;       // uint32 [6][stride] ranks sorted by pair key, then [6][stride] caller indices
+    DevBuf w_pent;       // block-pair tables: rank blocks (w_pwords words), then caller-index blocks of the same shape
+    size_t w_pwords = 0;
     DevBuf w_delmap;     // 2^30 bits: every 15-mer deletion variant of the whitelist
     uint32_t w_n = 0;
     int w_pbits = 0, w_bbits = 0;

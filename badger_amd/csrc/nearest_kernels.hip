@@ -123,9 +123,12 @@ void k_nearest_scan(const uint32_t* __restrict__ q, const uint32_t* __restrict__
 // deletion variant with the query.  Lane i probes del(q,i) in a 2^30-bit map of all deletion
 // variants of the whitelist; only on a hit are the 64 re-insertions looked up.
 struct PairTables {
-    const uint32_t* off;     // [6][65537]
-    const uint32_t* rank;    // [6][stride] ranks sorted by pair key (stride = nw rounded up to 4: 16-byte aligned tables)
-    const uint32_t* idx;     // [6][stride] caller index of the same entry (read only on a hit)
+    // Blocks of 16 words (64 bytes, one memory sector): word 0 = entries in the block (<= 15) | next block of the bucket << 8
+    // (0 = none), words 1..15 = ranks.  Block p * 65536 + key is the head of bucket `key` of table p; longer buckets
+    // continue in blocks appended behind the 6 * 65536 heads.  `idx` has the same shape and holds the caller index of each
+    // entry (read only on a hit).  One sector per bucket probe instead of an offset pair plus the entries.
+    const uint32_t* rank;
+    const uint32_t* idx;
     const uint32_t* delmap;  // 2^30 bits
     uint32_t nw;
 };
@@ -171,42 +174,32 @@ void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t nq, PairTables pt,
     if (on) {
         const uint32_t qq = q[i];
         uint32_t best = 3u, bidx = NONE_IDX, ties = 0u;
-        const size_t stride = ((size_t)pt.nw + 3) & ~size_t(3);
-        auto bounds = [&](int p, uint32_t& lo, uint32_t& hi) {
-            const uint32_t* o = pt.off + (size_t)p * 65537u + pair_key(qq, p);
-            lo = o[0]; hi = o[1];
-        };
-        auto scan_bucket = [&](int p, uint32_t lo, uint32_t hi) {
-            const uint32_t* rk = pt.rank + (size_t)p * stride;
-            const uint32_t* ix = pt.idx + (size_t)p * stride;
-            // four ranks per 16-byte load (tables are 16-byte aligned); the caller index is fetched only for a hit
-            for (uint32_t e0 = lo & ~3u; e0 < hi; e0 += 4) {
-                const uint4 w4 = *reinterpret_cast<const uint4*>(rk + e0);
-                const uint32_t wr[4] = { w4.x, w4.y, w4.z, w4.w };
+        auto scan_bucket = [&](int p) {
+            uint32_t blk = (uint32_t)p * 65536u + pair_key(qq, p);
+            do {
+                const uint4* rb = reinterpret_cast<const uint4*>(pt.rank + (size_t)blk * 16u);
+                const uint4 q0 = rb[0], q1 = rb[1], q2 = rb[2], q3 = rb[3];          // the whole sector, four independent loads
+                const uint32_t wr[16] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
+                const uint32_t cnt = wr[0] & 0xFFu;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t kk = e0 + u;
+                for (uint32_t u = 1; u < 16; ++u) {
                     const uint32_t x = qq ^ wr[u];
                     const uint32_t h = hamming16(x);
-                    if (kk >= lo && kk < hi && h <= 2u && h <= best && canonical_pair(x) == p) {
-                        const uint32_t wo = ix[kk];
+                    if (u <= cnt && h <= 2u && h <= best && canonical_pair(x) == p) {
+                        const uint32_t wo = pt.idx[(size_t)blk * 16u + u];
                         if (h < best) { best = h; bidx = wo; ties = 1u; }
                         else { ties++; bidx = wo < bidx ? wo : bidx; }
                     }
                 }
-            }
+                blk = wr[0] >> 8;
+            } while (blk);
         };
-        uint32_t lo0, hi0, lo5, hi5;
-        bounds(0, lo0, hi0); bounds(5, lo5, hi5);          // both bucket bounds first: independent loads
-        scan_bucket(0, lo0, hi0);
+        scan_bucket(0);
         if (best != 0u) {                                  // an exact match sits in table (0,1) and nothing can tie with it
-            scan_bucket(5, lo5, hi5);
+            scan_bucket(5);
             if (best > 1u) {                               // otherwise all entries within distance 1 have been seen
-                uint32_t lo[4], hi[4];
 #pragma unroll
-                for (int p = 1; p <= 4; ++p) bounds(p, lo[p - 1], hi[p - 1]);
-#pragma unroll
-                for (int p = 1; p <= 4; ++p) scan_bucket(p, lo[p - 1], hi[p - 1]);
+                for (int p = 1; p <= 4; ++p) scan_bucket(p);
             }
         }
         if (best > max_ed) { best = 255u; bidx = NONE_IDX; ties = 0u; }
@@ -381,28 +374,33 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
     BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_bitmap.p, bitmap.data(), sizeof(uint32_t) * bitmap.size(), hipMemcpyHostToDevice));
     ctx->w_n = nw; ctx->w_pbits = pbits; ctx->w_bbits = bbits;
 
-    // six block-pair tables (counting sort by the 16-bit pair key)
-    std::vector<uint32_t> poff(6u * 65537u, 0u);
-    const size_t nwe = ((size_t)nw + 3) & ~size_t(3);          // table stride: multiple of 4, so every table starts 16-byte aligned
-    std::vector<uint32_t> prank(6ull * nwe, 0u), pidx(6ull * nwe, 0u);
+    // six block-pair tables as chains of 16-word blocks (see PairTables)
+    std::vector<uint32_t> prank(6ull * 65536ull * 16ull, 0u), pidx(6ull * 65536ull * 16ull, 0u);
     for (int p = 0; p < 6; ++p) {
         const int bi = p < 3 ? 0 : (p < 5 ? 1 : 2);
         const int bj = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
-        uint32_t* o = poff.data() + (size_t)p * 65537u;
         auto key = [&](uint32_t r) { return ((r >> (8 * bi)) & 0xFFu) | (((r >> (8 * bj)) & 0xFFu) << 8); };
-        for (uint32_t i = 0; i < nw; ++i) o[key(srt[i]) + 1]++;
-        for (uint32_t k = 0; k < 65536u; ++k) o[k + 1] += o[k];
-        std::vector<uint32_t> fill(o, o + 65536);
-        for (uint32_t i = 0; i < nw; ++i) {
-            const uint32_t at = fill[key(srt[i])]++;
-            prank[(size_t)p * nwe + at] = srt[i];
-            pidx[(size_t)p * nwe + at] = order[i];
+        std::vector<uint32_t> tail(65536);                 // block currently being filled, per bucket
+        for (uint32_t k = 0; k < 65536u; ++k) tail[k] = (uint32_t)p * 65536u + k;
+        for (uint32_t i = 0; i < nw; ++i) {                // ascending rank inside a bucket
+            const uint32_t k = key(srt[i]);
+            uint32_t blk = tail[k];
+            uint32_t cnt = prank[(size_t)blk * 16] & 0xFFu;
+            if (cnt == 15u) {                              // chain a fresh block
+                const uint32_t nb = (uint32_t)(prank.size() / 16);
+                if (nb >= (1u << 24)) return bdg_fail(ctx, BDG_E_ARG, "whitelist too large for the pair tables");
+                prank.resize(prank.size() + 16, 0u); pidx.resize(pidx.size() + 16, 0u);
+                prank[(size_t)blk * 16] |= nb << 8;
+                tail[k] = blk = nb; cnt = 0;
+            }
+            prank[(size_t)blk * 16 + 1 + cnt] = srt[i];
+            pidx[(size_t)blk * 16 + 1 + cnt] = order[i];
+            prank[(size_t)blk * 16] = (prank[(size_t)blk * 16] & ~0xFFu) | (cnt + 1u);
         }
     }
-    if ((rc = bdg_reserve(ctx, ctx->w_poff, sizeof(uint32_t) * poff.size()))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->w_pent, sizeof(uint32_t) * (prank.size() + pidx.size())))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->w_delmap, size_t(1) << 27))) return rc;          // 2^30 bits
-    BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_poff.p, poff.data(), sizeof(uint32_t) * poff.size(), hipMemcpyHostToDevice));
+    ctx->w_pwords = prank.size();
     BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_pent.p, prank.data(), sizeof(uint32_t) * prank.size(), hipMemcpyHostToDevice));
     BDG_HIP_TRY(ctx, hipMemcpy(static_cast<uint32_t*>(ctx->w_pent.p) + prank.size(), pidx.data(), sizeof(uint32_t) * pidx.size(), hipMemcpyHostToDevice));
     BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->w_delmap.p, 0, size_t(1) << 27, ctx->stream));
@@ -441,9 +439,7 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_
     BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, NCTR_BYTES, st));
     WlIndex ix{ srt, org, static_cast<const uint32_t*>(ctx->w_prefix.p), static_cast<const uint32_t*>(ctx->w_bitmap.p),
                 ctx->w_n, 32 - ctx->w_pbits, 32 - ctx->w_bbits };
-    const size_t pstride = ((size_t)ctx->w_n + 3) & ~size_t(3);
-    PairTables pt{ static_cast<const uint32_t*>(ctx->w_poff.p), static_cast<const uint32_t*>(ctx->w_pent.p),
-                   static_cast<const uint32_t*>(ctx->w_pent.p) + 6 * pstride,
+    PairTables pt{ static_cast<const uint32_t*>(ctx->w_pent.p), static_cast<const uint32_t*>(ctx->w_pent.p) + ctx->w_pwords,
                    static_cast<const uint32_t*>(ctx->w_delmap.p), ctx->w_n };
     {
         ScopedKernelTimer tm(ctx, "k_nearest_pairs");
