@@ -30,7 +30,7 @@ EXPORTS = [
     "bdg_profile_enable", "bdg_profile_reset", "bdg_profile_read",
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_set_algo",
-    "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
+    "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
 ]
 
 
@@ -83,6 +83,7 @@ def load():
     L.bdg_nearest16_set_algo.argtypes = [vp, C.c_int]
     L.bdg_graph_edges.argtypes = [vp, vp, u32, u32, i32, vp, u64, C.POINTER(u64)]
     L.bdg_graph_edges_dev.argtypes = [vp, vp, u32, u32, i32, vp, u64, vp]
+    L.bdg_graph_edges_rows_dev.argtypes = [vp, vp, u32, u32, u32, u32, i32, vp, u64, vp]
     L.bdg_graph_set_algo.argtypes = [vp, C.c_int]
     L.bdg_distinct_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     for name in EXPORTS:
@@ -207,6 +208,11 @@ class Context:
     def graph_edges_dev(self, d_ranks, n, thr, qgram_T, d_out, cap, d_n_edges):
         self._check(self.lib.bdg_graph_edges_dev(self.h, d_ranks.data_ptr(), n, thr, qgram_T,
                                                  d_out.data_ptr(), cap, d_n_edges.data_ptr()))
+
+    def graph_edges_rows_dev(self, d_ranks, n, row_begin, row_end, thr, qgram_T, d_out, cap, d_n_edges):
+        """edges whose smaller rank is row row_begin <= i < row_end of the sorted array (one GPU's share)"""
+        self._check(self.lib.bdg_graph_edges_rows_dev(self.h, d_ranks.data_ptr(), n, row_begin, row_end, thr, qgram_T,
+                                                      d_out.data_ptr(), cap, d_n_edges.data_ptr()))
 
     def graph_set_algo(self, algo):
         self._check(self.lib.bdg_graph_set_algo(self.h, algo))

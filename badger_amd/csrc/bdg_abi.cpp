@@ -11,7 +11,7 @@ int bdg_extract_status_impl(bdg_ctx*, uint64_t*, uint64_t*);
 int bdg_extract_counters_impl(bdg_ctx*, uint64_t*);
 int bdg_whitelist_load_impl(bdg_ctx*, const uint32_t*, uint32_t);
 int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
-int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*);
+int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*);
 int bdg_distinct_launch(bdg_ctx*, const bdg_extract_rec*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 
 static thread_local std::string g_err_noctx;
@@ -290,7 +290,17 @@ int bdg_graph_edges_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint3
     if (!ctx) return BDG_E_ARG;
     if (!d_n_edges || (n && !d_ranks) || (cap && !d_out)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return bdg_graph_launch(ctx, d_ranks, n, thr, qgram_T, d_out, cap, d_n_edges);
+    return bdg_graph_launch(ctx, d_ranks, n, 0u, n, thr, qgram_T, d_out, cap, d_n_edges);
+}
+
+int bdg_graph_edges_rows_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t row_begin, uint32_t row_end,
+                             uint32_t thr, int32_t qgram_T, bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (!d_n_edges || (n && !d_ranks) || (cap && !d_out)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    if (row_begin > row_end || row_end > n) return bdg_fail(ctx, BDG_E_ARG, "row block outside [0, n]");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bdg_graph_launch(ctx, d_ranks, n, row_begin, row_end, thr, qgram_T, d_out, cap, d_n_edges);
 }
 
 int bdg_graph_edges(bdg_ctx* ctx, const uint32_t* ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
@@ -314,7 +324,7 @@ int bdg_graph_edges(bdg_ctx* ctx, const uint32_t* ranks, uint32_t n, uint32_t th
     std::vector<bdg_edge> all;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = bdg_reserve(ctx, ctx->g_tmp1, sizeof(bdg_edge) * dcap))) return rc;
-        rc = bdg_graph_launch(ctx, static_cast<const uint32_t*>(ctx->g_tmp0.p), n, thr, qgram_T,
+        rc = bdg_graph_launch(ctx, static_cast<const uint32_t*>(ctx->g_tmp0.p), n, 0u, n, thr, qgram_T,
                               static_cast<bdg_edge*>(ctx->g_tmp1.p), dcap, static_cast<uint64_t*>(ctx->g_cnt.p));
         if (rc) return rc;
         uint64_t total = 0;

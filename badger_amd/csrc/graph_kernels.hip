@@ -159,6 +159,7 @@ __device__ __forceinline__ void verify_pair(bool on, uint32_t a, uint32_t b, uin
 
 __global__ __launch_bounds__(256)
 void k_graph_scan(const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ sig, uint32_t n,
+                  uint32_t row_begin, uint32_t row_end,
                   uint32_t thr, int32_t T, bdg_edge* __restrict__ out, uint64_t cap,
                   unsigned long long* __restrict__ n_edges)
 {
@@ -170,14 +171,14 @@ void k_graph_scan(const uint32_t* __restrict__ ranks, const uint32_t* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t ne = 0;
     // triangular load balance: block k takes row tile k from the front and the matching one from the back
-    const uint32_t ntiles = (n + 255u) / 256u;
+    const uint32_t tile0 = row_begin / 256u, ntiles = (row_end + 255u) / 256u;      // row tiles [tile0, ntiles) of this block of rows
     const uint32_t lim = 2u * thr + 1u;
     for (uint32_t pass = 0; pass < 2; ++pass) {
-        const uint32_t tile = pass == 0 ? blockIdx.x : ntiles - 1u - blockIdx.x;
-        if (pass == 1 && tile <= blockIdx.x) break;          // middle tile handled once
+        const uint32_t tile = pass == 0 ? tile0 + blockIdx.x : ntiles - 1u - blockIdx.x;
+        if (pass == 1 && tile <= tile0 + blockIdx.x) break;  // middle tile handled once
         if (tile >= ntiles) break;
         const uint32_t i = tile * 256u + tid;
-        const bool row = i < n;
+        const bool row = i >= row_begin && i < row_end;
         const uint32_t a = row ? ranks[i] : 0u, sa = row ? sig[i] : 0u;
         uint32_t qn = 0;
         for (uint32_t j0 = tile * 256u; j0 < n; j0 += GT) {
@@ -302,7 +303,7 @@ void k_graph_bitmap(const uint32_t* __restrict__ ranks, uint32_t n, int shift, u
 }
 
 __global__ __launch_bounds__(256)
-void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, int32_t T,
+void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_begin, uint32_t row_end, int32_t T,
                    const uint32_t* __restrict__ bitmap, int shift,
                    bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges)
 {
@@ -312,8 +313,8 @@ void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, int32_t T,
     // 4 lanes per barcode: lane sub-index s takes candidates s, s+4, ...
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t i = gid >> 2; const int sub = (int)(gid & 3u);
-    const bool on = i < n;
+    const uint32_t i = row_begin + (gid >> 2); const int sub = (int)(gid & 3u);
+    const bool on = i < row_end;
     const uint32_t a = on ? ranks[i] : 0u;
     uint32_t ne = 0;
     for (int t = sub; t < NPROBE; t += 4) {                 // same trip count in every lane
@@ -331,12 +332,12 @@ void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, int32_t T,
 }  // namespace
 
 // ---------------------------------------------------------------------------
-int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
-                     bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges)
+int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t row_begin, uint32_t row_end,
+                     uint32_t thr, int32_t qgram_T, bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges)
 {
     hipStream_t st = ctx->stream;
     BDG_HIP_TRY(ctx, hipMemsetAsync(d_n_edges, 0, 8, st));
-    if (n < 2) return BDG_OK;
+    if (n < 2 || row_begin >= row_end) return BDG_OK;
     if (thr > 16) return bdg_fail(ctx, BDG_E_ARG, "thr must be <= 16");
     if (qgram_T < 1) return bdg_fail(ctx, BDG_E_ARG, "qgram_T must be >= 1 (index.py:22-24 never yields less)");
     const bool probe = ctx->graph_algo == 2 || (ctx->graph_algo == 0 && thr == 1);
@@ -354,8 +355,8 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             hipLaunchKernelGGL(k_graph_bitmap, dim3((n + 255) / 256), dim3(256), 0, st, d_ranks, n, 32 - bbits, bitmap);
         }
         ScopedKernelTimer tm(ctx, "k_graph_probe");
-        const uint64_t threads = 4ull * n;
-        hipLaunchKernelGGL(k_graph_probe, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st, d_ranks, n, qgram_T,
+        const uint64_t threads = 4ull * (row_end - row_begin);
+        hipLaunchKernelGGL(k_graph_probe, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st, d_ranks, n, row_begin, row_end, qgram_T,
                            bitmap, 32 - bbits, d_out, cap, reinterpret_cast<unsigned long long*>(d_n_edges));
         BDG_HIP_TRY(ctx, hipGetLastError());
         return BDG_OK;
@@ -368,8 +369,8 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
     }
     {
         ScopedKernelTimer tm(ctx, "k_graph_scan");
-        const uint32_t ntiles = (n + 255u) / 256u;
-        hipLaunchKernelGGL(k_graph_scan, dim3((ntiles + 1) / 2), dim3(256), 0, st, d_ranks, sig, n, thr, qgram_T,
+        const uint32_t ntiles = (row_end + 255u) / 256u - row_begin / 256u;
+        hipLaunchKernelGGL(k_graph_scan, dim3((ntiles + 1) / 2), dim3(256), 0, st, d_ranks, sig, n, row_begin, row_end, thr, qgram_T,
                            d_out, cap, reinterpret_cast<unsigned long long*>(d_n_edges));
     }
     BDG_HIP_TRY(ctx, hipGetLastError());

@@ -1,6 +1,7 @@
 """One process per GPU.  Reads partition independently, so the data path needs no
 collective: each rank takes a contiguous range of reads, the whitelist is replicated, and
-results are concatenated in rank order.  torch.distributed (RCCL on the GPU box, gloo on CPU)
+results are concatenated in rank order.  Graph rows shard the same way (every rank holds the whole
+sorted rank array and emits the edges whose smaller rank lies in its block of rows).  torch.distributed (RCCL on the GPU box, gloo on CPU)
 is used only for the barrier, the max-over-ranks clock and the final gather of records."""
 import os
 import time
@@ -79,3 +80,33 @@ def extract_sharded(extract_fn, bases, off, umi_len=12):
     if rank != 0:
         return None
     return np.concatenate([np.frombuffer(b, dtype=mine.dtype) for b in gathered])
+
+
+def graph_row_blocks(n, world, balance="rows"):
+    """Row blocks [lo, hi) of the sorted rank array, one per rank.  balance="rows": equal rows
+    (neighbourhood probes: the work per row is constant); "pairs": equal numbers of (i, j > i) pairs, i.e.
+    boundaries at n * (1 - sqrt(1 - g / world)) (all-pairs sweep: row i meets n - 1 - i partners)."""
+    if balance == "rows":
+        return [partition(n, world, r) for r in range(world)]
+    cuts = [int(round(n * (1.0 - (1.0 - g / world) ** 0.5))) for g in range(world)] + [n]
+    cuts = [min(max(c, 0), n) for c in cuts]
+    for g in range(1, world + 1):
+        cuts[g] = max(cuts[g], cuts[g - 1])
+    return [(cuts[g], cuts[g + 1]) for g in range(world)]
+
+
+def graph_edges_sharded(edges_fn, ranks_sorted, thr, qgram_T, balance="rows"):
+    """Run edges_fn(ranks_sorted, row_lo, row_hi, thr, qgram_T) -> structured edge array on this rank's row block
+    and return, on rank 0, all edges sorted by (a, b) (None elsewhere).  No collective on the data path: the gather
+    of the edge lists is the only exchange."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    lo, hi = graph_row_blocks(len(ranks_sorted), world, balance)[rank]
+    mine = edges_fn(ranks_sorted, lo, hi, thr, qgram_T)
+    if world > 1:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine.tobytes(), gathered, dst=0)
+        if rank != 0:
+            return None
+        mine = np.concatenate([np.frombuffer(b, dtype=mine.dtype) for b in gathered])
+    return mine[np.lexsort((mine["b"], mine["a"]))]

@@ -148,6 +148,12 @@ int  bdg_graph_edges(bdg_ctx* ctx, const uint32_t* ranks, uint32_t n, uint32_t t
  * unsorted; *d_n_edges (device, 8 bytes) receives the total.  Asynchronous. */
 int  bdg_graph_edges_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
                          bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges);
+/* Row block of the same computation, for sharding over GPUs (the reference splits the rows over
+ * processes the same way, barcode_graph.py:177-190 compare_chunk): only edges (a, b), a < b, whose smaller rank a is
+ * d_ranks[i] with row_begin <= i < row_end are produced.  The row blocks of a partition of [0, n) give disjoint edge
+ * lists whose union is the full list. */
+int  bdg_graph_edges_rows_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t row_begin, uint32_t row_end,
+                              uint32_t thr, int32_t qgram_T, bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges);
 int  bdg_graph_set_algo(bdg_ctx* ctx, int algo);   /* 0 auto, 1 all-pairs scan, 2 neighbourhood probes (thr=1) */
 /* Distinct-barcode counting of a batch on the device (BarcodeGraph.index_bc_single_thread,
  * barcode_graph.py:192-204): from n extraction records, the distinct barcodes of records with a

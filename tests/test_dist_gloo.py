@@ -26,9 +26,24 @@ def _worker(rank, world, port, q):
     b, o = bases.numpy(), off.numpy().astype(np.uint64)
     recs = bdist.extract_sharded(lambda bb, oo, u: orc.extract_batch(bb, oo, u, threads=1), b, o, 12)
     t = bdist.timed(lambda: time.sleep(0.05 * (rank + 1)), 2)
+    # graph rows: every rank holds all ranks and emits the edges whose smaller rank lies in its row block
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 1 << 32, 40, dtype=np.uint64)
+    near = base[rng.integers(0, 40, 400)] ^ (rng.integers(1, 4, 400).astype(np.uint64) << (2 * rng.integers(0, 16, 400).astype(np.uint64)))
+    ranks = np.unique(np.concatenate([base, near]).astype(np.uint32))
+
+    def rows_fn(rs, lo, hi, thr, T):
+        e = orc.graph_edges(rs, thr, T)
+        keep = (e["a"] >= rs[lo]) & (e["a"] <= rs[hi - 1]) if hi > lo else np.zeros(len(e), bool)
+        return e[keep]
+
+    edges = bdist.graph_edges_sharded(rows_fn, ranks, 1, 5, balance="pairs")
     if rank == 0:
         whole = orc.extract_batch(b, o, 12, threads=1)
-        q.put((bool((recs == whole).all()), len(recs), t))
+        all_edges = orc.graph_edges(ranks, 1, 5)
+        all_edges = all_edges[np.lexsort((all_edges["b"], all_edges["a"]))]
+        graph_ok = len(edges) == len(all_edges) and bool((edges == all_edges).all()) and len(edges) > 50
+        q.put((bool((recs == whole).all()) and graph_ok, len(recs), t))
     bdist.barrier()
 
 
@@ -39,6 +54,19 @@ def test_partition_covers_everything():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
+
+
+def test_graph_row_blocks_cover_everything():
+    for n in (0, 1, 2, 255, 256, 1000, 500000):
+        for w in (1, 2, 3, 8):
+            for balance in ("rows", "pairs"):
+                blocks = bdist.graph_row_blocks(n, w, balance)
+                assert blocks[0][0] == 0 and blocks[-1][1] == n and len(blocks) == w
+                assert all(blocks[i][1] == blocks[i + 1][0] and blocks[i][0] <= blocks[i][1] for i in range(w - 1))
+    # equal pairs: the row blocks grow towards the end, the pair counts stay within a few percent
+    n, w = 500000, 8
+    pairs = [sum(n - 1 - i for i in (lo, hi - 1)) * (hi - lo) / 2 for lo, hi in bdist.graph_row_blocks(n, w, "pairs")]
+    assert max(pairs) / min(pairs) < 1.02
 
 
 def test_world2_gloo_sharded_extract_and_clock():

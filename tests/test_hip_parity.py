@@ -244,6 +244,42 @@ def test_graph_vs_oracle(ctx, orc, algo, thr):
     ctx.graph_set_algo(0)
 
 
+@pytest.mark.parametrize("algo,thr", [(2, 1), (1, 1), (1, 2)])
+def test_graph_row_blocks_partition_the_edges(ctx, orc, algo, thr):
+    """a GPU owns a block of rows of the sorted rank array and emits the edges whose smaller rank lies in
+    it; the blocks of any partition give disjoint lists whose union is the full list (blocks cut inside 256-row tiles,
+    empty blocks and one-row blocks included)."""
+    import torch
+    from badger_amd import dist as bdist
+    ranks = _observed_barcodes(300, 9000, 33)
+    n = len(ranks)
+    T = orc.qgram_threshold(thr)
+    want = orc.graph_edges(ranks, thr, T, threads=8)
+    want = want[np.lexsort((want["b"], want["a"]))]
+    d_ranks = torch.from_numpy(ranks.view(np.int32)).cuda()
+    cap = 4 * n + 1024
+    d_out = torch.zeros((cap, 3), dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ctx.graph_set_algo(algo)
+    cuts = [(0, 0), (0, 1), (1, 300), (300, 1000), (1000, 1000), (1000, n)]
+    for blocks in (cuts, bdist.graph_row_blocks(n, 3, "pairs"), bdist.graph_row_blocks(n, 8, "rows")):
+        got = []
+        for lo, hi in blocks:
+            ctx.graph_edges_rows_dev(d_ranks, n, lo, hi, thr, T, d_out, cap, d_cnt)
+            ctx.synchronize()
+            k = int(d_cnt[0])
+            assert k <= cap
+            e = d_out[:k].cpu().numpy().view(np.uint32)
+            if k:
+                assert (e[:, 0] >= ranks[lo]).all() and (e[:, 0] <= ranks[hi - 1]).all() and (e[:, 0] < e[:, 1]).all()
+            got.append(e)
+        e = np.concatenate(got)
+        e = e[np.lexsort((e[:, 1], e[:, 0]))]
+        assert len(e) == len(want) and len(e) > 100
+        assert (e[:, 0] == want["a"]).all() and (e[:, 1] == want["b"]).all() and (e[:, 2] == want["dist"]).all()
+    ctx.graph_set_algo(0)
+
+
 def test_graph_edge_cases(ctx):
     assert len(ctx.graph_edges(np.zeros(0, np.uint32), 1, 5)) == 0
     assert len(ctx.graph_edges(np.array([7], np.uint32), 1, 5)) == 0
