@@ -148,6 +148,14 @@ __device__ __forceinline__ uint32_t find_read(const TaskTab& t, uint32_t slot)
     return j;
 }
 
+// 16 bytes of the read stream, non-temporal: every byte is used once
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream16(const uint8_t* p)
+{
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ uint32_t spread16(uint32_t x)      // bit k -> bit 2k
 {
     x = (x | (x << 8)) & 0x00FF00FFu;
@@ -235,7 +243,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     auto vec_at = [&](const TaskTab& tb, uint32_t j, uint32_t slot) -> uint4 {
         const uint2 a = *reinterpret_cast<const uint2*>(&tb.rd[j]);
         const uint64_t g0 = (((uint64_t)a.y << 32) | a.x) + 16ull * slot;
-        return *reinterpret_cast<const uint4*>(bases + g0);
+        return ld_stream16(bases + g0);
     };
     auto slot_vec = [&](const TaskTab& tb, uint32_t slot, uint32_t nslots) -> uint4 {
         uint4 vv = make_uint4(0, 0, 0, 0);
@@ -431,7 +439,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             }
             const uint2 pa = *reinterpret_cast<const uint2*>(&ptab->rd[pj]);
             const uint64_t pg = pvalid ? (((uint64_t)pa.y << 32) | pa.x) + 16ull * pslot : 0ull;
-            const uint4 vn = *reinterpret_cast<const uint4*>(bases + pg);
+            const uint4 vn = ld_stream16(bases + pg);      // streamed once: keep it out of the caches the gathers of the later kernels live in
             const bool act = slot < nslots;
             const uint4 rd = tb.rd[j];
             const int32_t L = act ? (int32_t)rd.w : 0;

@@ -2,7 +2,7 @@
 """Headline benchmark: barcode calls/s against the 737K-entry whitelist (BASELINE.json).
 
 One step = one pass of the hot path over one device-resident batch of synthetic ONT reads:
-  K1 extract (k_scan_reads, k_sw_windows, k_finalize_reads)  -> 32-byte record per read
+  K1 extract (k_scan_reads, k_sw_clusters x3, k_strict_filter, k_finalize_reads)  -> 32-byte record per read
   K2 nearest16 (probe path, max_ed 2) of every extracted barcode against the whitelist
 A "call" is one read taken through both.  Reads are sharded per GPU (weak scaling, no
 collective on the data path); the process group is only used for the barrier and the
@@ -123,20 +123,33 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n / (elapsed / args.steps)
         # roofline of the dominant kernel: algorithmic bytes of the unit it serves / its own launch time
-        k1 = ("k_scan_reads", "k_sw_windows", "k_finalize_reads")
+        k1 = ("k_scan_reads", "k_sw_clusters", "k_sw_requeued", "k_sw_survivors", "k_strict_filter", "k_finalize_reads")
         per_launch_ms = {k: v[1] / max(1, v[0]) for k, v in prof.items()}
         dom = max(per_launch_ms, key=per_launch_ms.get)
         k1_bytes = total_bytes + 40 * n                # sum(L_i) + 8 (offset) + 32 (record) per read
         k2_bytes = 11 * n + 4 * len(wl)                # 4 (query) + 7 (idx, ed, ties) per call + whitelist once
         alg = k1_bytes if dom in k1 else k2_bytes
         achieved = alg / (per_launch_ms[dom] * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(dom)
-            except Exception:
-                traffic = None
+        # from the committed rocprofv3 PMC passes (tools/pmc_profile.sh -> tools/summarize_profile.py): HBM bytes and
+        # vector instructions of one launch of that kernel
+        traffic, valu = None, None
+        for name in ("traffic.json", "valu.json"):
+            f = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(f):
+                try:
+                    v = json.load(open(f)).get(dom)
+                except Exception:
+                    v = None
+                if name == "traffic.json":
+                    traffic = v
+                else:
+                    valu = v
+        # the path is integer-issue bound, so say how close the kernel is to THAT ceiling:
+        # 1024 SIMDs, one wave64 VALU instruction per 4 clocks each, at the 2.4 GHz peak clock
+        issue_peak = 1024 * 2.4e9 / 4.0
+        int_issue = None if valu is None else {"valu_insts_per_launch": valu, "achieved": valu / (per_launch_ms[dom] * 1e-3),
+                                               "peak": issue_peak, "unit": "wave-instr/s",
+                                               "frac": valu / (per_launch_ms[dom] * 1e-3) / issue_peak}
         line = {
             "metric": "barcode calls/sec vs 737K 10x whitelist", "value": value, "unit": "calls/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -148,7 +161,7 @@ def main():
                        "parallelism": "reads sharded per GPU, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": per_launch_ms[dom]},
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": per_launch_ms[dom], "int_issue": int_issue},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(per_launch_ms.items())},
         }
         if not args.no_cpu_baseline:

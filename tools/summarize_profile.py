@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Condense a tools/pmc_profile.sh output directory into profiles/<tag>_summary.json and
-profiles/traffic.json (HBM bytes per launch per kernel, what bench.py reports as roofline.traffic).
+profiles/traffic.json (HBM bytes per launch per kernel, what bench.py reports as roofline.traffic) and
+profiles/valu.json (vector instructions per launch, bench.py's roofline.int_issue).
 
 HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE counts 128-byte requests as 64 bytes for wide coalesced streaming reads, so it is
@@ -51,6 +52,8 @@ for k, s in summary.items():
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(summary, open(os.path.join(ROOT, "profiles", tag + "_summary.json"), "w"), indent=1, sort_keys=True)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
+json.dump({k: s["SQ_INSTS_VALU"] for k, s in summary.items() if "SQ_INSTS_VALU" in s},
+          open(os.path.join(ROOT, "profiles", "valu.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(summary):
     s = summary[k]
     print("%-26s avg %8.1f us  VALU %6.1fM  hbm %s" % (k, s.get("avg_ns", 0) / 1e3, s.get("SQ_INSTS_VALU", 0) / 1e6,
