@@ -165,14 +165,15 @@ constexpr size_t NCTR_BYTES = (LSH + 1) * 128;
 __global__ __launch_bounds__(256)
 void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t nq, PairTables pt, uint32_t max_ed,
                      uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
-                     uint32_t* __restrict__ list2, uint32_t* __restrict__ counters)
+                     uint2* __restrict__ list2, uint32_t* __restrict__ counters)
 {
     __shared__ uint32_t s_wcnt[4], s_base;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const bool on = i < nq;
     bool need2 = false;
+    uint32_t qq = 0;
     if (on) {
-        const uint32_t qq = q[i];
+        qq = q[i];
         uint32_t best = 3u, bidx = NONE_IDX, ties = 0u;
         auto scan_bucket = [&](int p) {
             uint32_t blk = (uint32_t)p * 65536u + pair_key(qq, p);
@@ -221,7 +222,7 @@ void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t nq, PairTables pt,
     if (need2) {
         uint32_t at = s_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         for (int w = 0; w < wv; ++w) at += s_wcnt[w];
-        list2[(size_t)seg * nq + at] = i;
+        list2[(size_t)seg * nq + at] = make_uint2(i, qq);                 // pass 2 gets the query with its index: one load less on its chain
     }
 }
 
@@ -240,7 +241,7 @@ void k_build_delmap(const uint32_t* __restrict__ wl, uint32_t nw, uint32_t* __re
 }
 
 __global__ __launch_bounds__(256)
-void k_nearest_delins(const uint32_t* __restrict__ q, const uint32_t* __restrict__ list2,
+void k_nearest_delins(const uint2* __restrict__ list2,
                       uint32_t nq, const uint32_t* counters, WlIndex ix, const uint32_t* __restrict__ delmap,
                       uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
                       uint32_t* __restrict__ list3, uint32_t* counters_out)
@@ -251,18 +252,31 @@ void k_nearest_delins(const uint32_t* __restrict__ q, const uint32_t* __restrict
     n2 *= LSH;
     const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
     const uint32_t wave_slot0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u;     // first query slot of this wave
-    const uint32_t ngroups = gridDim.x * 16u;
+    const uint32_t ngroups = gridDim.x * 16u;                                     // a multiple of LSH: a group stays in its segment
     const unsigned long long gmask = 0xFFFFull << (16 * grp);
+    const uint32_t seg = (wave_slot0 + (uint32_t)grp) % LSH;
+    const uint32_t seg_cnt = counters[seg * 32];
+    const uint2* seg_list = list2 + (size_t)seg * nq;
+    const uint32_t lm = low_mask(sub);
+    // Two loads lead to a group's answer before any look-up: its list entry {index, query} and the deletion-map word of
+    // its variant.  They are issued two and one iterations ahead, so an iteration starts with both in registers.
+    auto fetch = [&](uint32_t s0) -> uint2 {                                      // entry s / LSH of segment s % LSH
+        const uint32_t s = s0 + (uint32_t)grp;
+        return (s < n2 && s / LSH < seg_cnt) ? seg_list[s / LSH] : make_uint2(NONE_IDX, 0u);
+    };
+    auto variant = [&](uint32_t qq) -> uint32_t { return ((qq & lm) | ((qq >> 2) & ~lm)) & 0x3FFFFFFFu; };   // lane i: deletion variant i
+    uint2 e1 = fetch(wave_slot0), e2 = fetch(wave_slot0 + ngroups);
+    uint32_t w1 = e1.x != NONE_IDX ? delmap[variant(e1.y) >> 5] : 0u;
     for (uint32_t s0 = wave_slot0; s0 < n2; s0 += ngroups) {                      // wave-uniform loop bound
-        const uint32_t s = s0 + (uint32_t)grp;                                     // entry s / LSH of segment s % LSH
-        const bool on = s < n2 && s / LSH < counters[(s % LSH) * 32];
-        const uint32_t qi = on ? list2[(size_t)(s % LSH) * nq + s / LSH] : 0u;
-        const uint32_t qq = on ? q[qi] : 0u;
-        // lane i of the group: deletion variant i (equal neighbours give equal variants: keep the first of a run)
-        const uint32_t lm = low_mask(sub);
-        const uint32_t d = ((qq & lm) | ((qq >> 2) & ~lm)) & 0x3FFFFFFFu;
+        const uint32_t qi = e1.x, qq = e1.y, dword = w1;
+        const bool on = qi != NONE_IDX;
+        e1 = e2;
+        w1 = e1.x != NONE_IDX ? delmap[variant(e1.y) >> 5] : 0u;
+        e2 = fetch(s0 + 2u * ngroups);
+        const uint32_t d = variant(qq);
+        // equal neighbours give equal variants: keep the first of a run
         const bool dup_del = sub > 0 && (((qq >> (2 * sub)) ^ (qq >> (2 * sub - 2))) & 3u) == 0u;
-        const bool hit = on && !dup_del && ((delmap[d >> 5] >> (d & 31u)) & 1u);
+        const bool hit = on && !dup_del && ((dword >> (d & 31u)) & 1u);
         unsigned long long pend = __ballot(hit);
         uint32_t found[4] = { 0, 0, 0, 0 }; int nf = 0; bool overflow = false;
         // each variant that occurs in the whitelist: the group's 16 lanes take one insertion slot each, 4 letters
@@ -431,10 +445,10 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_
         return BDG_OK;
     }
     int rc;
-    if ((rc = bdg_reserve(ctx, ctx->n_list, sizeof(uint32_t) * (LSH + 1ull) * nq))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->n_list, sizeof(uint32_t) * (2ull * LSH + 1ull) * nq))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->n_counters, NCTR_BYTES))) return rc;
-    auto* list2 = static_cast<uint32_t*>(ctx->n_list.p);
-    auto* list3 = list2 + (size_t)LSH * nq;
+    auto* list2 = static_cast<uint2*>(ctx->n_list.p);                          // LSH segments of nq {index, query} entries
+    auto* list3 = reinterpret_cast<uint32_t*>(list2 + (size_t)LSH * nq);       // overflow list, nq indices
     auto* counters = static_cast<uint32_t*>(ctx->n_counters.p);
     BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, NCTR_BYTES, st));
     WlIndex ix{ srt, org, static_cast<const uint32_t*>(ctx->w_prefix.p), static_cast<const uint32_t*>(ctx->w_bitmap.p),
@@ -450,7 +464,7 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_
         {
             ScopedKernelTimer tm(ctx, "k_nearest_delins");
             const uint32_t grid = std::min<uint32_t>((nq + 15) / 16, 256u * 8u);
-            hipLaunchKernelGGL(k_nearest_delins, dim3(grid), dim3(256), 0, st, d_q, list2, nq, counters, ix, pt.delmap,
+            hipLaunchKernelGGL(k_nearest_delins, dim3(grid), dim3(256), 0, st, list2, nq, counters, ix, pt.delmap,
                                d_best_idx, d_best_ed, d_n_ties, list3, counters);
         }
         // queries whose hit list overflowed (one lane found more than 4 distinct entries): exhaustive
