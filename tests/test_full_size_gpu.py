@@ -1,6 +1,7 @@
 """BASELINE-size runs on the GPU, checked through size-independent properties and oracle samples
 (the oracle cannot finish the full sizes in seconds): config 2 (1M reads vs the 737,280-entry
-whitelist) and config 3 (graph at thr 1 over 500K distinct barcodes)."""
+whitelist), config 3 (graph at thr 1 over 500K distinct barcodes) and one GPU's share of config 5
+(4.9M-entry whitelist, thr 2 graph from row blocks)."""
 import numpy as np
 import pytest
 import torch
@@ -180,3 +181,74 @@ def test_config2_distinct_on_device_matches_host_counting(world):
     # first-occurrence order of the reference's counts dict
     order = np.argsort(first[:nu].cpu().numpy(), kind="stable")
     assert (np.diff(first[:nu].cpu().numpy()[order]) > 0).all()
+
+
+def test_config5_visium_scale_whitelist_and_thr2_graph(world):
+    """BASELINE config 5 on one GPU's share: nearest16 against a 4.9M-entry whitelist (pair-table buckets are chains of
+    several blocks there, the deletion map is 7 % full) and the thr = 2 graph (all-pairs sweep with the lossy q-gram
+    statistic) built from row blocks the way 8 GPUs would split it."""
+    from badger_amd import dist as bdist
+    orc, dev, recs = world["orc"], world["dev"], world["recs"]
+    rng = np.random.default_rng(55)
+    wl = synth.make_whitelist(4900000)
+    ctx = _native.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.whitelist_load(wl)
+    # queries: whitelist entries as they are, with 1-3 substitutions, with a deletion (tail shifts in), and random 16-mers
+    nq = 200000
+    src = wl[rng.integers(0, len(wl), nq)].astype(np.uint64)
+    kind = rng.integers(0, 5, nq)
+    q = src.copy()
+    for rounds, sel in ((1, kind == 1), (2, kind == 2), (3, kind == 3)):
+        for _ in range(rounds):
+            q = np.where(sel, q ^ (rng.integers(1, 4, nq).astype(np.uint64) << (2 * rng.integers(0, 16, nq).astype(np.uint64))), q)
+    pos = rng.integers(0, 16, nq).astype(np.uint64)
+    low = (np.uint64(1) << (np.uint64(2) * pos)) - np.uint64(1)
+    dele = (q & low) | ((q >> np.uint64(2)) & ~low & np.uint64(0x3FFFFFFF)) | (rng.integers(0, 4, nq).astype(np.uint64) << np.uint64(30))
+    q = np.where(kind == 4, dele, q)
+    q = np.where(rng.random(nq) < 0.1, rng.integers(0, 1 << 32, nq, dtype=np.uint64), q).astype(np.uint32)
+    d_q = torch.from_numpy(q.view(np.int32)).to(dev)
+    bi = torch.zeros(nq, dtype=torch.int32, device=dev)
+    be = torch.zeros(nq, dtype=torch.uint8, device=dev)
+    bt = torch.zeros(nq, dtype=torch.int16, device=dev)
+    ctx.nearest16_dev(d_q, nq, 2, bi, be, bt)
+    torch.cuda.synchronize()
+    idx, ed, ties = bi.cpu().numpy().view(np.uint32), be.cpu().numpy(), bt.cpu().numpy().view(np.uint16)
+    hit = ed != 255
+    assert hit.mean() > 0.9 and (ed[hit] <= 2).all()        # the radius-2 ball (~2,100 strings) times 4.9M entries covers the space ~2.4 times
+    assert ((idx == 0xFFFFFFFF) == ~hit).all()
+    assert (wl[idx[ed == 0]] == q[ed == 0]).all() and (ed[kind == 0][q[kind == 0] == src[kind == 0].astype(np.uint32)] == 0).all()
+    # the exhaustive device path on a sample, the oracle on a smaller one
+    sel = rng.integers(0, nq, 512)
+    ctx.nearest16_set_algo(1)
+    ctx.nearest16_dev(torch.from_numpy(q[sel].view(np.int32)).to(dev), 512, 2, bi, be, bt)
+    torch.cuda.synchronize()
+    assert (bi[:512].cpu().numpy().view(np.uint32) == idx[sel]).all() and (be[:512].cpu().numpy() == ed[sel]).all()
+    assert (bt[:512].cpu().numpy().view(np.uint16) == ties[sel]).all()
+    ctx.nearest16_set_algo(0)
+    wi, we, wt = orc.nearest16(q[sel[:12]], wl, 2, threads=8)
+    assert (wi == idx[sel[:12]]).all() and (we == ed[sel[:12]]).all() and (wt == ties[sel[:12]]).all()
+
+    # thr = 2 graph over 60K observed barcodes: row blocks (equal pair counts, as 8 GPUs would take them) == one call
+    ranks = np.unique(recs["bc_rank"][(recs["flags"] & 2) != 0])[:60000]
+    n, T = len(ranks), orc.qgram_threshold(2)
+    whole = ctx.graph_edges(ranks, 2, T)
+    assert len(whole) > 10000 and (whole["dist"] <= 2).all() and (whole["a"] < whole["b"]).all()
+    d_ranks = torch.from_numpy(ranks.view(np.int32)).to(dev)
+    cap = len(whole) + 1024
+    d_out = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    parts = []
+    for lo, hi in bdist.graph_row_blocks(n, 8, "pairs"):
+        ctx.graph_edges_rows_dev(d_ranks, n, lo, hi, 2, T, d_out, cap, d_cnt)
+        torch.cuda.synchronize()
+        parts.append(d_out[:int(d_cnt[0])].cpu().numpy().view(np.uint32).copy())
+    e = np.concatenate(parts)
+    e = e[np.lexsort((e[:, 1], e[:, 0]))]
+    assert len(e) == len(whole) and (e[:, 0] == whole["a"]).all() and (e[:, 1] == whole["b"]).all() and (e[:, 2] == whole["dist"]).all()
+    # the edge condition depends on the pair only: the oracle's graph of a subset == the full graph restricted to it
+    sub = np.sort(ranks[rng.permutation(n)[:6000]])
+    want = orc.graph_edges(sub, 2, T, threads=8)
+    keep = np.isin(whole["a"], sub) & np.isin(whole["b"], sub)
+    got = whole[keep]
+    assert len(got) == len(want) and (got == want).all()
