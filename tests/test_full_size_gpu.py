@@ -1,7 +1,7 @@
 """BASELINE-size runs on the GPU, checked through size-independent properties and oracle samples
 (the oracle cannot finish the full sizes in seconds): config 2 (1M reads vs the 737,280-entry
 whitelist), config 3 (graph at thr 1 over 500K distinct barcodes) and one GPU's share of config 5
-(4.9M-entry whitelist, thr 2 graph from row blocks)."""
+(4.9M-entry whitelist, thr 2 graph from row blocks) and of config 4 (12.5M reads in one batch)."""
 import numpy as np
 import pytest
 import torch
@@ -252,3 +252,42 @@ def test_config5_visium_scale_whitelist_and_thr2_graph(world):
     keep = np.isin(whole["a"], sub) & np.isin(whole["b"], sub)
     got = whole[keep]
     assert len(got) == len(want) and (got == want).all()
+
+
+def test_config4_one_gpu_share_of_100m_reads():
+    """BASELINE config 4: 100M reads over 8 GPUs = 12.5M reads (12.6 GB of bases) per GPU in ONE batch.  Records of
+    sampled ranges must equal what the same reads give when extracted alone (no dependence on batch size, queue
+    segment or task placement) and what the oracle gives."""
+    from oracle import pyoracle as orc
+    dev = torch.device("cuda", 0)
+    n = 12500000
+    wl = synth.make_whitelist(N_WL)
+    bases, off = synth.make_reads(n, wl, seed=4, device=dev)
+    total = int(off[-1])
+    assert total > 12 * 10 ** 9
+    bases = torch.cat([bases, torch.zeros(64, dtype=torch.uint8, device=dev)])
+    off = off.contiguous()
+    ctx = _native.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    recs = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    for _ in range(2):
+        ctx.extract_batch_dev(bases, off, n, total, 12, recs)
+        rc, bad, nwin = ctx.extract_status()
+        if rc != _native.E_CAPACITY:
+            break
+    assert rc == 0 and nwin > n
+    valid = recs[:, 6].contiguous().view(torch.uint8).reshape(-1, 4)[:, 2]          # byte 26 of the record
+    assert 0.98 < float(valid.float().mean()) < 1.0
+    small = torch.zeros((4000, 8), dtype=torch.int32, device=dev)
+    for lo in (0, 6249000, n - 4000):
+        sub_off = off[lo:lo + 4001].contiguous()
+        ctx.extract_batch_dev(bases, sub_off, 4000, total, 12, small)
+        rc, _, _ = ctx.extract_status()
+        assert rc == 0
+        assert bool((small == recs[lo:lo + 4000]).all())
+        b0, b1 = int(sub_off[0]), int(sub_off[-1])
+        hb = bases[b0:b1].cpu().numpy()
+        ho = (sub_off.cpu().numpy() - b0).astype(np.uint64)
+        want = orc.extract_batch(hb, ho[:1001], 12, threads=8)
+        got = small[:1000].cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+        assert (got == want).all()
