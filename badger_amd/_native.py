@@ -29,7 +29,7 @@ EXPORTS = [
     "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_set_stream", "bdg_synchronize",
     "bdg_profile_enable", "bdg_profile_reset", "bdg_profile_read",
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters",
-    "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_set_algo",
+    "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
 ]
 
@@ -80,6 +80,7 @@ def load():
     L.bdg_nearest16.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp, vp]
     L.bdg_whitelist_load.argtypes = [vp, vp, u32]
     L.bdg_nearest16_dev.argtypes = [vp, vp, u32, u32, vp, vp, vp]
+    L.bdg_nearest16_recs_dev.argtypes = [vp, vp, u32, u32, vp, vp, vp]
     L.bdg_nearest16_set_algo.argtypes = [vp, C.c_int]
     L.bdg_graph_edges.argtypes = [vp, vp, u32, u32, i32, vp, u64, C.POINTER(u64)]
     L.bdg_graph_edges_dev.argtypes = [vp, vp, u32, u32, i32, vp, u64, vp]
@@ -186,6 +187,11 @@ class Context:
     def nearest16_dev(self, d_q, nq, max_ed, d_idx, d_ed, d_ties):
         self._check(self.lib.bdg_nearest16_dev(self.h, d_q.data_ptr(), nq, max_ed, d_idx.data_ptr(),
                                                d_ed.data_ptr(), d_ties.data_ptr()))
+
+    def nearest16_recs_dev(self, d_recs, n, max_ed, d_idx, d_ed, d_ties):
+        """nearest16 of every record's barcode (records without a 16-base ACGT barcode report no hit)"""
+        self._check(self.lib.bdg_nearest16_recs_dev(self.h, d_recs.data_ptr(), n, max_ed, d_idx.data_ptr(),
+                                                    d_ed.data_ptr(), d_ties.data_ptr()))
 
     def nearest16_set_algo(self, algo):
         self._check(self.lib.bdg_nearest16_set_algo(self.h, algo))

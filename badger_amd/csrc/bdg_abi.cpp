@@ -2,6 +2,8 @@
 // wrappers (H2D, launch, D2H) and the device-resident entry points.
 #include "bdg_common.hpp"
 
+#include <cstddef>
+
 #include <algorithm>
 #include <mutex>
 
@@ -10,7 +12,7 @@ int bdg_extract_launch(bdg_ctx*, const uint8_t*, const uint64_t*, uint32_t, uint
 int bdg_extract_status_impl(bdg_ctx*, uint64_t*, uint64_t*);
 int bdg_extract_counters_impl(bdg_ctx*, uint64_t*);
 int bdg_whitelist_load_impl(bdg_ctx*, const uint32_t*, uint32_t);
-int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
+int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, int, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
 int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*);
 int bdg_distinct_launch(bdg_ctx*, const bdg_extract_rec*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 
@@ -243,7 +245,18 @@ int bdg_nearest16_dev(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t m
     if (!ctx) return BDG_E_ARG;
     if (nq && (!d_q || !d_best_idx || !d_best_ed || !d_n_ties)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return bdg_nearest16_launch(ctx, d_q, nq, max_ed, d_best_idx, d_best_ed, d_n_ties);
+    return bdg_nearest16_launch(ctx, d_q, 1u, 0, nq, max_ed, d_best_idx, d_best_ed, d_n_ties);
+}
+
+int bdg_nearest16_recs_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n, uint32_t max_ed,
+                           uint32_t* d_best_idx, uint8_t* d_best_ed, uint16_t* d_n_ties)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (n && (!d_recs || !d_best_idx || !d_best_ed || !d_n_ties)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    static_assert(sizeof(bdg_extract_rec) == 32 && offsetof(bdg_extract_rec, bc_rank) == 20 && offsetof(bdg_extract_rec, flags) == 27,
+                  "record layout the strided query reads");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bdg_nearest16_launch(ctx, reinterpret_cast<const uint32_t*>(d_recs) + 5, 8u, 1, n, max_ed, d_best_idx, d_best_ed, d_n_ties);
 }
 
 int bdg_nearest16(bdg_ctx* ctx, const uint32_t* q, uint32_t nq, const uint32_t* wl, uint32_t nw,
@@ -267,7 +280,7 @@ int bdg_nearest16(bdg_ctx* ctx, const uint32_t* q, uint32_t nq, const uint32_t* 
     auto* d_ties = reinterpret_cast<uint16_t*>(d_idx + nq);
     auto* d_ed = reinterpret_cast<uint8_t*>(d_ties + nq);
     BDG_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_in0.p, q, bq, hipMemcpyHostToDevice, st));
-    rc = bdg_nearest16_launch(ctx, static_cast<const uint32_t*>(ctx->s_in0.p), nq, max_ed, d_idx, d_ed, d_ties);
+    rc = bdg_nearest16_launch(ctx, static_cast<const uint32_t*>(ctx->s_in0.p), 1u, 0, nq, max_ed, d_idx, d_ed, d_ties);
     if (rc) return rc;
     BDG_HIP_TRY(ctx, hipMemcpyAsync(best_idx, d_idx, bq, hipMemcpyDeviceToHost, st));
     BDG_HIP_TRY(ctx, hipMemcpyAsync(n_ties, d_ties, sizeof(uint16_t) * (size_t)nq, hipMemcpyDeviceToHost, st));

@@ -51,7 +51,8 @@ __device__ __forceinline__ bool wl_lookup(const WlIndex& ix, uint32_t key, uint3
 constexpr int SCAN_TILE = 4096;
 
 __global__ __launch_bounds__(256)
-void k_nearest_scan(const uint32_t* __restrict__ q, const uint32_t* __restrict__ qlist, uint32_t nq_host,
+void k_nearest_scan(const uint32_t* __restrict__ q, uint32_t qstride, int recs,
+                    const uint32_t* __restrict__ qlist, uint32_t nq_host,
                     const uint32_t* __restrict__ d_nq,
                     const uint32_t* __restrict__ wl_sorted, const uint32_t* __restrict__ wl_orig, uint32_t nw,
                     uint32_t max_ed, uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed,
@@ -63,8 +64,11 @@ void k_nearest_scan(const uint32_t* __restrict__ q, const uint32_t* __restrict__
   for (uint32_t slot0 = blockIdx.x * 256u; slot0 < nq; slot0 += gridDim.x * 256u) {
     const uint32_t slot = slot0 + threadIdx.x;
     const bool active = slot < nq;
+    // queries: a plain array (qstride 1) or the bc_rank field of extraction records (qstride 8 words; a record whose
+    // barcode is not 16 ACGT bases has no query and reports "nothing within max_ed")
     const uint32_t qi = active ? (qlist ? qlist[slot] : slot) : 0u;
-    const uint32_t qq = active ? q[qi] : 0u;
+    const uint32_t qq = active ? q[(size_t)qi * qstride] : 0u;
+    const bool usable = !recs || !active || ((q[(size_t)qi * qstride + 1] >> 24) & BDG_FLAG_RANK_OK) != 0;
     uint32_t peq[4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -104,7 +108,7 @@ void k_nearest_scan(const uint32_t* __restrict__ q, const uint32_t* __restrict__
         }
     }
     if (active) {
-        if (best > max_ed) { best = 255u; bidx = NONE_IDX; ties = 0u; }
+        if (best > max_ed || !usable) { best = 255u; bidx = NONE_IDX; ties = 0u; }
         best_idx[qi] = bidx; best_ed[qi] = (uint8_t)best; n_ties[qi] = (uint16_t)(ties > 0xFFFFu ? 0xFFFFu : ties);
     }
   }
@@ -163,7 +167,7 @@ constexpr int CTR_N3 = LSH * 32;           // uint32 index of the overflow-list 
 constexpr size_t NCTR_BYTES = (LSH + 1) * 128;
 
 __global__ __launch_bounds__(256)
-void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t nq, PairTables pt, uint32_t max_ed,
+void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t qstride, int recs, uint32_t nq, PairTables pt, uint32_t max_ed,
                      uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
                      uint2* __restrict__ list2, uint32_t* __restrict__ counters)
 {
@@ -172,8 +176,13 @@ void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t nq, PairTables pt,
     const bool on = i < nq;
     bool need2 = false;
     uint32_t qq = 0;
+    bool usable = on;
     if (on) {
-        qq = q[i];
+        qq = q[(size_t)i * qstride];
+        if (recs) usable = ((q[(size_t)i * qstride + 1] >> 24) & BDG_FLAG_RANK_OK) != 0;      // flags byte of the record
+    }
+    if (on && !usable) { best_idx[i] = NONE_IDX; best_ed[i] = 255; n_ties[i] = 0; }
+    if (usable) {
         uint32_t best = 3u, bidx = NONE_IDX, ties = 0u;
         auto scan_bucket = [&](int p) {
             uint32_t blk = (uint32_t)p * 65536u + pair_key(qq, p);
@@ -427,7 +436,7 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
     return BDG_OK;
 }
 
-int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t max_ed,
+int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t qstride, int recs, uint32_t nq, uint32_t max_ed,
                          uint32_t* d_best_idx, uint8_t* d_best_ed, uint16_t* d_n_ties)
 {
     if (nq == 0) return BDG_OK;
@@ -439,7 +448,7 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_
     if (ctx->n16_algo == 2 && max_ed > 2) return bdg_fail(ctx, BDG_E_ARG, "probe path needs max_ed <= 2");
     if (!probe) {
         ScopedKernelTimer tm(ctx, "k_nearest_scan");
-        hipLaunchKernelGGL(k_nearest_scan, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, (const uint32_t*)nullptr, nq,
+        hipLaunchKernelGGL(k_nearest_scan, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, qstride, recs, (const uint32_t*)nullptr, nq,
                            (const uint32_t*)nullptr, srt, org, ctx->w_n, max_ed, d_best_idx, d_best_ed, d_n_ties);
         BDG_HIP_TRY(ctx, hipGetLastError());
         return BDG_OK;
@@ -457,7 +466,7 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_
                    static_cast<const uint32_t*>(ctx->w_delmap.p), ctx->w_n };
     {
         ScopedKernelTimer tm(ctx, "k_nearest_pairs");
-        hipLaunchKernelGGL(k_nearest_pairs, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, nq, pt, max_ed,
+        hipLaunchKernelGGL(k_nearest_pairs, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, qstride, recs, nq, pt, max_ed,
                            d_best_idx, d_best_ed, d_n_ties, list2, counters);
     }
     if (max_ed >= 2) {
@@ -471,7 +480,7 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_
         // scan of just those; the list length stays on the device, so no host round trip
         {
             ScopedKernelTimer tm(ctx, "k_nearest_scan_overflow");
-            hipLaunchKernelGGL(k_nearest_scan, dim3(64), dim3(256), 0, st, d_q, list3, 0u, counters + CTR_N3,
+            hipLaunchKernelGGL(k_nearest_scan, dim3(64), dim3(256), 0, st, d_q, qstride, recs, list3, 0u, counters + CTR_N3,
                                srt, org, ctx->w_n, max_ed, d_best_idx, d_best_ed, d_n_ties);
         }
     }

@@ -133,6 +133,11 @@ int  bdg_nearest16(bdg_ctx* ctx, const uint32_t* q, uint32_t nq, const uint32_t*
 int  bdg_whitelist_load(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw);
 int  bdg_nearest16_dev(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t max_ed,
                        uint32_t* d_best_idx, uint8_t* d_best_ed, uint16_t* d_n_ties);
+/* The same for the barcodes of a batch of extraction records, straight from bdg_extract_batch_dev's output (query i =
+ * d_recs[i].bc_rank): the per-read step of the pipeline without a gather in between.  A record without
+ * BDG_FLAG_RANK_OK (invalid read, or a barcode holding N) reports idx 0xFFFFFFFF, ed 255, ties 0. */
+int  bdg_nearest16_recs_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n, uint32_t max_ed,
+                            uint32_t* d_best_idx, uint8_t* d_best_ed, uint16_t* d_n_ties);
 /* algorithm: 0 = automatic, 1 = force the exhaustive Myers scan, 2 = force the
  * neighbourhood-probe path (max_ed <= 2 only). Results are identical. */
 int  bdg_nearest16_set_algo(bdg_ctx* ctx, int algo);

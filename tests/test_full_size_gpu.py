@@ -98,6 +98,18 @@ def test_config2_nearest_properties_and_samples(world):
     assert (wl[idx[ed == 0]] == qh[ed == 0]).all()                                    # distance 0 is membership
     x = wl[idx[ed == 1]] ^ qh[ed == 1]
     assert (np.array([bin(int((v | (v >> 1)) & 0x55555555)).count("1") for v in x[:20000]]) == 1).all()   # distance 1 = one substitution
+    # the record-strided entry point (what bench.py calls): same answers for usable barcodes, "no hit" for the others
+    d_recs = torch.from_numpy(recs.view(np.int32).reshape(-1, 8).copy()).to(dev)
+    ri = torch.zeros(N_READS, dtype=torch.int32, device=dev)
+    re = torch.zeros(N_READS, dtype=torch.uint8, device=dev)
+    rt = torch.zeros(N_READS, dtype=torch.int16, device=dev)
+    ctx.nearest16_recs_dev(d_recs, N_READS, 2, ri, re, rt)
+    torch.cuda.synchronize()
+    usable = (recs["flags"] & 2) != 0
+    assert 0.95 < usable.mean() < 1.0
+    r_idx, r_ed, r_ties = ri.cpu().numpy().astype(np.uint32), re.cpu().numpy(), rt.cpu().numpy().astype(np.uint16)
+    assert (r_idx[usable] == idx[usable]).all() and (r_ed[usable] == ed[usable]).all() and (r_ties[usable] == ties[usable]).all()
+    assert (r_idx[~usable] == 0xFFFFFFFF).all() and (r_ed[~usable] == 255).all() and (r_ties[~usable] == 0).all()
     # idempotence: a whitelist entry calls itself
     ctx.nearest16_dev(torch.from_numpy(wl[:100000].astype(np.int64)).to(dev).to(torch.int32), 100000, 2, bi, be, bt)
     torch.cuda.synchronize()
