@@ -112,7 +112,7 @@ void bdg_free(bdg_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = { &ctx->x_lut, &ctx->x_polyt, &ctx->x_keys, &ctx->x_hits, &ctx->x_counters, &ctx->s_in0,
-                       &ctx->s_in1, &ctx->s_out0, &ctx->w_sorted, &ctx->w_orig, &ctx->w_prefix, &ctx->w_bitmap, &ctx->w_pent, &ctx->w_delmap,
+                       &ctx->s_in1, &ctx->s_out0, &ctx->w_sorted, &ctx->w_orig, &ctx->w_prefix, &ctx->w_bitmap, &ctx->w_pent, &ctx->w_delmap, &ctx->w_dv,
                        &ctx->n_list, &ctx->n_counters, &ctx->g_sig, &ctx->g_tmp0, &ctx->g_tmp1, &ctx->g_cnt };
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& t : ctx->timers) for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

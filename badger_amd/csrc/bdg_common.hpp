@@ -53,6 +53,7 @@ struct bdg_ctx {
     DevBuf w_pent;       // block-pair tables: rank blocks (w_pwords words), then caller-index blocks of the same shape
     size_t w_pwords = 0;
     DevBuf w_delmap;     // 2^30 bits: every 15-mer deletion variant of the whitelist
+    DevBuf w_dv;         // the same variants as (variant, sorted-whitelist position) pairs sorted by variant, + directory
     uint32_t w_n = 0;
     int w_pbits = 0, w_bbits = 0;
     bool w_identity = false;

@@ -16,6 +16,8 @@
 //          is exhaustive.
 #include "bdg_common.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <numeric>
 
@@ -237,8 +239,16 @@ void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t qstride, int recs,
 
 __device__ __forceinline__ uint32_t low_mask(int bases) { return bases >= 16 ? 0xFFFFFFFFu : ((1u << (2 * bases)) - 1u); }
 
+// Deletion variants of the whitelist, twice: as a 2^30-bit membership map (the cheap first question) and as (variant, entry)
+// pairs to be sorted by variant (the second: WHICH entries own a variant).  Deleting a base inside a run of equal bases
+// gives the same variant as deleting its left neighbour: only the first of a run is emitted (key 0xFFFFFFFF sorts the
+// others to the end).
+constexpr int DV_DIR_SHIFT = 8;                          // directory over the top 22 of the 30 variant bits
+constexpr uint32_t DV_DIR_N = 1u << (30 - DV_DIR_SHIFT);
+
 __global__ __launch_bounds__(256)
-void k_build_delmap(const uint32_t* __restrict__ wl, uint32_t nw, uint32_t* __restrict__ delmap)
+void k_build_delmap(const uint32_t* __restrict__ wl, uint32_t nw, uint32_t* __restrict__ delmap,
+                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ dir)
 {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t w = g >> 4; const int i = (int)(g & 15u);
@@ -246,12 +256,19 @@ void k_build_delmap(const uint32_t* __restrict__ wl, uint32_t nw, uint32_t* __re
     const uint32_t r = wl[w];
     const uint32_t lm = low_mask(i);
     const uint32_t d = ((r & lm) | ((r >> 2) & ~lm)) & 0x3FFFFFFFu;
-    atomicOr(&delmap[d >> 5], 1u << (d & 31u));
+    const bool dup = i > 0 && (((r >> (2 * i)) ^ (r >> (2 * i - 2))) & 3u) == 0u;
+    keys[g] = dup ? 0xFFFFFFFFu : d;
+    vals[g] = w;                                          // position in the sorted whitelist
+    if (!dup) {
+        atomicOr(&delmap[d >> 5], 1u << (d & 31u));
+        atomicAdd(&dir[(d >> DV_DIR_SHIFT) + 1], 1u);     // histogram; an inclusive scan turns it into bucket starts
+    }
 }
 
 __global__ __launch_bounds__(256)
 void k_nearest_delins(const uint2* __restrict__ list2,
                       uint32_t nq, const uint32_t* counters, WlIndex ix, const uint32_t* __restrict__ delmap,
+                      const uint32_t* __restrict__ dv_var, const uint32_t* __restrict__ dv_pos, const uint32_t* __restrict__ dv_dir,
                       uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
                       uint32_t* __restrict__ list3, uint32_t* counters_out)
 {
@@ -286,47 +303,25 @@ void k_nearest_delins(const uint2* __restrict__ list2,
         // equal neighbours give equal variants: keep the first of a run
         const bool dup_del = sub > 0 && (((qq >> (2 * sub)) ^ (qq >> (2 * sub - 2))) & 3u) == 0u;
         const bool hit = on && !dup_del && ((dword >> (d & 31u)) & 1u);
-        unsigned long long pend = __ballot(hit);
+        // A lane whose variant occurs in the whitelist looks up WHICH entries own it (they are the re-insertions of one base
+        // into the variant): directory -> the few sorted (variant, entry) pairs of its bucket -> rank and caller index.
+        // All lanes do this at once.  Entries within Hamming distance 2 were pass 1's.
         uint32_t found[4] = { 0, 0, 0, 0 }; int nf = 0; bool overflow = false;
-        // each variant that occurs in the whitelist: the group's 16 lanes take one insertion slot each, 4 letters
-        while (pend) {
-            const unsigned long long mine = pend & gmask;
-            const int src = mine ? __builtin_ctzll(mine) : lane;
-            const uint32_t dv = __shfl(d, src);
-            if (mine) {
-                const uint32_t sm = low_mask(sub);
-                const uint32_t prev = sub > 0 ? (dv >> (2 * sub - 2)) & 3u : 4u;
-                uint32_t r[4]; bool go[4]; uint32_t o[4] = { 0, 0, 0, 0 };
-#pragma unroll
-                for (uint32_t c = 0; c < 4; ++c) {
-                    r[c] = (dv & sm) | (c << (2 * sub)) | ((dv & ~sm) << 2);
-                    // inserting c next to an equal base repeats the previous slot's string; Hamming <= 2 is pass 1's
-                    go[c] = prev != c && hamming16(r[c] ^ qq) > 2u;
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) go[c] = go[c] && wl_lookup(ix, r[c], o[c]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (go[c]) {
-                        const uint32_t oo = o[c];
-                        const bool dup = (nf > 0 && found[0] == oo) || (nf > 1 && found[1] == oo) ||
-                                         (nf > 2 && found[2] == oo) || (nf > 3 && found[3] == oo);
-                        if (!dup) {
-                            if (nf < 4) { found[0] = nf == 0 ? oo : found[0]; found[1] = nf == 1 ? oo : found[1];
-                                          found[2] = nf == 2 ? oo : found[2]; found[3] = nf == 3 ? oo : found[3]; ++nf; }
-                            else overflow = true;
-                        }
-                    }
+        if (hit) {
+            const uint32_t lo = dv_dir[d >> DV_DIR_SHIFT], hi = dv_dir[(d >> DV_DIR_SHIFT) + 1];
+            for (uint32_t k = lo; k < hi; ++k) {
+                if (dv_var[k] != d) continue;
+                const uint32_t p = dv_pos[k];
+                if (hamming16(ix.sorted[p] ^ qq) <= 2u) continue;
+                const uint32_t oo = ix.orig[p];
+                const bool dup = (nf > 0 && found[0] == oo) || (nf > 1 && found[1] == oo) ||
+                                 (nf > 2 && found[2] == oo) || (nf > 3 && found[3] == oo);
+                if (!dup) {
+                    if (nf < 4) { found[0] = nf == 0 ? oo : found[0]; found[1] = nf == 1 ? oo : found[1];
+                                  found[2] = nf == 2 ? oo : found[2]; found[3] = nf == 3 ? oo : found[3]; ++nf; }
+                    else overflow = true;
                 }
             }
-            // every group drops the variant it just handled
-            unsigned long long done = 0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const unsigned long long m = pend & (0xFFFFull << (16 * g));
-                if (m) done |= 1ull << __builtin_ctzll(m);
-            }
-            pend &= ~done;
         }
         // merge inside the 16-lane group: distinct hits, lowest caller index
         const bool any_over = (__ballot(overflow) & gmask) != 0;
@@ -428,9 +423,31 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
     BDG_HIP_TRY(ctx, hipMemcpy(static_cast<uint32_t*>(ctx->w_pent.p) + prank.size(), pidx.data(), sizeof(uint32_t) * pidx.size(), hipMemcpyHostToDevice));
     BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->w_delmap.p, 0, size_t(1) << 27, ctx->stream));
     {
-        const uint64_t threads = 16ull * nw;
-        hipLaunchKernelGGL(k_build_delmap, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
-                           static_cast<const uint32_t*>(ctx->w_sorted.p), nw, static_cast<uint32_t*>(ctx->w_delmap.p));
+        // deletion variants: map bits + (variant, entry) pairs sorted by variant on the device + directory
+        const size_t npairs = 16ull * nw;
+        if (npairs >= (size_t(1) << 31)) return bdg_fail(ctx, BDG_E_ARG, "whitelist too large");
+        if ((rc = bdg_reserve(ctx, ctx->w_dv, sizeof(uint32_t) * (2 * npairs + DV_DIR_N + 2)))) return rc;
+        auto* dv_var = static_cast<uint32_t*>(ctx->w_dv.p);
+        auto* dv_pos = dv_var + npairs;
+        auto* dv_dir = dv_pos + npairs;
+        uint32_t *k_in = nullptr, *v_in = nullptr; void* temp = nullptr;
+        size_t t_sort = 0, t_scan = 0;
+        BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, k_in, dv_var, v_in, dv_pos, (int)npairs, 0, 32, ctx->stream));
+        BDG_HIP_TRY(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, t_scan, dv_dir, dv_dir, (int)(DV_DIR_N + 1), ctx->stream));
+        BDG_HIP_TRY(ctx, hipMalloc(&k_in, sizeof(uint32_t) * npairs));
+        hipError_t e = hipMalloc(&v_in, sizeof(uint32_t) * npairs);
+        if (e == hipSuccess) e = hipMalloc(&temp, std::max(t_sort, t_scan));
+        if (e == hipSuccess) e = hipMemsetAsync(dv_dir, 0, sizeof(uint32_t) * (DV_DIR_N + 2), ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_build_delmap, dim3((uint32_t)((npairs + 255) / 256)), dim3(256), 0, ctx->stream,
+                               static_cast<const uint32_t*>(ctx->w_sorted.p), nw, static_cast<uint32_t*>(ctx->w_delmap.p),
+                               k_in, v_in, dv_dir);
+            e = hipcub::DeviceRadixSort::SortPairs(temp, t_sort, k_in, dv_var, v_in, dv_pos, (int)npairs, 0, 32, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(temp, t_scan, dv_dir, dv_dir, (int)(DV_DIR_N + 1), ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(k_in); (void)hipFree(v_in); (void)hipFree(temp);
+        BDG_HIP_TRY(ctx, e);
     }
     BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return BDG_OK;
@@ -473,7 +490,10 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t qstride, in
         {
             ScopedKernelTimer tm(ctx, "k_nearest_delins");
             const uint32_t grid = std::min<uint32_t>((nq + 15) / 16, 256u * 8u);
+            const auto* dv_var = static_cast<const uint32_t*>(ctx->w_dv.p);
+            const size_t npairs = 16ull * ctx->w_n;
             hipLaunchKernelGGL(k_nearest_delins, dim3(grid), dim3(256), 0, st, list2, nq, counters, ix, pt.delmap,
+                               dv_var, dv_var + npairs, dv_var + 2 * npairs,
                                d_best_idx, d_best_ed, d_n_ties, list3, counters);
         }
         // queries whose hit list overflowed (one lane found more than 4 distinct entries): exhaustive
