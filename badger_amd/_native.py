@@ -166,8 +166,8 @@ class Context:
     def extract_counters(self):
         out = (C.c_uint64 * 8)()
         self._check(self.lib.bdg_extract_counters(self.h, out))
-        names = ("hits", "clusters", "filter_in", "filter_skipped", "filter_kept", "requeued", "alignments")
-        return dict(zip(names, [int(x) for x in out[:7]]))
+        names = ("hits", "clusters", "filter_in", "filter_skipped", "filter_kept", "requeued", "alignments", "filter_in_clusters")
+        return dict(zip(names, [int(x) for x in out[:8]]))
 
     # -- nearest ---------------------------------------------------------------
     def nearest16(self, q, wl, max_ed=2):

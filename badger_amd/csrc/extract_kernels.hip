@@ -57,7 +57,7 @@ enum { K_TASK = 0,      // next task of the shard (k_scan_reads)
        K_NC = 2, K_ND = 3,
        K_STAT = 4,      // S_* words below
        K_LINES = 5 };
-enum { S_BADREAD = 0 /* max of ~read index, 0 = none */, S_NWINDOWS = 1, S_NKEPT = 2, S_NHITS = 3, S_NSKIPPED = 4 };
+enum { S_BADREAD = 0 /* max of ~read index, 0 = none */, S_NWINDOWS = 1, S_NKEPT = 2, S_NHITS = 3, S_NSKIPPED = 4, S_NBHITS = 5, S_N = 6 };
 constexpr int SH_WORDS = K_LINES * 16;                       // 64-bit words per shard
 constexpr size_t COUNTER_BYTES = (size_t)NSH * SH_WORDS * 8;
 
@@ -259,7 +259,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     // (relaxed search applies), any other is split into single hits for the filter (queue B).  One packed reservation
     // (A count | B count << 32) per call.  force_a: polyT not known yet (staging overflow), everything to queue A.
     auto emit = [&](bool from_lds, uint2 mine, bool mine_on, uint32_t n_items, bool force_a) {
-        struct Cl { QEnt f, r; bool af, ar; uint32_t nbf, nbr; };
+        struct Cl { QEnt f, r; bool af, ar, bf, br; };
         // Two items that are neighbouring vectors of one read and whose hits of a strand span at most 17 positions (one
         // adapter copy cut by the vector boundary) form ONE cluster: its union window still fits the 56 columns of
         // k_sw_clusters and one alignment serves both.  The item holding the cluster's first hit in strand order
@@ -298,19 +298,19 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             const int32_t posF = p0 + k0;
             cl.f = make_uint4(r, (uint32_t)posF << 1, hF >> k0, 0u);
             cl.af = hF != 0 && (force_a || (ptF >= 0 && posF + KMER <= ptF + 1));
-            cl.nbf = (hF != 0 && !cl.af) ? __popc(hF) : 0u;
+            cl.bf = hF != 0 && !cl.af;
             const int k1 = hR ? 31 - __builtin_clz(hR) : 0;
             const int32_t posR = L - KMER - (p0r + k1);
             cl.r = make_uint4(r, ((uint32_t)posR << 1) | 1u, __brev(hR) >> (31 - k1), 0u);
             cl.ar = hR != 0 && (force_a || (ptR >= 0 && posR + KMER <= ptR + 1));
-            cl.nbr = (hR != 0 && !cl.ar) ? __popc(hR) : 0u;
+            cl.br = hR != 0 && !cl.ar;
             return cl;
         };
         const uint32_t nchunk = from_lds ? (n_items + 63u) / 64u : 1u;
         uint32_t acc = 0;
         for (uint32_t c = 0; c < nchunk; ++c) {
             const Cl cl = clusters(c);
-            acc += (cl.af ? 1u : 0u) + (cl.ar ? 1u : 0u) + ((cl.nbf + cl.nbr) << 16);
+            acc += (cl.af ? 1u : 0u) + (cl.ar ? 1u : 0u) + (((cl.bf ? 1u : 0u) + (cl.br ? 1u : 0u)) << 16);
         }
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(acc), 63);
         unsigned long long base = 0;
@@ -319,24 +319,14 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         unsigned long long gA = base & 0xFFFFFFFFull, gB = base >> 32;
         for (uint32_t c = 0; c < nchunk; ++c) {
             const Cl cl = clusters(c);
-            const uint32_t mine_cnt = (cl.af ? 1u : 0u) + (cl.ar ? 1u : 0u) + ((cl.nbf + cl.nbr) << 16);
+            const uint32_t mine_cnt = (cl.af ? 1u : 0u) + (cl.ar ? 1u : 0u) + (((cl.bf ? 1u : 0u) + (cl.br ? 1u : 0u)) << 16);
             const uint32_t incl = wave_incl_scan(mine_cnt);
             const uint32_t excl = incl - mine_cnt;
             unsigned long long ga = gA + (excl & 0xFFFFu), gb = gB + (excl >> 16);
             if (cl.af) { if (ga < qcap) qa[ga] = cl.f; ++ga; }
             if (cl.ar) { if (ga < qcap) qa[ga] = cl.r; }
-            uint32_t m = cl.nbf ? cl.f.z : 0u;
-            while (m) {
-                const int jb = __builtin_ctz(m); m &= m - 1;
-                if (gb < qcap) qb[gb] = make_uint4(cl.f.x, cl.f.y + ((uint32_t)jb << 1), 1u, 0u);
-                ++gb;
-            }
-            m = cl.nbr ? cl.r.z : 0u;
-            while (m) {
-                const int jb = __builtin_ctz(m); m &= m - 1;
-                if (gb < qcap) qb[gb] = make_uint4(cl.r.x, cl.r.y + ((uint32_t)jb << 1), 1u, 0u);
-                ++gb;
-            }
+            if (cl.bf) { if (gb < qcap) qb[gb] = cl.f; ++gb; }
+            if (cl.br) { if (gb < qcap) qb[gb] = cl.r; }
             const uint32_t ctot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             gA += ctot & 0xFFFFu; gB += ctot >> 16;
         }
@@ -859,14 +849,14 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                      unsigned long long* __restrict__ counters,
                      const unsigned long long* __restrict__ keys)
 {
-    __shared__ uint2 s_buf[4][128];          // live hits {read, (pos << 1) | strand}, compacted per wave
+    __shared__ uint2 s_buf[4][192];          // live hits {read, (pos << 1) | strand}, compacted per wave (< 64 waiting + <= 128 new)
     __shared__ uint2 s_out[4][128];          // survivors, flushed with one reservation
     __shared__ uint32_t s_cnt[NSH];
     const uint64_t nb = queue_counts(counters, K_NAB, 1, seg, s_cnt);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t shard = blockIdx.x % NSH;
     const uint64_t stride = (uint64_t)gridDim.x * 256ull;
-    uint32_t nkept = 0, nskip = 0, nbuf = 0, nout = 0;
+    uint32_t nkept = 0, nskip = 0, nbhits = 0, nbuf = 0, nout = 0;
 
     auto process = [&](uint2 h, bool active) {
         uint64_t rs = 0; int64_t L = 0;
@@ -889,24 +879,35 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     };
 
     for (uint64_t base = (uint64_t)blockIdx.x * 256ull + (threadIdx.x & ~63); base < nb; base += stride) {
-        const QEnt e = queue_fetch(qb, seg, s_cnt, base + lane, nb);
-        bool active = e.x != HOLE_R;
-        if (active) {
+        const QEnt e = queue_fetch(qb, seg, s_cnt, base + lane, nb);       // a cluster: first hit + offset mask of all its hits
+        uint32_t mask = e.x != HOLE_R ? e.z : 0u;
+        nbhits += __popc(mask);
+        if (mask) {
             // The strict search only runs when the relaxed one found nothing acceptable (barcode_callers.py:195).
             // Every relaxed candidate of this read-strand has been aligned by now: if its winner passes
             // end_delta = 4, the strict result is never looked at.
             const unsigned long long kr = keys[2ull * e.x + (e.y & 1u)];
-            if (kr != 0 && (R1_LEN - 1 - (int)(kr & 31u)) <= 4) { active = false; ++nskip; }
+            if (kr != 0 && (R1_LEN - 1 - (int)(kr & 31u)) <= 4) { nskip += __popc(mask); mask = 0u; }
         }
-        const unsigned long long m = __ballot(active);
-        if (active) s_buf[wv][nbuf + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(e.x, e.y);
-        nbuf += (uint32_t)__popcll(m);
-        __builtin_amdgcn_wave_barrier();
-        if (nbuf >= 64u) {
-            nbuf -= 64u;
-            const uint2 h = s_buf[wv][nbuf + lane];
+        // live clusters hand over their hits, at most two per lane and round, to the compacted list
+        while (__ballot(mask != 0u)) {
+            const int j0 = mask ? __builtin_ctz(mask) : 0;
+            const uint32_t m1 = mask & (mask - 1u);
+            const int j1 = m1 ? __builtin_ctz(m1) : 0;
+            const uint32_t cnt = (mask ? 1u : 0u) + (m1 ? 1u : 0u);
+            mask = m1 & (m1 - 1u);
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t at = nbuf + incl - cnt;
+            if (cnt >= 1u) s_buf[wv][at] = make_uint2(e.x, e.y + ((uint32_t)j0 << 1));
+            if (cnt == 2u) s_buf[wv][at + 1u] = make_uint2(e.x, e.y + ((uint32_t)j1 << 1));
+            nbuf += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             __builtin_amdgcn_wave_barrier();
-            process(h, true);
+            while (nbuf >= 64u) {
+                nbuf -= 64u;
+                const uint2 h = s_buf[wv][nbuf + lane];
+                __builtin_amdgcn_wave_barrier();
+                process(h, true);
+            }
         }
     }
     if (nbuf) {
@@ -921,6 +922,9 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) nskip += __shfl_xor(nskip, d);
     if (lane == 0 && nskip) atomicAdd(&stat[S_NSKIPPED], (unsigned long long)nskip);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nbhits += __shfl_xor(nbhits, d);
+    if (lane == 0 && nbhits) atomicAdd(&stat[S_NBHITS], (unsigned long long)nbhits);
 }
 
 // ---------------------------------------------------------------------------
@@ -1291,7 +1295,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
 }
 
 namespace {
-struct CounterSums { uint64_t a_max, b_max, c_max, a, b, c, d, bad, stat[5]; };
+struct CounterSums { uint64_t a_max, b_max, c_max, a, b, c, d, bad, stat[S_N]; };
 
 int read_counters(bdg_ctx* ctx, CounterSums& cs)
 {
@@ -1306,7 +1310,7 @@ int read_counters(bdg_ctx* ctx, CounterSums& cs)
         cs.a_max = a > cs.a_max ? a : cs.a_max; cs.b_max = b > cs.b_max ? b : cs.b_max; cs.c_max = cc > cs.c_max ? cc : cs.c_max;
         const uint64_t* st = w + K_STAT * 16;
         cs.bad = st[S_BADREAD] > cs.bad ? st[S_BADREAD] : cs.bad;                 // max of ~index = smallest index
-        for (int k = 1; k < 5; ++k) cs.stat[k] += st[k];
+        for (int k = 1; k < S_N; ++k) cs.stat[k] += st[k];
     }
     return BDG_OK;
 }
@@ -1339,7 +1343,7 @@ int bdg_extract_counters_impl(bdg_ctx* ctx, uint64_t out[8])
     CounterSums cs;
     int rc;
     if ((rc = read_counters(ctx, cs))) return rc;
-    out[0] = cs.stat[S_NHITS]; out[1] = cs.a; out[2] = cs.b; out[3] = cs.stat[S_NSKIPPED];
-    out[4] = cs.stat[S_NKEPT]; out[5] = cs.c; out[6] = cs.stat[S_NWINDOWS];
+    out[0] = cs.stat[S_NHITS]; out[1] = cs.a; out[2] = cs.stat[S_NBHITS]; out[3] = cs.stat[S_NSKIPPED];
+    out[4] = cs.stat[S_NKEPT]; out[5] = cs.c; out[6] = cs.stat[S_NWINDOWS]; out[7] = cs.b;
     return BDG_OK;
 }

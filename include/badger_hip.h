@@ -115,9 +115,9 @@ int  bdg_extract_batch_dev(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t*
  * workspace has been grown). n_windows: Smith-Waterman windows evaluated. */
 int  bdg_extract_status(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_windows);
 /* Pipeline statistics of the last extraction (synchronises): out[0] 6-mer hits, [1] clusters aligned
- * (queue A), [2] single hits sent to the strict filter (queue B), [3] of those skipped because the
+ * (queue A), [2] hits sent to the strict filter (queue B), [3] of those skipped because the
  * relaxed search had already succeeded, [4] filter survivors, [5] hits re-queued from clusters,
- * [6] alignments run, [7] reserved. */
+ * [6] alignments run, [7] clusters the hits of [2] arrived in. */
 int  bdg_extract_counters(bdg_ctx* ctx, uint64_t out[8]);
 
 /* ---- B-N: nearest whitelist barcode ----------------------------------- */
