@@ -162,7 +162,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": per_launch_ms[dom], "int_issue": int_issue},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(per_launch_ms.items())},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU leg runs at N = 1 only (256 host threads would fight the other ranks)
             line["cpu_baseline"] = cpu_baseline(bases, off_u, wl, 100000, 48)
         print(json.dumps(line))
     if world > 1:
