@@ -4,7 +4,7 @@ For several seeds / error profiles: extraction of N synthetic reads on the GPU v
 then nearest16 of the extracted barcodes vs the oracle on a sample, and graph edges (thr 1 and 2) of a slice of the
 distinct barcodes vs the oracle.  Prints one line per case; exit code 1 on any mismatch.
 
-    python tools/stress_parity.py [--reads 1000000] [--cases 6]
+    python tools/stress_parity.py [--reads 1000000] [--cases 6] [--n-rate 0.001]
 """
 import argparse
 import os
@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=1000000)
     ap.add_argument("--cases", type=int, default=len(PROFILES))
+    ap.add_argument("--n-rate", type=float, default=0.0, help="probability of replacing a base by N")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cores = len(os.sched_getaffinity(0))
@@ -41,6 +42,10 @@ def main():
         n = args.reads
         bases, off = synth.make_reads(n, wl, seed=100 + case, device=dev, **prof)
         total = int(off[-1])
+        if args.n_rate > 0:                                   # sprinkle N: exercises the exact per-byte path of the scan at scale
+            g = torch.Generator(device=dev)
+            g.manual_seed(1000 + case)
+            bases[torch.rand(total, generator=g, device=dev) < args.n_rate] = ord("N")
         bases = torch.cat([bases, torch.zeros(64, dtype=torch.uint8, device=dev)])
         recs = torch.zeros((n, 8), dtype=torch.int32, device=dev)
         for _ in range(2):
