@@ -113,7 +113,7 @@ void bdg_free(bdg_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = { &ctx->x_lut, &ctx->x_polyt, &ctx->x_keys, &ctx->x_hits, &ctx->x_counters, &ctx->s_in0,
                        &ctx->s_in1, &ctx->s_out0, &ctx->w_sorted, &ctx->w_orig, &ctx->w_prefix, &ctx->w_bitmap, &ctx->w_pent, &ctx->w_delmap, &ctx->w_dv,
-                       &ctx->n_list, &ctx->n_counters, &ctx->g_sig, &ctx->g_tmp0, &ctx->g_tmp1, &ctx->g_cnt };
+                       &ctx->n_list, &ctx->n_counters, &ctx->g_sig, &ctx->g_tmp0, &ctx->g_tmp1, &ctx->g_cnt, &ctx->g_qj };
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& t : ctx->timers) for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -292,7 +292,7 @@ int bdg_nearest16(bdg_ctx* ctx, const uint32_t* q, uint32_t nq, const uint32_t* 
 // ---- graph --------------------------------------------------------------------
 int bdg_graph_set_algo(bdg_ctx* ctx, int algo)
 {
-    if (!ctx || algo < 0 || algo > 2) return BDG_E_ARG;
+    if (!ctx || algo < 0 || algo > 4) return BDG_E_ARG;
     ctx->graph_algo = algo;
     return BDG_OK;
 }

@@ -65,6 +65,7 @@ struct bdg_ctx {
     int graph_algo = 0;
     DevBuf g_sig;        // uint32 [n] letter-count signatures
     DevBuf g_tmp0, g_tmp1, g_cnt;
+    DevBuf g_qj;         // q-gram join: sorted (six-mer, row) entries, inverse positions, bucket and slice starts
 };
 
 #define BDG_HIP_TRY(ctx, expr)                                                           \

@@ -19,7 +19,10 @@
 // see graph_probe_candidates() below.
 #include "bdg_common.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -95,7 +98,7 @@ void k_graph_sig(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t* __res
 
 // Edge output.  Edges are staged per wave in LDS; a block reserves output slots with ONE atomic when it ends (returning
 // atomics on one address complete ~11 ns apart device-wide, so one per edge - or per wave step - would bound the kernel).
-constexpr uint32_t ECAP = 256;                   // staged edges per wave
+constexpr uint32_t ECAP = 128;                   // staged edges per wave
 
 struct EdgeStage { uint32_t a[ECAP], b[ECAP]; uint8_t d[ECAP]; };
 
@@ -329,6 +332,338 @@ void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
     edge_finish(s_edges, ne, s_ecnt, &s_ebase, out, cap, n_edges);
 }
 
+
+// ---------------------------------------------------------------------------
+// thr >= 2: q-gram join (the device form of QGramIndex, index.py:29-35,77-93).
+//
+// The reference keeps 4096 buckets {rank: count} and, for every barcode, sums the counts of all later
+// barcodes over its 11 six-mers: distances[j] = S(i, j); candidates are the j with S >= T.  Here:
+//   k_qj_emit    one entry (six-mer, row << 4 | position) per barcode and position: 11 n entries,
+//   hipCUB       stable radix sort on the 12 key bits: a bucket is a contiguous run, rows ascending inside it,
+//   k_qj_index   where each (row, position) landed (pos_of), where each bucket starts,
+//   k_qj_split   for every bucket the first entry at or past each multiple of W rows (so that a row can take its
+//                candidates in slices of W rows without searching),
+//   k_graph_qjoin one block per row i: for each slice of later rows, every entry of the 11 bucket tails is one unit
+//                of S(i, j); the block accumulates them in an LDS hash table {j: count} - the count IS the reference's
+//                statistic - then sweeps the table: entries with count >= T are verified with one Myers pass (dmin3)
+//                64 at a time.  Nothing is computed for the ~99 % of candidate pairs that share a single six-mer
+//                by chance, except one LDS atomic.
+// A slice with more entries than the table takes is cut by a hash of j into parts that are counted first, so a
+// pass can never overflow the table; a slice that cannot be cut (P_MAX parts are not enough - only contrived inputs)
+// is verified entry by entry in closed form (qgram_S + "is this the first matching position pair").
+// ---------------------------------------------------------------------------
+constexpr int QJ_NQ = 11;                        // six-mers per 16-mer
+constexpr int QJ_TAB_BITS = 12;                  // table slots (LDS: 16 KiB of a block's ~26 KiB, 6 blocks per CU)
+constexpr uint32_t QJ_PMAX = 1024;               // parts of a slice
+
+__global__ __launch_bounds__(256)
+void k_qj_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= (uint64_t)n * QJ_NQ) return;
+    const uint32_t row = (uint32_t)(g / QJ_NQ), p = (uint32_t)(g % QJ_NQ);
+    keys[g] = (ranks[row] >> (2u * p)) & 0xFFFu;            // barcode[p:p+6] (index.py:31-33), as the rank of the slice
+    vals[g] = (row << 4) | p;
+}
+
+__global__ __launch_bounds__(256)
+void k_qj_index(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t m,
+                uint32_t* __restrict__ pos_of, uint32_t* __restrict__ bucket_off /* [4097] */)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t v = vals[k];
+    pos_of[(v >> 4) * QJ_NQ + (v & 15u)] = k;
+    const uint32_t key = keys[k];
+    const uint32_t first = k ? keys[k - 1] + 1u : 0u;       // buckets (prev key, key] start here (empty ones included)
+    for (uint32_t q = first; q <= key; ++q) bucket_off[q] = k;
+    if (k == m - 1) for (uint32_t q = key + 1u; q <= 4096u; ++q) bucket_off[q] = m;
+}
+
+// split[q * (G + 1) + g] = first entry of bucket q whose row is >= g * W
+__global__ __launch_bounds__(256)
+void k_qj_split(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ bucket_off, uint32_t G, uint32_t W,
+                uint32_t* __restrict__ split)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= 4096u * (G + 1u)) return;
+    const uint32_t q = t / (G + 1u), g = t % (G + 1u);
+    uint32_t lo = bucket_off[q], hi = bucket_off[q + 1];
+    const uint64_t want = (uint64_t)g * W;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint64_t)(vals[mid] >> 4) < want) lo = mid + 1; else hi = mid;
+    }
+    split[t] = lo;
+}
+
+// Myers pass with the pattern's match vectors given (the pattern is the block's row: built once per row)
+__device__ __forceinline__ uint32_t dmin3_peq(const uint32_t (&peq)[4], uint32_t b)
+{
+    uint32_t pv = 0xFFFFu, mv = 0u, score = 16u, score15 = 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t c = (b >> (2 * j)) & 3u;
+        const uint32_t eq = (c & 2u) ? ((c & 1u) ? peq[3] : peq[2]) : ((c & 1u) ? peq[1] : peq[0]);
+        const uint32_t xv = eq | mv;
+        const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+        uint32_t ph = mv | ~(xh | pv);
+        uint32_t mh = pv & xh;
+        score += (ph >> 15) & 1u;
+        score -= (mh >> 15) & 1u;
+        ph = (ph << 1) | 1u;
+        mh = mh << 1;
+        pv = mh | ~(xv | ph);
+        mv = ph & xv;
+        if (j == 14) score15 = score;
+    }
+    const uint32_t d1516 = score - ((pv >> 15) & 1u) + ((mv >> 15) & 1u);
+    uint32_t d = score < score15 ? score : score15;
+    return d < d1516 ? d : d1516;
+}
+
+// first matching six-mer position pair (p in a, p' in b), lexicographically: p * 16 + p'; 0xFFFFFFFF if none
+__device__ __forceinline__ uint32_t qgram_first_match(uint32_t a, uint32_t b)
+{
+    uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int sh = -10; sh <= 10; ++sh) {
+        const int len = 16 - (sh < 0 ? -sh : sh);
+        const uint32_t x = sh >= 0 ? (a ^ (b >> (2 * sh))) : ((a >> (-2 * sh)) ^ b);
+        uint32_t z = ~(x | (x >> 1)) & 0x55555555u;
+        z &= len >= 16 ? 0xFFFFFFFFu : ((1u << (2 * len)) - 1u);
+        const uint32_t z2 = z & (z >> 2);
+        const uint32_t z4 = z2 & (z2 >> 4);
+        const uint32_t z6 = z4 & (z2 >> 8);
+        if (z6) {
+            const uint32_t p = (uint32_t)__builtin_ctz(z6) >> 1;           // index in the unshifted operand
+            const uint32_t pa = sh >= 0 ? p : p + (uint32_t)(-sh), pb = sh >= 0 ? p + (uint32_t)sh : p;
+            const uint32_t key = pa * 16u + pb;
+            best = key < best ? key : best;
+        }
+    }
+    return best;
+}
+
+constexpr uint32_t QJ_GMAX = 64;      // slices per row (their bounds are kept in LDS; the launcher widens W to keep G <= QJ_GMAX)
+constexpr uint32_t QJ_HCAP = 1024;    // rows j with S >= T waiting for their Myers pass (verified once per row)
+
+__global__ __launch_bounds__(256)
+void k_graph_qjoin(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_begin, uint32_t row_end,
+                   const uint32_t* __restrict__ vals, const uint32_t* __restrict__ pos_of,
+                   const uint32_t* __restrict__ split, uint32_t G, uint32_t W,
+                   uint32_t thr, int32_t T, int force_closed_form,
+                   bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges)
+{
+    constexpr uint32_t QJ_TAB = 1u << QJ_TAB_BITS;   // slots: (j + 1) << 7 | count
+    constexpr uint32_t QJ_CAP = QJ_TAB / 2;          // entries per pass (load <= 50 %)
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[QJ_TAB];
+    uint32_t* const s_pcnt = s_tab;                  // the parts are counted while the table is empty (and zeroed again)
+    static_assert(QJ_PMAX <= QJ_TAB, "part counters live in the table");
+    __shared__ uint32_t s_split[QJ_NQ][QJ_GMAX + 1]; // bounds of the row's 11 bucket tails, slice by slice
+    __shared__ uint32_t s_hit[QJ_HCAP];
+    __shared__ uint32_t s_dummy[256];                // never 0, never a key: what idle lanes aim their atomics at
+    __shared__ uint32_t s_nh, s_pmax, s_over;
+    __shared__ EdgeStage s_edges[4];
+    __shared__ uint32_t s_ecnt[4];
+    __shared__ unsigned long long s_ebase;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t ne = 0;
+    for (uint32_t k = tid; k < QJ_TAB; k += 256u) s_tab[k] = 0u;
+    s_dummy[tid] = 0xFFFFFFFFu;
+    const uint32_t Tc = T < 1 ? 1u : (uint32_t)T;
+
+    for (uint32_t i = row_begin + blockIdx.x; i < row_end; i += gridDim.x) {
+        const uint32_t a = ranks[i];
+        uint32_t peq[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t c = (a >> (2 * u)) & 3u;
+            peq[0] |= (c == 0u ? 1u : 0u) << u; peq[1] |= (c == 1u ? 1u : 0u) << u;
+            peq[2] |= (c == 2u ? 1u : 0u) << u; peq[3] |= (c == 3u ? 1u : 0u) << u;
+        }
+        auto verify = [&](bool on, uint32_t j) {
+            uint32_t b = 0, d = 99u;
+            if (on) { b = ranks[j]; d = dmin3_peq(peq, b); }
+            edge_push(on && d <= thr, a, b, d, s_edges[wv], ne, lane, out, cap, n_edges);
+        };
+        // one Myers pass per listed row, full lanes (block-wide; the list is empty afterwards)
+        auto flush_hits = [&](uint32_t nh) {
+            for (uint32_t h0 = 0; h0 < nh; h0 += 256u) {
+                const uint32_t h = h0 + (uint32_t)tid;
+                verify(h < nh, h < nh ? s_hit[h] : 0u);
+            }
+            __syncthreads();
+            if (tid == 0) s_nh = 0u;
+            __syncthreads();
+        };
+        uint32_t nh0 = 0;                                            // list length when the current pass began
+        __syncthreads();                                             // previous row done with s_split / s_hit
+        // the bounds of all the row's slices in one round trip: row i lies in slice g0, its candidates in slices g0 .. G-1
+        const uint32_t g0 = i / W, ng = G - g0;
+        for (uint32_t t = tid; t < QJ_NQ * (ng + 1u); t += 256u) {
+            const uint32_t sg = t / (ng + 1u), gi = t % (ng + 1u);
+            uint32_t v = split[(size_t)((a >> (2u * sg)) & 0xFFFu) * (G + 1u) + g0 + gi];
+            if (gi == 0u) { const uint32_t tail = pos_of[(size_t)i * QJ_NQ + sg] + 1u; v = v > tail ? v : tail; }   // behind row i's own entry
+            s_split[sg][gi] = v;
+        }
+        if (tid == 0) { s_nh = 0u; s_over = 0u; }
+        __syncthreads();
+        for (uint32_t gi = 0; gi < ng; ++gi) {
+            // the slice's candidates are 11 runs of the sorted entry array (one per six-mer of row i); wave w walks runs
+            // w, w + 4, w + 8 in strides of 64
+            uint32_t total = 0;
+#pragma unroll
+            for (int sg = 0; sg < QJ_NQ; ++sg) {
+                const uint32_t lo = s_split[sg][gi], hi = s_split[sg][gi + 1];
+                total += hi > lo ? hi - lo : 0u;
+            }
+            if (total == 0) continue;
+            // number of parts: 1 if the slice fits, else counted (a part never exceeds 3/4 of the table)
+            uint32_t P = 1;
+            bool closed = force_closed_form != 0;
+            if (!closed && total > QJ_CAP) {
+                P = (total + QJ_CAP - 1u) / QJ_CAP;
+                for (;;) {
+                    if (P > QJ_PMAX) { closed = true; break; }
+                    for (uint32_t k = tid; k < P; k += 256u) s_pcnt[k] = 0u;
+                    if (tid == 0) s_pmax = 0u;
+                    __syncthreads();
+                    for (int sg = wv; sg < QJ_NQ; sg += 4) {
+                        const uint32_t hi = s_split[sg][gi + 1];
+                        for (uint32_t k = s_split[sg][gi] + (uint32_t)lane; k < hi; k += 64u) {
+                            const uint32_t j = vals[k] >> 4;
+                            if (j > i) atomicAdd(&s_pcnt[((j * 0x85EBCA6Bu) >> 12) % P], 1u);
+                        }
+                    }
+                    __syncthreads();
+                    uint32_t mx = 0;
+                    for (uint32_t k = tid; k < P; k += 256u) mx = s_pcnt[k] > mx ? s_pcnt[k] : mx;
+                    if (mx) atomicMax(&s_pmax, mx);
+                    __syncthreads();
+                    const uint32_t pm = s_pmax;
+                    __syncthreads();
+                    if (pm <= QJ_TAB / 4u * 3u) break;
+                    P *= 2u;
+                }
+                for (uint32_t k = tid; k < (P < QJ_PMAX ? P : QJ_PMAX); k += 256u) s_pcnt[k] = 0u;
+                __syncthreads();
+            }
+            if (closed) {
+                // entry by entry: the pair is reported by its first matching position pair only
+                for (int sg = wv; sg < QJ_NQ; sg += 4) {
+                    const uint32_t lo = s_split[sg][gi], hi = s_split[sg][gi + 1];
+                    for (uint32_t k0 = lo; k0 < hi; k0 += 64u) {
+                        const uint32_t k = k0 + (uint32_t)lane;
+                        uint32_t b = 0, d = 99u; bool on = false;
+                        if (k < hi) {
+                            const uint32_t v = vals[k];
+                            const uint32_t j = v >> 4;
+                            if (j > i) {
+                                b = ranks[j];
+                                on = qgram_first_match(a, b) == (uint32_t)sg * 16u + (v & 15u) && qgram_S(a, b) >= Tc;
+                                if (on) d = dmin3_peq(peq, b);
+                            }
+                        }
+                        edge_push(on && d <= thr, a, b, d, s_edges[wv], ne, lane, out, cap, n_edges);
+                    }
+                }
+                continue;
+            }
+            for (uint32_t part = 0; part < P; ++part) {
+                // table size for this pass: at least twice the entries (P == 1), the whole table otherwise
+                uint32_t tb = QJ_TAB_BITS;
+                if (P == 1) { tb = 6; while ((1u << tb) < 2u * total) ++tb; }
+                const uint32_t mask = (1u << tb) - 1u;
+                {
+                    // this wave's runs (six-mers wv, wv + 4, wv + 8) as one flat list: entry t lies at vals[t + off]
+                    const uint32_t loA = s_split[wv][gi], hiA = s_split[wv][gi + 1];
+                    const uint32_t loB = s_split[wv + 4][gi], hiB = s_split[wv + 4][gi + 1];
+                    const bool hasC = wv + 8 < QJ_NQ;
+                    const uint32_t loC = hasC ? s_split[hasC ? wv + 8 : 0][gi] : 0u, hiC = hasC ? s_split[hasC ? wv + 8 : 0][gi + 1] : 0u;
+                    const uint32_t lenA = hiA > loA ? hiA - loA : 0u, lenB = hiB > loB ? hiB - loB : 0u, lenC = hiC > loC ? hiC - loC : 0u;
+                    const uint32_t eB = lenA + lenB, wt = eB + lenC;
+                    const uint32_t offA = loA, offB = loB - lenA, offC = loC - eB;
+                    for (uint32_t t0 = 0; t0 < wt; t0 += 512u) {
+                        uint32_t jv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {                // eight loads in flight per lane: one round trip per 512 entries
+                            const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
+                            const uint32_t o = t < lenA ? offA : (t < eB ? offB : offC);
+                            jv[u] = t < wt ? vals[t + o] >> 4 : 0u;
+                        }
+#pragma unroll
+                        for (int grp = 0; grp < 2; ++grp) {
+                            // four entries per lane probe the table in lock step (four LDS atomics in flight)
+                            uint32_t hh[4], jj[4]; bool pend[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const uint32_t j = jv[4 * grp + u];
+                                jj[u] = j;
+                                pend[u] = j > i && (P == 1 || ((j * 0x85EBCA6Bu) >> 12) % P == part);   // j <= i: nothing, or row i's own repeat
+                                hh[u] = (j * 0x9E3779B1u) >> (32 - tb);
+                            }
+                            // Branch-free probing: a lane with nothing to do aims its compare-and-swap at a private dummy word
+                            // that can neither be claimed nor match; every branch below is wave-uniform.
+                            while (__ballot(pend[0] || pend[1] || pend[2] || pend[3])) {
+                                uint32_t cur[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    uint32_t* const slot = pend[u] ? &s_tab[hh[u]] : &s_dummy[tid];
+                                    cur[u] = atomicCAS(slot, 0u, ((jj[u] + 1u) << 7) | 1u);
+                                }
+                                bool reached[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const bool fresh = cur[u] == 0u;                                    // claimed an empty slot: S = 1
+                                    const bool same = (cur[u] >> 7) == jj[u] + 1u;                      // the slot is j's: S += 1
+                                    reached[u] = fresh && Tc == 1u;
+                                    if (__ballot(same)) {
+                                        uint32_t* const slot = same ? &s_tab[hh[u]] : &s_dummy[tid];
+                                        const uint32_t old = atomicAdd(slot, same ? 1u : 0u);
+                                        reached[u] = reached[u] || (same && (old & 127u) + 1u == Tc);   // a count passes T exactly once
+                                    }
+                                    pend[u] = pend[u] && !fresh && !same;
+                                    hh[u] = (hh[u] + 1u) & mask;
+                                }
+                                if (__ballot(reached[0] || reached[1] || reached[2] || reached[3])) {
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        if (reached[u]) {                                                // lists j for the Myers pass
+                                            const uint32_t at = atomicAdd(&s_nh, 1u);
+                                            if (at < QJ_HCAP) s_hit[at] = jj[u]; else s_over = 1u;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                if (s_over) {
+                    // the list overflowed during this pass: drop what the pass listed and take its hits from the table instead
+                    __syncthreads();
+                    if (tid == 0) { s_nh = nh0; s_over = 0u; }
+                    for (uint32_t s0 = (uint32_t)wv * 64u; s0 <= mask; s0 += 256u) {
+                        const uint32_t cur = s_tab[s0 + lane];
+                        const bool hit = cur != 0u && (cur & 127u) >= Tc;
+                        if (__ballot(hit)) verify(hit, (cur >> 7) - 1u);
+                    }
+                }
+                // clear the part of the table this pass used
+                for (uint32_t k = (uint32_t)tid * 4u; k <= mask; k += 1024u) *reinterpret_cast<uint4*>(&s_tab[k]) = make_uint4(0u, 0u, 0u, 0u);
+                __syncthreads();
+                nh0 = s_nh < QJ_HCAP ? s_nh : QJ_HCAP;
+                if (nh0 > QJ_HCAP / 2u) { flush_hits(nh0); nh0 = 0u; }
+            }
+        }
+        __syncthreads();
+        flush_hits(s_nh < QJ_HCAP ? s_nh : QJ_HCAP);
+    }
+    __syncthreads();
+    edge_finish(s_edges, ne, s_ecnt, &s_ebase, out, cap, n_edges);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -342,7 +677,54 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
     if (qgram_T < 1) return bdg_fail(ctx, BDG_E_ARG, "qgram_T must be >= 1 (index.py:22-24 never yields less)");
     const bool probe = ctx->graph_algo == 2 || (ctx->graph_algo == 0 && thr == 1);
     if (ctx->graph_algo == 2 && thr != 1) return bdg_fail(ctx, BDG_E_ARG, "probe path needs thr == 1");
+    // q-gram join: any thr; the automatic choice for thr >= 2 (row << 4 | position and (j + 1) << 7 | count must fit 32 bits)
+    const bool qjoin = ctx->graph_algo == 3 || ctx->graph_algo == 4 || (ctx->graph_algo == 0 && thr >= 2 && n < (1u << 25));
+    if ((ctx->graph_algo == 3 || ctx->graph_algo == 4) && n >= (1u << 25)) return bdg_fail(ctx, BDG_E_ARG, "q-gram join needs n < 2^25");
     int rc;
+    if (qjoin) {
+        const size_t m = (size_t)n * QJ_NQ;
+        // slices of W rows: a row meets ~0.03 W entries per slice (11 buckets x 11 W / 4096); aim at half a table
+        // slices of W rows: a row meets ~0.03 W entries per slice (11 buckets x 11 W / 4096), i.e. about half a pass
+        // (measured at 500K rows: W = 32K 27.6 ms, 16K 36 ms, 64K 28 ms; 8K- and 16K-slot tables 32 - 40 ms)
+        uint32_t W = (1u << QJ_TAB_BITS) * 8u;
+        while ((n + W - 1) / W > QJ_GMAX) W *= 2u;
+        const uint32_t G = (n + W - 1) / W;
+        size_t t_sort = 0;
+        uint32_t* nul = nullptr;
+        BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, nul, nul, nul, nul, (int)m, 0, 12, st));
+        const size_t words = 5 * m + 4097 + 4096ull * (G + 1) + 64;
+        if ((rc = bdg_reserve(ctx, ctx->g_qj, sizeof(uint32_t) * words + t_sort + 256))) return rc;
+        auto* k_in = static_cast<uint32_t*>(ctx->g_qj.p);
+        auto* k_out = k_in + m;
+        auto* v_in = k_out + m;
+        auto* v_out = v_in + m;
+        auto* pos_of = v_out + m;
+        auto* bucket_off = pos_of + m;
+        auto* split = bucket_off + 4097;
+        void* temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(split + 4096ull * (G + 1)) + 255) & ~uintptr_t(255));
+        {
+            ScopedKernelTimer tm(ctx, "k_qj_build");
+            hipLaunchKernelGGL(k_qj_emit, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, d_ranks, n, k_in, v_in);
+            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(temp, t_sort, k_in, k_out, v_in, v_out, (int)m, 0, 12, st));
+            hipLaunchKernelGGL(k_qj_index, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, k_out, v_out, (uint32_t)m, pos_of, bucket_off);
+            hipLaunchKernelGGL(k_qj_split, dim3((4096u * (G + 1) + 255) / 256), dim3(256), 0, st, v_out, bucket_off, G, W, split);
+        }
+        {
+            ScopedKernelTimer tm(ctx, "k_graph_qjoin");
+            auto kern = k_graph_qjoin;
+            int per_cu = 0;
+            BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0));
+            if (per_cu < 1) per_cu = 1;
+            hipDeviceProp_t prop;
+            BDG_HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+            uint32_t grid = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;      // resident grid, rows interleaved
+            if (grid > row_end - row_begin) grid = row_end - row_begin;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, d_ranks, n, row_begin, row_end, v_out, pos_of, split, G, W,
+                               thr, qgram_T, ctx->graph_algo == 4 ? 1 : 0, d_out, cap, reinterpret_cast<unsigned long long*>(d_n_edges));
+        }
+        BDG_HIP_TRY(ctx, hipGetLastError());
+        return BDG_OK;
+    }
     if (probe) {
         int bbits = 16;
         while (bbits < 27 && (1u << (bbits - 4)) < n) ++bbits;           // ~16 bits per barcode

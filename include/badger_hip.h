@@ -159,7 +159,10 @@ int  bdg_graph_edges_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint
  * lists whose union is the full list. */
 int  bdg_graph_edges_rows_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t row_begin, uint32_t row_end,
                               uint32_t thr, int32_t qgram_T, bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges);
-int  bdg_graph_set_algo(bdg_ctx* ctx, int algo);   /* 0 auto, 1 all-pairs scan, 2 neighbourhood probes (thr=1) */
+/* 0 automatic (thr 1: neighbourhood probes; thr >= 2: q-gram join), 1 all-pairs scan, 2 neighbourhood probes (thr = 1 only),
+ * 3 q-gram join (the device form of QGramIndex, index.py:29-35,77-93; any thr), 4 the same with every candidate verified
+ * in closed form (the join's fallback for slices its table cannot take; for tests).  All give identical edge lists. */
+int  bdg_graph_set_algo(bdg_ctx* ctx, int algo);
 /* Distinct-barcode counting of a batch on the device (BarcodeGraph.index_bc_single_thread,
  * barcode_graph.py:192-204): from n extraction records, the distinct barcodes of records with a
  * full 16-base ACGT barcode, ascending in d_uniq, with their multiplicity (d_count) and the index of

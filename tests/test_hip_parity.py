@@ -199,7 +199,7 @@ def _ranks_of(barcodes):
     return np.unique(np.array(out, dtype=np.uint32))
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
 def test_graph_golden(ctx, golden_dir, algo):
     g = json.load(open(os.path.join(golden_dir, "graph.json")))
     for key in ("c1_thr1", "c1_thr2", "cells60_thr1", "cells60_thr2"):
@@ -232,7 +232,7 @@ def _observed_barcodes(n_cells, n_obs, seed):
     return np.unique(out.astype(np.uint32))
 
 
-@pytest.mark.parametrize("algo,thr", [(1, 1), (2, 1), (1, 2), (1, 3)])
+@pytest.mark.parametrize("algo,thr", [(1, 1), (2, 1), (1, 2), (1, 3), (3, 1), (3, 2), (3, 3), (4, 1), (4, 2), (0, 2), (0, 3)])
 def test_graph_vs_oracle(ctx, orc, algo, thr):
     ranks = _observed_barcodes(300, 12000, 31)
     ctx.graph_set_algo(algo)
@@ -244,7 +244,7 @@ def test_graph_vs_oracle(ctx, orc, algo, thr):
     ctx.graph_set_algo(0)
 
 
-@pytest.mark.parametrize("algo,thr", [(2, 1), (1, 1), (1, 2)])
+@pytest.mark.parametrize("algo,thr", [(2, 1), (1, 1), (1, 2), (3, 2), (4, 2)])
 def test_graph_row_blocks_partition_the_edges(ctx, orc, algo, thr):
     """a GPU owns a block of rows of the sorted rank array and emits the edges whose smaller rank lies in
     it; the blocks of any partition give disjoint lists whose union is the full list (blocks cut inside 256-row tiles,
@@ -277,6 +277,56 @@ def test_graph_row_blocks_partition_the_edges(ctx, orc, algo, thr):
         e = e[np.lexsort((e[:, 1], e[:, 0]))]
         assert len(e) == len(want) and len(e) > 100
         assert (e[:, 0] == want["a"]).all() and (e[:, 1] == want["b"]).all() and (e[:, 2] == want["dist"]).all()
+    ctx.graph_set_algo(0)
+
+
+def _low_complexity_barcodes(n, seed):
+    """16-mers made of short repeats and homopolymer runs with a few edits: six-mers repeat inside a barcode
+    (S counts products of multiplicities, index.py:80-93), buckets are very uneven, many pairs have S >= T."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        unit = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(1, 5))))
+        s = list((unit * 16)[:16])
+        for _ in range(int(rng.integers(0, 4))):
+            s[int(rng.integers(0, 16))] = "ACGT"[int(rng.integers(0, 4))]
+        if rng.random() < 0.3:
+            k = int(rng.integers(0, 16))
+            s = (s[:k] + s[k + 1:] + ["ACGT"[int(rng.integers(0, 4))]])
+        out.append(synth.str_to_rank("".join(s)))
+    return np.unique(np.array(out, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("thr", [1, 2, 3])
+def test_graph_qjoin_low_complexity(ctx, orc, thr):
+    """q-gram join (and its closed-form fallback) against the all-pairs sweep and the oracle where six-mers repeat."""
+    ranks = _low_complexity_barcodes(6000, 40 + thr)
+    T = orc.qgram_threshold(thr)
+    w = orc.graph_edges(ranks, thr, T, threads=8)
+    assert len(w) > 1000
+    for algo in (1, 3, 4):
+        ctx.graph_set_algo(algo)
+        e = ctx.graph_edges(ranks, thr, T)
+        assert len(e) == len(w) and (e == w).all(), algo
+    ctx.graph_set_algo(0)
+
+
+def test_graph_qjoin_dense_slices(ctx, orc):
+    """Few distinct cells, many near-identical variants: the bucket tails of a row exceed the join's table
+    several times over, so slices are cut into counted hash parts (P > 1)."""
+    rng = np.random.default_rng(77)
+    cell = int(rng.integers(0, 1 << 32))
+    obs = np.full(40000, cell, dtype=np.uint64)
+    for _ in range(4):                       # up to four substitutions, all in bases 6..15: bases 0..5 (one six-mer) never change
+        obs = obs ^ (rng.integers(0, 4, len(obs)).astype(np.uint64) << (2 * rng.integers(6, 16, len(obs)).astype(np.uint64)))
+    ranks = np.unique(obs.astype(np.uint32))
+    assert len(ranks) > 6000                 # the shared bucket's tail alone exceeds the 4096-entry pass for the early rows
+    T = orc.qgram_threshold(2)
+    w = orc.graph_edges(ranks, 2, T, threads=8)
+    for algo in (3, 1):
+        ctx.graph_set_algo(algo)
+        e = ctx.graph_edges(ranks, 2, T)
+        assert len(e) == len(w) and (e == w).all(), algo
     ctx.graph_set_algo(0)
 
 
