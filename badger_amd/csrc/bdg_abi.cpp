@@ -85,7 +85,10 @@ static int collect_timers(bdg_ctx* ctx)
 
 extern "C" {
 
-const char* bdg_version(void) { return "badger_hip 0.1 (gfx950)"; }
+#ifndef BDG_SRC_HASH
+#define BDG_SRC_HASH "unhashed"
+#endif
+const char* bdg_version(void) { return "badger_hip 0.2 (gfx950) src " BDG_SRC_HASH; }
 
 int bdg_init(int device_id, bdg_ctx** out)
 {

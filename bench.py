@@ -10,10 +10,21 @@ max-over-ranks clock.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--whitelist W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 from a plain `python bench.py` starts torch.distributed.run itself, as a child process and
+before this process has touched a GPU, and exits with the child's code.
+
+`--config 3` / `--config 5` time the other GPU configurations of BASELINE.json instead (K3 graph edges over 500K
+distinct barcodes at threshold 1 / 2) and print a line of the same shape with their own unit and roofline block.
+
+After the timed region the run is checked: the library's status word (queue overflow, bad base) and a sample of the
+final records and calls against the CPU oracle; a mismatch exits non-zero and prints no line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,28 +40,229 @@ from badger_amd import dist as bdist  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(bases_dev, off_dev, wl, n_extract, n_nearest):
-    """The CPU oracle (a port of the reference algorithm) timed on this box's host cores,
-    on a bounded sample of the same workload.  Only the checker is timed here; nothing the
-    product path produces depends on it."""
+def host_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def cpu_baseline(bases_dev, off_dev, wl):
+    """The CPU oracle (a port of the reference algorithm) timed on this box's host cores, on a bounded sample of the
+    same workload.  Only the checker is timed here; nothing the product path produces depends on it.
+    Legs, each on all cores and on one core:
+      extract  orc_extract_batch: the reference's per-read path (barcode_callers.py:165-229), OpenMP over reads like the
+               reference's ProcessPoolExecutor over chunks
+      nearest  the whitelist match.  `probe`: neighbourhood enumeration against a hash set, the algorithm class the GPU
+               path uses (a tuned CPU implementation).  `exhaustive`: Levenshtein against every entry, which is what the
+               reference's postprocessing loop does against its ~5K centres (barcode_graph.py:376-384) - against 737K
+               entries it is a lower bound nobody would run, reported for completeness only.
+    value = calls/s of extract + probe on all cores."""
     from oracle import pyoracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n_extract = min(n_extract, off_dev.numel() - 1)
-    end = int(off_dev[n_extract])
+    cores = host_cores()
+    n_all, n_one = 100000, 3000
+    n_all = min(n_all, off_dev.numel() - 1)
+    end = int(off_dev[n_all])
     b = bases_dev[:end].cpu().numpy()
-    o = off_dev[:n_extract + 1].cpu().numpy().astype(np.uint64)
+    o = off_dev[:n_all + 1].cpu().numpy().astype(np.uint64)
     orc.extract_batch(b[:int(o[64])], o[:65], 12, threads=cores)          # warm
     t0 = time.perf_counter()
     recs = orc.extract_batch(b, o, 12, threads=cores)
-    t_ext = (time.perf_counter() - t0) / n_extract
-    q = recs["bc_rank"][(recs["flags"] & 2) != 0][:n_nearest]
+    ext_all = n_all / (time.perf_counter() - t0)
     t0 = time.perf_counter()
-    orc.nearest16(q, wl, 2, threads=cores)
-    t_near = (time.perf_counter() - t0) / max(1, len(q))
-    return {"value": 1.0 / (t_ext + t_near), "unit": "calls/s", "cores": cores, "kind": "port",
-            "sample": "%d reads through oracle extract_batch (%.0f reads/s) + %d barcodes through the exhaustive "
-                      "Levenshtein scan of the %d-entry whitelist the reference's postprocessing loop does "
-                      "(%.1f calls/s); OpenMP over all %d cores" % (n_extract, 1.0 / t_ext, len(q), len(wl), 1.0 / t_near, cores)}
+    orc.extract_batch(b[:int(o[n_one])], o[:n_one + 1], 12, threads=1)
+    ext_one = n_one / (time.perf_counter() - t0)
+    q = recs["bc_rank"][(recs["flags"] & 2) != 0]
+    orc.nearest16(q[:64], wl, 2, threads=cores, probe=True)                # warm (builds nothing persistent, pages the code in)
+    t0 = time.perf_counter()
+    orc.nearest16(q, wl, 2, threads=cores, probe=True)
+    near_all = len(q) / (time.perf_counter() - t0)
+    q1 = q[:20000]
+    t0 = time.perf_counter()
+    orc.nearest16(q1, wl, 2, threads=1, probe=True)
+    near_one = len(q1) / (time.perf_counter() - t0)
+    qe = q[:48]
+    t0 = time.perf_counter()
+    orc.nearest16(qe, wl, 2, threads=cores)
+    near_exh = len(qe) / (time.perf_counter() - t0)
+    return {"value": 1.0 / (1.0 / ext_all + 1.0 / near_all), "unit": "calls/s", "cores": cores, "kind": "port",
+            "sample": "%d reads through the oracle's extract_batch + their %d barcodes through the oracle's neighbourhood-probe "
+                      "nearest16 against the %d-entry whitelist, OpenMP over all %d cores; 1-core legs on %d reads / %d barcodes; "
+                      "exhaustive-scan leg on %d barcodes" % (n_all, len(q), len(wl), cores, n_one, len(q1), len(qe)),
+            "extract_reads_per_s": ext_all, "extract_reads_per_s_1core": ext_one,
+            "nearest_probe_calls_per_s": near_all, "nearest_probe_calls_per_s_1core": near_one,
+            "nearest_exhaustive_calls_per_s": near_exh,
+            "value_1core": 1.0 / (1.0 / ext_one + 1.0 / near_one)}
+
+
+def profile_counters(kernel):
+    """HBM bytes / vector instructions per launch of `kernel` from the committed rocprofv3 PMC passes
+    (tools/pmc_profile.sh -> tools/summarize_profile.py), only if they were taken from this very build of the
+    library; otherwise None (a stale profile must not be printed beside live timings)."""
+    out = {"traffic": None, "valu": None, "source": None}
+    try:
+        lib_version = _native.load().bdg_version().decode()
+    except Exception:
+        return out
+    for name, key in (("traffic.json", "traffic"), ("valu.json", "valu")):
+        f = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(f):
+            continue
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        meta = d.get("_meta", {})
+        if meta.get("lib") != lib_version:
+            out["source"] = "profiles/%s is from build %r, this is %r: not reported" % (name, meta.get("lib"), lib_version)
+            continue
+        out[key] = d.get(kernel)
+        out["source"] = "profiles/%s@%s (rocprofv3 --pmc, %s)" % (name, meta.get("tag"), lib_version)
+    return out
+
+
+def parity_sample(ctx, bases, off_u, n, wl, recs, best_idx, best_ed, n_ties):
+    """A sample of the final step's output against the CPU oracle: 3 x 1000 records (start, middle, end of the
+    batch), the calls of those reads against the oracle's probe form, 24 of them against its exhaustive scan."""
+    from oracle import pyoracle as orc
+    cores = min(host_cores(), 32)
+    off = off_u.cpu().numpy().astype(np.uint64)
+    m = min(1000, n)
+    for lo in sorted({0, max(0, n // 2 - m // 2), n - m}):
+        hi = lo + m
+        b = bases[int(off[lo]):int(off[hi])].cpu().numpy()
+        want = orc.extract_batch(b, off[lo:hi + 1] - off[lo], 12, threads=cores)
+        got = recs[lo:hi].cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+        if not (got == want).all():
+            return "records %d..%d differ from the oracle" % (lo, hi)
+        ok = (want["flags"] & _native.FLAG_RANK_OK) != 0
+        gi = best_idx[lo:hi].cpu().numpy().view(np.uint32)
+        ge = best_ed[lo:hi].cpu().numpy()
+        gt = n_ties[lo:hi].cpu().numpy().view(np.uint16)
+        wi, we, wt = orc.nearest16(want["bc_rank"][ok], wl, 2, threads=cores, probe=True)
+        if not ((gi[ok] == wi).all() and (ge[ok] == we).all() and (gt[ok] == wt).all()):
+            return "calls of reads %d..%d differ from the oracle" % (lo, hi)
+        if not ((gi[~ok] == 0xFFFFFFFF).all() and (ge[~ok] == 255).all() and (gt[~ok] == 0).all()):
+            return "calls of unusable barcodes in %d..%d are not 'none'" % (lo, hi)
+        sel = np.nonzero(ok)[0][:8]
+        xi, xe, xt = orc.nearest16(want["bc_rank"][sel], wl, 2, threads=cores)
+        if not ((gi[sel] == xi).all() and (ge[sel] == xe).all() and (gt[sel] == xt).all()):
+            return "calls of reads %d.. differ from the oracle's exhaustive scan" % lo
+    return "ok"
+
+
+def spawn_ranks(ngpus):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU through torch.distributed.run as a CHILD
+    process (this process has not touched the GPU and never will) and hand back its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ngpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def observed_barcodes(n_distinct, wl, seed=3):
+    """n distinct 16-mers as extraction would see them: cell barcodes with substitutions and a
+    deletion, numpy.default_rng(seed)."""
+    rng = np.random.default_rng(seed)
+    cells = wl[rng.permutation(len(wl))[:5000]].astype(np.uint64)
+    out = np.zeros(0, dtype=np.uint32)
+    while len(out) < n_distinct:
+        m = 2 * n_distinct
+        r = cells[rng.integers(0, len(cells), m)]
+        for _ in range(2):
+            hit = rng.random(m) < 0.35
+            r = np.where(hit, r ^ (rng.integers(1, 4, m).astype(np.uint64) << (2 * rng.integers(0, 16, m).astype(np.uint64))), r)
+        hit = rng.random(m) < 0.25
+        pos = rng.integers(0, 16, m).astype(np.uint64)
+        low = (np.uint64(1) << (2 * pos)) - np.uint64(1)
+        d = (r & low) | ((r >> np.uint64(2)) & ~low & np.uint64(0xFFFFFFFF)) | (rng.integers(0, 4, m).astype(np.uint64) << np.uint64(30))
+        r = np.where(hit, d, r)
+        out = np.unique(np.concatenate([out, (r & np.uint64(0xFFFFFFFF)).astype(np.uint32)]))
+    rng.shuffle(out)
+    return np.sort(out[:n_distinct])
+
+
+def bench_graph(args, rank, world, dev, local_dev):
+    """BASELINE configs 3 / 5 (graph part): K3 over 500K distinct barcodes, thr 1 (neighbourhood probes) or thr 2
+    (q-gram join).  Rows shard over ranks in row blocks (every rank holds the whole sorted array), no collective."""
+    from oracle import pyoracle as orc
+    thr = 1 if args.config == 3 else 2
+    n = args.rows
+    wl = synth.make_whitelist(args.whitelist)
+    ranks = observed_barcodes(n, wl)
+    T = orc.qgram_threshold(thr)
+    lo, hi = bdist.graph_row_blocks(n, world, "rows")[rank]
+    d_ranks = torch.from_numpy(ranks.view(np.int32)).to(dev)
+    cap = 32 * n
+    d_edges = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int64, device=dev)
+    ctx = _native.Context(local_dev)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+    def step():
+        ctx.graph_edges_rows_dev(d_ranks, n, lo, hi, thr, T, d_edges, cap, d_n)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    ctx.profile(True)
+    ctx.profile_reset()
+    elapsed = bdist.timed(step, args.steps, dev)
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    ne = int(d_n[0])
+    if ne > cap:
+        raise SystemExit("edge capacity too small: %d > %d" % (ne, cap))
+    # check: every edge of 64 sampled rows of this rank's block against the oracle's S and dmin, both directions
+    e = d_edges[:ne].cpu().numpy().view(np.uint32)
+    rng = np.random.default_rng(7 + rank)
+    status = "ok"
+    for a in (ranks[lo:hi][rng.integers(0, hi - lo, 64)] if hi > lo else []):
+        mine = sorted((int(x[1]), int(x[2])) for x in e[e[:, 0] == a])
+        cand = ranks[ranks > a][:20000]
+        want = []
+        for b in cand:
+            if orc.qgram_S(int(a), int(b)) >= T:
+                d = orc.dmin3(int(a), int(b))
+                if d <= thr:
+                    want.append((int(b), d))
+        limit = int(cand[-1]) if len(cand) else 0
+        if sorted(want) != [m_ for m_ in mine if m_[0] <= limit]:
+            status = "row of rank %d differs from the oracle" % int(a)
+    fails = bdist.all_max(0.0 if status == "ok" else 1.0, dev)
+    if rank == 0:
+        if fails:
+            raise SystemExit("parity sample failed: " + status)
+        per_launch_ms = {k: v[1] / max(1, v[0]) for k, v in prof.items() if v[0]}
+        dom = max(per_launch_ms, key=per_launch_ms.get)
+        alg = 4 * n + 9 * ne                           # SURVEY 8d: 4n in + 9E out (rank's own edges)
+        achieved = alg / (per_launch_ms[dom] * 1e-3) / 1e9
+        pc = profile_counters(dom)
+        line = {
+            "metric": "graph rows/sec, threshold=%d, %d distinct barcodes" % (thr, n), "value": n / (elapsed / args.steps),
+            "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "BASELINE config %d: barcode_graph edges, threshold %d, %d distinct observed barcodes (%s)"
+                                   % (args.config, thr, n, "neighbourhood probes" if thr == 1 else "q-gram join"),
+                       "rows": n, "edges_rank0": ne, "qgram_T": T,
+                       "parallelism": "row blocks per GPU, no collectives"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pc["traffic"], "traffic_source": pc["source"],
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": per_launch_ms[dom]},
+            "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(per_launch_ms.items())},
+            "parity_sample": "ok",
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cores = host_cores()
+            m = min(n, 60000 if thr == 1 else 30000)
+            sub = np.sort(ranks[np.random.default_rng(1).permutation(n)[:m]])
+            t0 = time.perf_counter()
+            orc.graph_edges(sub, thr, T, threads=cores)
+            t_all = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": m / t_all, "unit": "rows/s", "cores": cores, "kind": "port",
+                                    "sample": "oracle graph_edges (QGramIndex buckets + 3 Levenshtein per candidate, "
+                                              "barcode_graph.py:207-249) on a %d-row subset, OpenMP over %d cores; the work per row "
+                                              "grows with the row count, so this rate is an upper bound for %d rows" % (m, cores, n)}
+        print(json.dumps(line))
 
 
 def main():
@@ -60,13 +272,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU (weak scaling)")
     ap.add_argument("--whitelist", type=int, default=737280)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
+                    help="BASELINE.json config: 2 = the headline (K1 + K2), 3 = graph thr 1, 5 = graph thr 2")
+    ap.add_argument("--rows", type=int, default=500000, help="distinct barcodes for --config 3 / 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     rank, local_rank, world = bdist.env_rank()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+            sys.exit(spawn_ranks(args.gpus))           # before anything here touches a GPU
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -78,7 +293,17 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     bdist.init(backend=backend, device=dev)           # RCCL; only the barrier and the clock use it
+    try:
+        if args.config in (3, 5):
+            bench_graph(args, rank, world, dev, local_dev)
+        else:
+            bench_calls(args, rank, world, dev, local_dev)
+    finally:
+        if world > 1 and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
 
+
+def bench_calls(args, rank, world, dev, local_dev):
     # ---- inputs, resident in HBM before the clock starts
     wl = synth.make_whitelist(args.whitelist)
     bases, off = synth.make_reads(args.reads, wl, seed=1 + rank, device=dev)
@@ -117,34 +342,33 @@ def main():
     prof = ctx.profile_read()
     ctx.profile(False)
 
+    # ---- the timed steps must have been clean, and their output right (every rank checks its own)
+    rc, bad, nwin = ctx.extract_status()
+    status = "ok" if rc == 0 else "extract status after the timed region: rc=%d bad_read=%d" % (rc, bad)
+    if status == "ok":
+        status = parity_sample(ctx, bases, off_u, n, wl, recs, best_idx, best_ed, n_ties)
+    fails = bdist.all_max(0.0 if status == "ok" else 1.0, dev)
+    if status != "ok":
+        sys.stderr.write("rank %d: %s\n" % (rank, status))
+    if fails:
+        raise SystemExit("parity sample failed")
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n / (elapsed / args.steps)
         # roofline of the dominant kernel: algorithmic bytes of the unit it serves / its own launch time
         k1 = ("k_scan_reads", "k_sw_clusters", "k_sw_requeued", "k_sw_survivors", "k_strict_filter", "k_finalize_reads")
-        per_launch_ms = {k: v[1] / max(1, v[0]) for k, v in prof.items()}
+        per_launch_ms = {k: v[1] / max(1, v[0]) for k, v in prof.items() if v[0]}
         dom = max(per_launch_ms, key=per_launch_ms.get)
         k1_bytes = total_bytes + 40 * n                # sum(L_i) + 8 (offset) + 32 (record) per read
         k2_bytes = 11 * n + 4 * len(wl)                # 4 (query) + 7 (idx, ed, ties) per call + whitelist once
         alg = k1_bytes if dom in k1 else k2_bytes
         achieved = alg / (per_launch_ms[dom] * 1e-3) / 1e9
-        # from the committed rocprofv3 PMC passes (tools/pmc_profile.sh -> tools/summarize_profile.py): HBM bytes and
-        # vector instructions of one launch of that kernel
-        traffic, valu = None, None
-        for name in ("traffic.json", "valu.json"):
-            f = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(f):
-                try:
-                    v = json.load(open(f)).get(dom)
-                except Exception:
-                    v = None
-                if name == "traffic.json":
-                    traffic = v
-                else:
-                    valu = v
+        pc = profile_counters(dom)
         # the path is integer-issue bound, so say how close the kernel is to THAT ceiling:
         # 1024 SIMDs, one wave64 VALU instruction per 4 clocks each, at the 2.4 GHz peak clock
         issue_peak = 1024 * 2.4e9 / 4.0
+        valu = pc["valu"]
         int_issue = None if valu is None else {"valu_insts_per_launch": valu, "achieved": valu / (per_launch_ms[dom] * 1e-3),
                                                "peak": issue_peak, "unit": "wave-instr/s",
                                                "frac": valu / (per_launch_ms[dom] * 1e-3) / issue_peak}
@@ -158,16 +382,16 @@ def main():
                        "reads_per_gpu": n, "whitelist": len(wl), "sw_windows_per_step": int(nwin), "pipeline_counts": stats,
                        "parallelism": "reads sharded per GPU, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pc["traffic"], "traffic_source": pc["source"],
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": per_launch_ms[dom], "int_issue": int_issue},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(per_launch_ms.items())},
+            "parity_sample": "ok",
         }
         if not args.no_cpu_baseline and world == 1:       # the CPU leg runs at N = 1 only (256 host threads would fight the other ranks)
-            line["cpu_baseline"] = cpu_baseline(bases, off_u, wl, 100000, 48)
+            line["cpu_baseline"] = cpu_baseline(bases, off_u, wl)
         print(json.dumps(line))
     if world > 1:
         bdist.barrier(dev)
-        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

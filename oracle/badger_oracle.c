@@ -537,3 +537,90 @@ void orc_nearest16(const uint32_t* q, uint32_t nq, const uint32_t* wl, uint32_t 
         n_ties[i] = (uint16_t)(ties > 0xFFFFu ? 0xFFFFu : ties);
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* The same operator for max_ed <= 2 by neighbourhood enumeration: the */
+/* query, its 48 substitution neighbours, its 1080 double substitutions */
+/* and its 1024 delete-one-insert-one variants are looked up in a hash  */
+/* set of the whitelist (equal-length strings at Levenshtein distance 1 */
+/* differ by one substitution; at distance 2 by two substitutions or    */
+/* one deletion plus one insertion).  NOT the reference's algorithm     */
+/* (barcode_graph.py:376-384 scans every center): it is the CPU         */
+/* baseline of the same algorithm class as the GPU path, and it lets    */
+/* the tests check large samples.  Pinned by equality with              */
+/* orc_nearest16 (tests/test_oracle_golden.py).                         */
+/* ------------------------------------------------------------------ */
+typedef struct { uint32_t* slot; uint32_t mask; int shift; const uint32_t* wl; } wl_set;
+
+static inline int wl_find(const wl_set* s, uint32_t key, uint32_t* idx)
+{
+    uint32_t h = (key * 0x9E3779B1u) >> s->shift;
+    for (;;) {
+        uint32_t v = s->slot[h];
+        if (v == 0) return 0;
+        if (s->wl[v - 1] == key) { *idx = v - 1; return 1; }
+        h = (h + 1) & s->mask;
+    }
+}
+
+void orc_nearest16_probe(const uint32_t* q, uint32_t nq, const uint32_t* wl, uint32_t nw,
+                         uint32_t max_ed, uint32_t* best_idx, uint8_t* best_ed, uint16_t* n_ties,
+                         int threads)
+{
+    if (threads < 1) threads = 1;
+    if (max_ed > 2 || nw == 0) { orc_nearest16(q, nq, wl, nw, max_ed, best_idx, best_ed, n_ties, threads); return; }
+    int bits = 4;
+    while ((1ull << bits) < 2ull * nw) ++bits;
+    wl_set set;
+    set.slot = (uint32_t*)calloc((size_t)1 << bits, sizeof(uint32_t));
+    set.mask = (uint32_t)((1ull << bits) - 1); set.shift = 32 - bits; set.wl = wl;
+    for (uint32_t w = 0; w < nw; ++w) {                       /* distinct entries (the ABI requires it) */
+        uint32_t h = (wl[w] * 0x9E3779B1u) >> set.shift;
+        while (set.slot[h]) h = (h + 1) & set.mask;
+        set.slot[h] = w + 1;
+    }
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads)
+    for (int64_t i = 0; i < (int64_t)nq; ++i) {
+        const uint32_t a = q[i];
+        uint32_t idx = 0xFFFFFFFFu, found; int best = 255; uint32_t ties = 0;
+        if (wl_find(&set, a, &found)) { best = 0; idx = found; ties = 1; }
+        if (best == 255 && max_ed >= 1) {
+            for (int p = 0; p < 16; ++p)
+                for (uint32_t x = 1; x < 4; ++x)
+                    if (wl_find(&set, a ^ (x << (2 * p)), &found)) { best = 1; ties++; if (found < idx) idx = found; }
+        }
+        if (best == 255 && max_ed >= 2) {
+            uint32_t seen[256]; uint32_t ns = 0; int overflow = 0;
+            for (int p = 0; p < 16 && !overflow; ++p)
+                for (int r = p + 1; r < 16; ++r)
+                    for (uint32_t x = 1; x < 4; ++x)
+                        for (uint32_t y = 1; y < 4; ++y)
+                            if (wl_find(&set, a ^ (x << (2 * p)) ^ (y << (2 * r)), &found)) {
+                                if (ns < 256) seen[ns++] = found; else overflow = 1;    /* distinct strings: no duplicates here */
+                            }
+            for (int p = 0; p < 16 && !overflow; ++p) {
+                const uint32_t lm = p ? ((1u << (2 * p)) - 1u) : 0u;
+                const uint32_t d15 = ((a & lm) | ((a >> 2) & ~lm)) & 0x3FFFFFFFu;                 /* base p deleted */
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t km = k ? ((1u << (2 * k)) - 1u) : 0u;
+                    for (uint32_t c = 0; c < 4; ++c) {
+                        const uint32_t b = (d15 & km) | (c << (2 * k)) | ((d15 & ~km) << 2);   /* letter c inserted at k */
+                        if (b == a || !wl_find(&set, b, &found)) continue;
+                        int dup = 0;
+                        for (uint32_t t = 0; t < ns; ++t) if (seen[t] == found) { dup = 1; break; }
+                        if (!dup) { if (ns < 256) seen[ns++] = found; else overflow = 1; }
+                    }
+                }
+            }
+            if (overflow) {                                    /* a crowd of neighbours: settle it exhaustively */
+                orc_nearest16(&a, 1, wl, nw, max_ed, &best_idx[i], &best_ed[i], &n_ties[i], 1);
+                continue;
+            }
+            if (ns) { best = 2; ties = ns; for (uint32_t t = 0; t < ns; ++t) if (seen[t] < idx) idx = seen[t]; }
+        }
+        if (best > (int)max_ed) { best = 255; idx = 0xFFFFFFFFu; ties = 0; }
+        best_idx[i] = idx; best_ed[i] = (uint8_t)best;
+        n_ties[i] = (uint16_t)(ties > 0xFFFFu ? 0xFFFFu : ties);
+    }
+    free(set.slot);
+}

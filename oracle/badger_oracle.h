@@ -108,6 +108,13 @@ void orc_nearest16(const uint32_t* q, uint32_t nq, const uint32_t* wl, uint32_t 
                    uint32_t max_ed, uint32_t* best_idx, uint8_t* best_ed, uint16_t* n_ties,
                    int threads);
 
+/* Same answers for max_ed <= 2 by enumerating the query's edit neighbourhood against a hash set of the
+ * whitelist (larger max_ed falls through to orc_nearest16).  Not the reference's algorithm: the CPU baseline of
+ * the GPU path's algorithm class and a fast checker for large samples; pinned by equality with orc_nearest16. */
+void orc_nearest16_probe(const uint32_t* q, uint32_t nq, const uint32_t* wl, uint32_t nw,
+                         uint32_t max_ed, uint32_t* best_idx, uint8_t* best_ed, uint16_t* n_ties,
+                         int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,8 @@ def lib():
     L.orc_nearest16.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.orc_nearest16.restype = None
+    L.orc_nearest16_probe.argtypes = L.orc_nearest16.argtypes
+    L.orc_nearest16_probe.restype = None
     _LIB = L
     return L
 
@@ -190,12 +192,13 @@ def graph_edges(ranks, thr, qgram_T=None, threads=1, brute=False):
         cap = int(tot)
 
 
-def nearest16(q, wl, max_ed=2, threads=1):
+def nearest16(q, wl, max_ed=2, threads=1, probe=False):
+    """probe=True: neighbourhood enumeration against a hash set (max_ed <= 2), same answers as the exhaustive scan"""
     q = np.ascontiguousarray(q, dtype=np.uint32)
     wl = np.ascontiguousarray(wl, dtype=np.uint32)
     idx = np.zeros(len(q), dtype=np.uint32)
     ed = np.zeros(len(q), dtype=np.uint8)
     ties = np.zeros(len(q), dtype=np.uint16)
-    lib().orc_nearest16(q.ctypes.data, len(q), wl.ctypes.data, len(wl), max_ed,
-                        idx.ctypes.data, ed.ctypes.data, ties.ctypes.data, threads)
+    fn = lib().orc_nearest16_probe if probe else lib().orc_nearest16
+    fn(q.ctypes.data, len(q), wl.ctypes.data, len(wl), max_ed, idx.ctypes.data, ed.ctypes.data, ties.ctypes.data, threads)
     return idx, ed, ties

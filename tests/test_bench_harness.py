@@ -1,0 +1,60 @@
+"""bench.py plumbing that must hold without a GPU: the self-launch for --gpus N > 1 starts torch.distributed.run as a
+child (and does nothing else), and committed PMC numbers are only reported for the build they were measured on."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def test_spawn_ranks_builds_a_torchrun_child(monkeypatch):
+    seen = {}
+
+    def fake_call(cmd):
+        seen["cmd"] = cmd
+        return 7
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench.spawn_ranks(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+
+
+def test_main_self_launches_before_touching_the_gpu(monkeypatch):
+    """world size 1 in the environment and --gpus 2 on the command line: spawn and exit with the child's code;
+    torch.cuda.is_available() (which initialises the GPU) must not have been called."""
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(bench, "spawn_ranks", lambda n: 0)
+
+    def boom():
+        raise AssertionError("GPU touched before the spawn")
+
+    monkeypatch.setattr(bench.torch.cuda, "is_available", boom)
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    else:
+        raise AssertionError("main() should exit with the child's code")
+
+
+def test_profile_counters_only_for_the_measured_build(monkeypatch, tmp_path):
+    lib = bench._native.load().bdg_version().decode()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    json.dump({"k_scan_reads": 123.0, "_meta": {"lib": "some other build", "tag": "old"}}, open(prof / "traffic.json", "w"))
+    json.dump({"k_scan_reads": 9.0, "_meta": {"lib": lib, "tag": "new"}}, open(prof / "valu.json", "w"))
+    pc = bench.profile_counters("k_scan_reads")
+    assert pc["traffic"] is None and pc["valu"] == 9.0
+    json.dump({"k_scan_reads": 123.0, "_meta": {"lib": lib, "tag": "new"}}, open(prof / "traffic.json", "w"))
+    pc = bench.profile_counters("k_scan_reads")
+    assert pc["traffic"] == 123.0 and "new" in pc["source"]

@@ -185,3 +185,43 @@ def test_nearest16_small():
     far = ed > 2
     assert (ed2[far] == 255).all() and (idx2[far] == 0xFFFFFFFF).all() and (ties2[far] == 0).all()
     assert (ed2[~far] == ed[~far]).all() and (idx2[~far] == idx[~far]).all()
+
+
+def test_nearest16_probe_form_equals_exhaustive_scan():
+    """The oracle's neighbourhood-probe nearest16 (CPU baseline of bench.py, large-sample checker) gives exactly what
+    the exhaustive Levenshtein scan (barcode_graph.py:376-384 as an operator) gives: index, distance, tie count."""
+    rng = np.random.default_rng(5)
+    wl = rng.permutation(np.unique(rng.integers(0, 1 << 32, 60000, dtype=np.uint64).astype(np.uint32)))     # caller order, not sorted
+    nq = 400
+    src = wl[rng.integers(0, len(wl), nq)].astype(np.uint64)
+    kind = rng.integers(0, 6, nq)
+    q = src.copy()
+    for rounds, sel in ((1, kind == 1), (2, kind == 2), (3, kind == 3)):
+        for _ in range(rounds):
+            q = np.where(sel, q ^ (rng.integers(1, 4, nq).astype(np.uint64) << (2 * rng.integers(0, 16, nq).astype(np.uint64))), q)
+    pos = rng.integers(0, 16, nq).astype(np.uint64)
+    low = (np.uint64(1) << (np.uint64(2) * pos)) - np.uint64(1)
+    dele = (q & low) | ((q >> np.uint64(2)) & ~low & np.uint64(0x3FFFFFFF)) | (rng.integers(0, 4, nq).astype(np.uint64) << np.uint64(30))
+    q = np.where(kind == 4, dele, q)
+    q = np.where(kind == 5, rng.integers(0, 1 << 32, nq, dtype=np.uint64), q).astype(np.uint32)
+    for max_ed in (0, 1, 2, 3):
+        a = orc.nearest16(q, wl, max_ed, threads=4)
+        b = orc.nearest16(q, wl, max_ed, threads=4, probe=True)
+        assert all((x == y).all() for x, y in zip(a, b)), max_ed
+    # a crowded whitelist: many entries one substitution apart, ties everywhere
+    cells = rng.integers(0, 1 << 32, 20, dtype=np.uint64)
+    dense = np.unique(np.concatenate([c ^ (rng.integers(0, 4, 300).astype(np.uint64) << (2 * rng.integers(0, 16, 300).astype(np.uint64)))
+                                      for c in cells]).astype(np.uint32))
+    dense = rng.permutation(dense)
+    qd = dense[rng.integers(0, len(dense), 300)] ^ (np.uint32(1) << (2 * rng.integers(0, 16, 300)).astype(np.uint32))
+    a = orc.nearest16(qd, dense, 2, threads=4)
+    b = orc.nearest16(qd, dense, 2, threads=4, probe=True)
+    assert all((x == y).all() for x, y in zip(a, b))
+    # 42 entries one substitution (positions 0..13) off a centre that is not itself an entry; the centre with its last base
+    # changed is two substitutions from each of them
+    c = np.uint32(0x1B2C3D4E)
+    ring = np.array([c ^ np.uint32(x << (2 * p)) for p in range(14) for x in (1, 2, 3)], dtype=np.uint32)
+    for qq in (c ^ np.uint32(1 << 30), c):
+        a = orc.nearest16(np.array([qq], np.uint32), ring, 2, threads=1)
+        b = orc.nearest16(np.array([qq], np.uint32), ring, 2, threads=1, probe=True)
+        assert all((x == y).all() for x, y in zip(a, b)) and a[2][0] == 42 and a[0][0] == 0

@@ -49,12 +49,18 @@ for k, s in summary.items():
         s["hbm_bytes_fetch_x1"] = rd1 + wr
         s["hbm_bytes_fetch_x2"] = 2 * rd1 + wr
         traffic[k] = s["hbm_bytes_fetch_x2"] if k in STREAMING else s["hbm_bytes_fetch_x1"]
+sys.path.insert(0, ROOT)
+from badger_amd import _native  # noqa: E402  (dlopen only: which build of the library the counters belong to)
+meta = {"lib": _native.load().bdg_version().decode(), "tag": tag}
+traffic["_meta"] = meta
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(summary, open(os.path.join(ROOT, "profiles", tag + "_summary.json"), "w"), indent=1, sort_keys=True)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
-json.dump({k: s["SQ_INSTS_VALU"] for k, s in summary.items() if "SQ_INSTS_VALU" in s},
-          open(os.path.join(ROOT, "profiles", "valu.json"), "w"), indent=1, sort_keys=True)
+valu = {k: s["SQ_INSTS_VALU"] for k, s in summary.items() if "SQ_INSTS_VALU" in s}
+valu["_meta"] = meta
+json.dump(valu, open(os.path.join(ROOT, "profiles", "valu.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(summary):
     s = summary[k]
     print("%-26s avg %8.1f us  VALU %6.1fM  hbm %s" % (k, s.get("avg_ns", 0) / 1e3, s.get("SQ_INSTS_VALU", 0) / 1e6,
                                                      ("%.3f GB" % (traffic[k] / 1e9)) if k in traffic else "-"))
+print("library:", meta["lib"])
