@@ -21,6 +21,7 @@ EDGE_DTYPE = np.dtype([("a", "<u4"), ("b", "<u4"), ("dist", "<u4")])
 FLAG_REV = 1
 FLAG_RANK_OK = 2
 FLAG_BC16 = 4
+FLAG_INCOMPLETE = 8
 NONE_IDX = 0xFFFFFFFF
 
 E_ARG, E_HIP, E_NOMEM, E_CAPACITY, E_BADBASE = -1, -2, -3, -4, -5
@@ -28,7 +29,7 @@ E_ARG, E_HIP, E_NOMEM, E_CAPACITY, E_BADBASE = -1, -2, -3, -4, -5
 EXPORTS = [
     "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_set_stream", "bdg_synchronize",
     "bdg_profile_enable", "bdg_profile_reset", "bdg_profile_read",
-    "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters",
+    "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
 ]
@@ -77,6 +78,7 @@ def load():
     L.bdg_extract_batch_dev.argtypes = [vp, vp, vp, u32, u64, u32, vp]
     L.bdg_extract_status.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.bdg_extract_counters.argtypes = [vp, C.POINTER(u64)]
+    L.bdg_extract_set_queue_capacity.argtypes = [vp, u64]
     L.bdg_nearest16.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp, vp]
     L.bdg_whitelist_load.argtypes = [vp, vp, u32]
     L.bdg_nearest16_dev.argtypes = [vp, vp, u32, u32, vp, vp, vp]
@@ -162,6 +164,10 @@ class Context:
         bad, nwin = C.c_uint64(), C.c_uint64()
         rc = self.lib.bdg_extract_status(self.h, C.byref(bad), C.byref(nwin))
         return rc, bad.value, nwin.value
+
+    def extract_set_queue_capacity(self, entries_per_segment):
+        """entries per segment of the internal candidate queues (0 = automatic); an overflow grows it again"""
+        self._check(self.lib.bdg_extract_set_queue_capacity(self.h, entries_per_segment))
 
     def extract_counters(self):
         out = (C.c_uint64 * 8)()

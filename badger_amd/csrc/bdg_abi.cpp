@@ -183,6 +183,15 @@ int bdg_extract_status(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_windows)
     return bdg_extract_status_impl(ctx, bad_read, n_windows);
 }
 
+int bdg_extract_set_queue_capacity(bdg_ctx* ctx, uint64_t entries_per_segment)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (entries_per_segment > (1ull << 32)) return bdg_fail(ctx, BDG_E_ARG, "queue capacity too large");
+    ctx->x_hits_cap_fixed = entries_per_segment;
+    if (entries_per_segment == 0) ctx->x_hits_cap = 0;
+    return BDG_OK;
+}
+
 int bdg_extract_counters(bdg_ctx* ctx, uint64_t out[8])
 {
     if (!ctx || !out) return BDG_E_ARG;
@@ -212,13 +221,15 @@ int bdg_extract_batch(bdg_ctx* ctx, const uint8_t* bases, const uint64_t* off, u
     hipStream_t st = ctx->stream;
     if (total) BDG_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_in0.p, bases + lo, total, hipMemcpyHostToDevice, st));
     BDG_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_in1.p, rel.data(), sizeof(uint64_t) * rel.size(), hipMemcpyHostToDevice, st));
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // A queue overflow grows the workspace from what the failed pass could count; the hits re-queued by clusters are only
+    // known once queue A is complete, so a second overflow is possible: loop (each pass at least 1.5 x the last one).
+    for (int attempt = 0; attempt < 8; ++attempt) {
         rc = bdg_extract_launch(ctx, static_cast<const uint8_t*>(ctx->s_in0.p), static_cast<const uint64_t*>(ctx->s_in1.p),
                                 n, total, umi_len, static_cast<bdg_extract_rec*>(ctx->s_out0.p));
         if (rc) return rc;
         uint64_t bad = 0, nwin = 0;
         rc = bdg_extract_status_impl(ctx, &bad, &nwin);
-        if (rc != BDG_E_CAPACITY) break;          // queue overflow: workspace grown, run again
+        if (rc != BDG_E_CAPACITY) break;
     }
     if (rc) return rc;
     BDG_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->s_out0.p, sizeof(bdg_extract_rec) * (size_t)n, hipMemcpyDeviceToHost, st));

@@ -41,6 +41,7 @@ struct bdg_ctx {
     DevBuf x_hits;       // uint64 [hits_cap]
     DevBuf x_counters;   // uint64 [8]
     uint64_t x_hits_cap = 0;
+    uint64_t x_hits_cap_fixed = 0;     // bdg_extract_set_queue_capacity (0 = automatic)
     void* x_counters_host = nullptr;   // pinned mirror
     // host-buffer staging
     DevBuf s_in0, s_in1, s_out0;
@@ -54,7 +55,10 @@ struct bdg_ctx {
     size_t w_pwords = 0;
     DevBuf w_delmap;     // 2^30 bits: every 15-mer deletion variant of the whitelist
     DevBuf w_dv;         // the same variants as (variant, sorted-whitelist position) pairs sorted by variant, + directory
-    uint32_t w_n = 0;
+    uint32_t w_n = 0;        // 0: no whitelist loaded (set last, after every table of the list is complete)
+    uint64_t w_fp = 0;       // fingerprint of the caller's list: the same list again is not rebuilt
+    bool w_probe_ready = false;                       // pair tables / deletion variants built (on first use of the probe path)
+    std::vector<uint32_t> w_host_sorted, w_host_order;  // host copy the probe index is built from
     int w_pbits = 0, w_bbits = 0;
     bool w_identity = false;
     int n16_algo = 0;

@@ -1146,10 +1146,33 @@ void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                       const uint64_t* __restrict__ off, uint32_t n,
                       const int32_t* __restrict__ polyt,
                       const unsigned long long* __restrict__ keys,
+                      const unsigned long long* __restrict__ counters, uint64_t qcap,
                       uint32_t umi_len, bdg_extract_rec* __restrict__ out)
 {
     const uint64_t r = (uint64_t)blockIdx.x * 256ull + threadIdx.x;
     const bool active = r < n;
+    // A queue that overflowed dropped alignment candidates: no record of this batch can be trusted.  Every record is
+    // then written as "not extracted, batch incomplete", so that whatever consumes the records next on the stream
+    // (bdg_nearest16_recs_dev, bdg_distinct_dev) sees nothing usable; bdg_extract_status() reports BDG_E_CAPACITY.
+    __shared__ uint32_t s_over;
+    if (threadIdx.x == 0) s_over = 0u;
+    __syncthreads();
+    if (threadIdx.x < NSH) {
+        const unsigned long long ab = *ctr(const_cast<unsigned long long*>(counters), threadIdx.x, K_NAB);
+        const unsigned long long c = *ctr(const_cast<unsigned long long*>(counters), threadIdx.x, K_NC);
+        const unsigned long long d = *ctr(const_cast<unsigned long long*>(counters), threadIdx.x, K_ND);
+        if ((ab & 0xFFFFFFFFull) > qcap || (ab >> 32) > qcap || c > qcap || d > qcap) s_over = 1u;
+    }
+    __syncthreads();
+    if (s_over) {
+        if (active) {
+            bdg_extract_rec rec;
+            rec.polyT = -1; rec.r1_end = -1; rec.bc_start = -1; rec.umi_start = -1; rec.umi_end = -1; rec.bc_rank = 0;
+            rec.r1_score = 0; rec.strand = 0; rec.valid = 0; rec.flags = BDG_FLAG_INCOMPLETE; rec.reserved = 0;
+            out[r] = rec;
+        }
+        return;
+    }
     uint64_t rs = 0; int64_t L = 0;
     int32_t ptF = -1, ptR = -1; uint64_t krF = 0, krR = 0, ksF = 0, ksR = 0;
     if (active) {
@@ -1240,8 +1263,9 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     // 16 B per entry, each made of NSH segments of x_hits_cap entries
     uint64_t want = (total_bytes / 48 + 4096 + NSH - 1) / NSH;
     if (want < ctx->x_hits_cap) want = ctx->x_hits_cap;
+    if (ctx->x_hits_cap_fixed) want = ctx->x_hits_cap_fixed;   // the caller's choice (bdg_extract_set_queue_capacity) until an overflow grows it
     if ((rc = bdg_reserve(ctx, ctx->x_hits, sizeof(QEnt) * 3ull * NSH * want))) return rc;
-    ctx->x_hits_cap = ctx->x_hits.bytes / sizeof(QEnt) / (3 * NSH);
+    ctx->x_hits_cap = ctx->x_hits_cap_fixed ? want : ctx->x_hits.bytes / sizeof(QEnt) / (3 * NSH);
     const uint64_t qcap = ctx->x_hits_cap;                     // per segment
     QEnt* qa = static_cast<QEnt*>(ctx->x_hits.p);
     QEnt* qb = qa + NSH * qcap;
@@ -1288,7 +1312,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
         ScopedKernelTimer tm(ctx, "k_finalize_reads");
         hipLaunchKernelGGL(k_finalize_reads, dim3((n + 255) / 256), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
                            static_cast<const int32_t*>(ctx->x_polyt.p),
-                           static_cast<const unsigned long long*>(ctx->x_keys.p), umi_len, d_out);
+                           static_cast<const unsigned long long*>(ctx->x_keys.p), counters, qcap, umi_len, d_out);
     }
     BDG_HIP_TRY(ctx, hipGetLastError());
     return BDG_OK;
@@ -1326,9 +1350,13 @@ int bdg_extract_status_impl(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_window
     if (bad_read) *bad_read = bad;
     if (n_windows) *n_windows = cs.stat[S_NWINDOWS];
     if (cs.a_max > ctx->x_hits_cap || cs.b_max > ctx->x_hits_cap || cs.c_max > ctx->x_hits_cap) {
+        // Queues A and B counted every entry they were offered, so their true sizes are known now; queue C (hits re-queued
+        // by clusters of A) was fed from a truncated A and may be under-counted: leave room, and the caller loops.
         uint64_t want = cs.a_max > cs.b_max ? cs.a_max : cs.b_max;
-        want = (want > cs.c_max ? want : cs.c_max) + 4096;    // queue D (filter survivors) never exceeds queue B
+        want = (want > cs.c_max ? want : cs.c_max);
+        want += want / 2 + 4096;           // queue D (filter survivors) never exceeds queue B
         ctx->x_hits_cap = want;            // next launch reserves this much per segment
+        ctx->x_hits_cap_fixed = 0;
         return bdg_fail(ctx, BDG_E_CAPACITY, "window queue overflow: rerun the batch (workspace grown)");
     }
     if (bad != ~0ull)

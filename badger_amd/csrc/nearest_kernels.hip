@@ -358,9 +358,23 @@ void k_nearest_delins(const uint2* __restrict__ list2,
 }  // namespace
 
 // ---------------------------------------------------------------------------
+static uint64_t wl_fingerprint(const uint32_t* wl, uint32_t nw)
+{
+    uint64_t h = 0xCBF29CE484222325ull ^ nw;                 // FNV-1a over the words, in caller order
+    for (uint32_t i = 0; i < nw; ++i) { h ^= wl[i]; h *= 0x100000001B3ull; }
+    return h ? h : 1;
+}
+
+static int build_probe_index(bdg_ctx* ctx);
+
 int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
 {
-    if (nw == 0) { ctx->w_n = 0; return BDG_OK; }
+    // the same list again (bdg_nearest16 is called per batch with the same centres): everything is still in place
+    const uint64_t fp = nw ? wl_fingerprint(wl, nw) : 0;
+    if (nw && ctx->w_n == nw && ctx->w_fp == fp) return BDG_OK;
+    // nothing is published until every table of the new list is complete: a failure below leaves "no whitelist loaded"
+    ctx->w_n = 0; ctx->w_fp = 0; ctx->w_probe_ready = false;
+    if (nw == 0) return BDG_OK;
     std::vector<uint32_t> order(nw);
     std::iota(order.begin(), order.end(), 0u);
     bool sorted_in = true;
@@ -390,8 +404,22 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
     BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_orig.p, order.data(), sizeof(uint32_t) * nw, hipMemcpyHostToDevice));
     BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_prefix.p, prefix.data(), sizeof(uint32_t) * prefix.size(), hipMemcpyHostToDevice));
     BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_bitmap.p, bitmap.data(), sizeof(uint32_t) * bitmap.size(), hipMemcpyHostToDevice));
-    ctx->w_n = nw; ctx->w_pbits = pbits; ctx->w_bbits = bbits;
+    ctx->w_pbits = pbits; ctx->w_bbits = bbits;
+    ctx->w_host_sorted.swap(srt);
+    ctx->w_host_order.swap(order);
+    ctx->w_n = nw; ctx->w_fp = fp;            // the scan path is usable from here; the probe index is built on first use
+    return BDG_OK;
+}
 
+// The neighbourhood-probe index (pair tables, deletion-variant map and sorted variant pairs): ~180 MB of tables for
+// 737K entries.  Built when the probe path first runs on a whitelist, not by bdg_whitelist_load: a call with
+// max_ed > 2 or a forced scan never needs it.
+static int build_probe_index(bdg_ctx* ctx)
+{
+    const uint32_t nw = ctx->w_n;
+    const std::vector<uint32_t>& srt = ctx->w_host_sorted;
+    const std::vector<uint32_t>& order = ctx->w_host_order;
+    int rc;
     // six block-pair tables as chains of 16-word blocks (see PairTables)
     std::vector<uint32_t> prank(6ull * 65536ull * 16ull, 0u), pidx(6ull * 65536ull * 16ull, 0u);
     for (int p = 0; p < 6; ++p) {
@@ -450,6 +478,7 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
         BDG_HIP_TRY(ctx, e);
     }
     BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->w_probe_ready = true;
     return BDG_OK;
 }
 
@@ -471,6 +500,7 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t qstride, in
         return BDG_OK;
     }
     int rc;
+    if (!ctx->w_probe_ready && (rc = build_probe_index(ctx))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->n_list, sizeof(uint32_t) * (2ull * LSH + 1ull) * nq))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->n_counters, NCTR_BYTES))) return rc;
     auto* list2 = static_cast<uint2*>(ctx->n_list.p);                          // LSH segments of nq {index, query} entries

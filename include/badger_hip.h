@@ -68,6 +68,8 @@ typedef struct bdg_extract_rec {
 #define BDG_FLAG_REV      1u  /* result comes from reverese_complement(read)          */
 #define BDG_FLAG_RANK_OK  2u  /* bc_rank is valid: 16 in-range ACGT bases             */
 #define BDG_FLAG_BC16     4u  /* the barcode slice holds 16 bases (some may be N)     */
+#define BDG_FLAG_INCOMPLETE 8u /* the batch overflowed an internal queue: this record (like every record of the
+                                  batch) is a placeholder with valid = 0; bdg_extract_status() returns BDG_E_CAPACITY */
 
 typedef struct bdg_edge {
     uint32_t a;          /* rank, a < b */
@@ -106,14 +108,22 @@ int  bdg_extract_batch(bdg_ctx* ctx, const uint8_t* bases, const uint64_t* off, 
                        uint32_t umi_len, bdg_extract_rec* out);
 /* Device-resident form.  d_bases must be 16-byte aligned and readable up to
  * total_bytes rounded up to 16 (any hipMalloc/torch allocation is).  Asynchronous;
- * a bad base is reported by the next bdg_extract_status(). */
+ * a bad base is reported by the next bdg_extract_status().
+ * Queue overflow: the alignment candidates of a batch pass through internal queues sized from the batch's byte
+ * count.  If one overflows (adapter-dense input), EVERY record of the batch is written as a placeholder
+ * {valid 0, flags BDG_FLAG_INCOMPLETE}: later device-side consumers of d_out (bdg_nearest16_recs_dev,
+ * bdg_distinct_dev) then find nothing to use instead of half-aligned records, bdg_extract_status() returns
+ * BDG_E_CAPACITY and has grown the workspace; call bdg_extract_batch_dev again (loop while BDG_E_CAPACITY:
+ * the second pass measures what the first could not; bdg_extract_batch does exactly that). */
 int  bdg_extract_batch_dev(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_off, uint32_t n,
                            uint64_t total_bytes, uint32_t umi_len, bdg_extract_rec* d_out);
 /* Synchronises and returns BDG_OK, BDG_E_BADBASE (read index in *bad_read) or
- * BDG_E_CAPACITY if the internal window queue overflowed (the host-buffer call
- * retries by itself; device callers call bdg_extract_batch_dev again, the
- * workspace has been grown). n_windows: Smith-Waterman windows evaluated. */
+ * BDG_E_CAPACITY (see above). n_windows: Smith-Waterman windows evaluated. */
 int  bdg_extract_status(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_windows);
+/* Entries per segment of the internal queues for the next launches (16 bytes each, 3 queues x 8 segments);
+ * 0 = automatic (total_bytes / 48 per queue).  An overflow still grows it.  For callers that must bound the
+ * workspace, and for tests of the overflow path. */
+int  bdg_extract_set_queue_capacity(bdg_ctx* ctx, uint64_t entries_per_segment);
 /* Pipeline statistics of the last extraction (synchronises): out[0] 6-mer hits, [1] clusters aligned
  * (queue A), [2] hits sent to the strict filter (queue B), [3] of those skipped because the
  * relaxed search had already succeeded, [4] filter survivors, [5] hits re-queued from clusters,

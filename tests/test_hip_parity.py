@@ -105,6 +105,68 @@ def test_extract_adversarial(ctx, orc):
     assert (got2 == orc.extract_batch(bases, off, 12, threads=8)[20:]).all()
 
 
+def test_extract_queue_overflow_is_contained_and_recovered(orc):
+    """Adapter-dense reads (concatemers) against a deliberately tiny candidate queue.  The host-buffer call loops until
+    the workspace fits and returns the oracle's records.  The device-resident call cannot loop by itself: an overflowing
+    batch must leave placeholder records only ({valid 0, BDG_FLAG_INCOMPLETE}), so that bdg_nearest16_recs_dev /
+    bdg_distinct_dev running behind it on the stream use nothing, bdg_extract_status says BDG_E_CAPACITY, and the
+    caller's rerun loop ends with the oracle's records."""
+    import torch
+    rng = np.random.default_rng(123)
+    R1 = "CTACACGACGCTCTTCCGATCT"
+    rnd = lambda k: "".join("ACGT"[i] for i in rng.integers(0, 4, k))
+    seqs = []
+    for k in range(600):
+        unit = rnd(int(rng.integers(0, 12))) + R1 + rnd(16) + rnd(12) + "T" * int(rng.integers(14, 32)) + rnd(int(rng.integers(0, 60)))
+        seqs.append(unit * int(rng.integers(1, 12)))
+    bases, off = synth.list_to_reads(seqs)
+    want = orc.extract_batch(bases, off, 12, threads=8)
+    assert want["valid"].mean() > 0.9
+    # host-buffer call
+    c = _native.Context(0)
+    c.extract_set_queue_capacity(16)
+    got = c.extract_batch(bases, off, 12)
+    assert (got == want).all(), _diff(got, want)
+    c.close()
+    # device-resident call
+    c = _native.Context(0)
+    dev = torch.device("cuda", 0)
+    c.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    wl = np.unique(want["bc_rank"][(want["flags"] & 2) != 0])
+    c.whitelist_load(wl)
+    n, total = len(seqs), int(off[-1])
+    d_bases = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    d_recs = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    bi = torch.zeros(n, dtype=torch.int32, device=dev)
+    be = torch.zeros(n, dtype=torch.uint8, device=dev)
+    bt = torch.zeros(n, dtype=torch.int16, device=dev)
+    uq = torch.zeros(n, dtype=torch.int32, device=dev)
+    uc = torch.zeros(n, dtype=torch.int32, device=dev)
+    uf = torch.zeros(n, dtype=torch.int32, device=dev)
+    dn = torch.zeros(2, dtype=torch.int32, device=dev)
+    c.extract_set_queue_capacity(16)
+    passes = 0
+    while True:
+        c.extract_batch_dev(d_bases, d_off, n, total, 12, d_recs)
+        c.nearest16_recs_dev(d_recs, n, 2, bi, be, bt)                 # enqueued before anybody looked at the status
+        c.distinct_dev(d_recs, n, uq, uc, uf, dn)
+        rc, bad, _ = c.extract_status()
+        passes += 1
+        recs = d_recs.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+        if rc != _native.E_CAPACITY:
+            break
+        assert passes < 8
+        assert (recs["valid"] == 0).all() and (recs["flags"] == _native.FLAG_INCOMPLETE).all()
+        assert (be.cpu().numpy() == 255).all() and (bi.cpu().numpy().view(np.uint32) == 0xFFFFFFFF).all()
+        assert int(dn[0]) == 0
+    assert rc == 0 and passes >= 2
+    assert (recs == want).all(), _diff(recs, want)
+    ok = (want["flags"] & 2) != 0
+    assert (be.cpu().numpy()[ok] == 0).all() and int(dn[0]) == len(wl)
+    c.close()
+
+
 def test_extract_empty_and_errors(ctx):
     assert len(ctx.extract_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))) == 0
     bases, off = synth.list_to_reads(["ACGT" * 30, "ACGTacgt" * 10, "ACGT" * 5])
