@@ -24,7 +24,8 @@ FLAG_BC16 = 4
 FLAG_INCOMPLETE = 8
 NONE_IDX = 0xFFFFFFFF
 
-E_ARG, E_HIP, E_NOMEM, E_CAPACITY, E_BADBASE = -1, -2, -3, -4, -5
+E_ARG, E_HIP, E_NOMEM, E_CAPACITY, E_BADBASE, E_FORMAT = -1, -2, -3, -4, -5, -6
+SLOTS = 4
 
 EXPORTS = [
     "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_set_stream", "bdg_synchronize",
@@ -32,11 +33,19 @@ EXPORTS = [
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
+    "bdg_extract_submit", "bdg_extract_collect",
+    "bdg_ingest_open", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error", "bdg_ingest_close", "bdg_format_rows",
 ]
 
 
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+class IngestChunk(C.Structure):
+    """bdg_ingest_chunk (include/badger_hip.h): one chunk of reads in (pinned) host memory"""
+    _fields_ = [("id", C.c_uint32), ("n", C.c_uint32), ("bases", C.c_void_p), ("off", C.c_void_p),
+                ("total_bytes", C.c_uint64), ("ids", C.c_void_p), ("id_off", C.c_void_p)]
 
 
 class BadgerHipError(RuntimeError):
@@ -89,6 +98,17 @@ def load():
     L.bdg_graph_edges_rows_dev.argtypes = [vp, vp, u32, u32, u32, u32, i32, vp, u64, vp]
     L.bdg_graph_set_algo.argtypes = [vp, C.c_int]
     L.bdg_distinct_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+    L.bdg_extract_submit.argtypes = [vp, u32, vp, vp, u32, u32]
+    L.bdg_extract_collect.argtypes = [vp, u32, vp]
+    L.bdg_ingest_open.argtypes = [C.c_char_p, u32, u32, C.c_int, C.POINTER(vp)]
+    L.bdg_ingest_next.argtypes = [vp, C.POINTER(IngestChunk)]
+    L.bdg_ingest_release.argtypes = [vp, u32]
+    L.bdg_ingest_error.argtypes = [vp]
+    L.bdg_ingest_error.restype = C.c_char_p
+    L.bdg_ingest_close.argtypes = [vp]
+    L.bdg_ingest_close.restype = None
+    L.bdg_format_rows.argtypes = [C.POINTER(IngestChunk), vp, vp, u64, C.POINTER(u64)]
+    L.bdg_format_rows.restype = C.c_int64
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("bdg_free",):
@@ -159,6 +179,16 @@ class Context:
     def extract_batch_dev(self, d_bases, d_off, n, total_bytes, umi_len, d_out):
         self._check(self.lib.bdg_extract_batch_dev(self.h, d_bases.data_ptr(), d_off.data_ptr(), n, total_bytes,
                                                    umi_len, d_out.data_ptr()))
+
+    def extract_submit(self, slot, bases_ptr, off_ptr, n, umi_len=12):
+        """enqueue one chunk (host pointers, best pinned) on staging set `slot`; returns at once"""
+        self._check(self.lib.bdg_extract_submit(self.h, slot, bases_ptr, off_ptr, n, umi_len))
+
+    def extract_collect(self, slot, n):
+        """wait for the chunk submitted to `slot` and return its records"""
+        out = np.zeros(n, dtype=REC_DTYPE)
+        self._check(self.lib.bdg_extract_collect(self.h, slot, out.ctypes.data))
+        return out
 
     def extract_status(self):
         bad, nwin = C.c_uint64(), C.c_uint64()
@@ -234,11 +264,64 @@ class Context:
                                               d_first.data_ptr(), d_n.data_ptr()))
 
 
+class Ingest:
+    """[gzipped] FASTA / FASTQ -> chunks of reads in pinned host memory, parsed by a native background thread
+    (bdg_ingest_*).  Iterating yields IngestChunk structures; release(chunk) hands the memory back to the parser."""
+
+    def __init__(self, path, chunk_reads=100000, ring_chunks=4, pinned=True):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.bdg_ingest_open(os.fsencode(path), chunk_reads, ring_chunks, 1 if pinned else 0, C.byref(h))
+        if rc != 0:
+            raise BadgerHipError(rc, "cannot read %s (unknown extension or unreadable file)" % path)
+        self.h = h
+
+    def next(self):
+        ch = IngestChunk()
+        rc = self.lib.bdg_ingest_next(self.h, C.byref(ch))
+        if rc == E_FORMAT:
+            raise ValueError(self.lib.bdg_ingest_error(self.h).decode())
+        if rc != 0:
+            raise BadgerHipError(rc, self.lib.bdg_ingest_error(self.h).decode())
+        return ch
+
+    def release(self, ch):
+        self.lib.bdg_ingest_release(self.h, ch.id)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bdg_ingest_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_rows(ch, recs):
+    """TSV rows of a chunk as bytes (one "\n"-terminated line per read) + (reads, barcodes, polyT, R1) counts"""
+    L = load()
+    recs = np.ascontiguousarray(recs)
+    counts = (C.c_uint64 * 4)()
+    need = L.bdg_format_rows(C.byref(ch), recs.ctypes.data, None, 0, counts)
+    if need < 0:
+        raise BadgerHipError(int(need), "bdg_format_rows")
+    buf = C.create_string_buffer(int(need) + 1)
+    got = L.bdg_format_rows(C.byref(ch), recs.ctypes.data, buf, int(need), counts)
+    if got < 0 or got > need:
+        raise BadgerHipError(int(got), "bdg_format_rows")
+    return buf.raw[:got], tuple(int(x) for x in counts)
+
+
 _DEFAULT = {}
 
 
-def default_context(device=0):
-    """Process-wide context per device (created on first use; raises without a GPU)."""
-    if device not in _DEFAULT:
-        _DEFAULT[device] = Context(device)
-    return _DEFAULT[device]
+def default_context(device=0, instance=0):
+    """Process-wide context per device (created on first use; raises without a GPU).  `instance` > 0 gives further,
+    independent contexts on the same device (each with its own stream and workspaces)."""
+    key = (device, instance)
+    if key not in _DEFAULT:
+        _DEFAULT[key] = Context(device)
+    return _DEFAULT[key]

@@ -160,19 +160,21 @@ class TenXBarcodeExtractor:
     TERMINAL_MATCH_DELTA = 4
     STRICT_TERMINAL_MATCH_DELTA = 1
 
-    def __init__(self, protocol_version=TenXVersions.v3, device=0):
+    def __init__(self, protocol_version=TenXVersions.v3, device=0, instance=0):
         self.UMI_LEN_10X = self.UMI_LENGTHS[protocol_version]
         self.device = device
+        self.instance = instance          # > 0: a further independent context on the same device
 
     # the detector is pickled to workers in the reference; keep it stateless and cheap
     def __getstate__(self):
-        return {"UMI_LEN_10X": self.UMI_LEN_10X, "device": self.device}
+        return {"UMI_LEN_10X": self.UMI_LEN_10X, "device": self.device, "instance": self.instance}
 
     def __setstate__(self, st):
         self.__dict__.update(st)
+        self.__dict__.setdefault("instance", 0)
 
     def _ctx(self):
-        return _native.default_context(self.device)
+        return _native.default_context(self.device, self.instance)
 
     def extract_records(self, sequences):
         """list[str] -> structured array of bdg_extract_rec (one device call)."""
@@ -205,10 +207,10 @@ class TenXBarcodeExtractor:
 
 
 class TenXBarcodeExtractorV2(TenXBarcodeExtractor):
-    def __init__(self, device=0):
-        TenXBarcodeExtractor.__init__(self, TenXVersions.v2, device)
+    def __init__(self, device=0, instance=0):
+        TenXBarcodeExtractor.__init__(self, TenXVersions.v2, device, instance)
 
 
 class TenXBarcodeExtractorV3(TenXBarcodeExtractor):
-    def __init__(self, device=0):
-        TenXBarcodeExtractor.__init__(self, TenXVersions.v3, device)
+    def __init__(self, device=0, instance=0):
+        TenXBarcodeExtractor.__init__(self, TenXVersions.v3, device, instance)

@@ -11,6 +11,8 @@
 int bdg_extract_launch(bdg_ctx*, const uint8_t*, const uint64_t*, uint32_t, uint64_t, uint32_t, bdg_extract_rec*);
 int bdg_extract_status_impl(bdg_ctx*, uint64_t*, uint64_t*);
 int bdg_extract_counters_impl(bdg_ctx*, uint64_t*);
+int bdg_extract_judge_host(bdg_ctx*, const void*, uint64_t, uint64_t*, uint64_t*);
+size_t bdg_extract_counter_bytes();
 int bdg_whitelist_load_impl(bdg_ctx*, const uint32_t*, uint32_t);
 int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, int, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
 int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*);
@@ -118,6 +120,13 @@ void bdg_free(bdg_ctx* ctx)
                        &ctx->s_in1, &ctx->s_out0, &ctx->w_sorted, &ctx->w_orig, &ctx->w_prefix, &ctx->w_bitmap, &ctx->w_pent, &ctx->w_delmap, &ctx->w_dv,
                        &ctx->n_list, &ctx->n_counters, &ctx->g_sig, &ctx->g_tmp0, &ctx->g_tmp1, &ctx->g_cnt, &ctx->g_qj };
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    for (auto& sl : ctx->slots) {
+        for (DevBuf* b : { &sl.d_bases, &sl.d_off, &sl.d_recs }) if (b->p) (void)hipFree(b->p);
+        if (sl.h_recs) (void)hipHostFree(sl.h_recs);
+        if (sl.h_off) (void)hipHostFree(sl.h_off);
+        if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     for (auto& t : ctx->timers) for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -234,6 +243,93 @@ int bdg_extract_batch(bdg_ctx* ctx, const uint8_t* bases, const uint64_t* off, u
     if (rc) return rc;
     BDG_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->s_out0.p, sizeof(bdg_extract_rec) * (size_t)n, hipMemcpyDeviceToHost, st));
     BDG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return BDG_OK;
+}
+
+// ---- pipelined chunks ---------------------------------------------------------
+static int pinned_reserve(bdg_ctx* ctx, void*& p, size_t& have, size_t want)
+{
+    if (want <= have && p) return BDG_OK;
+    if (p) { BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(p); p = nullptr; have = 0; }
+    want += want / 4 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return bdg_fail(ctx, BDG_E_NOMEM, "hipHostMalloc failed"); }
+    have = want;
+    return BDG_OK;
+}
+
+static int slot_enqueue(bdg_ctx* ctx, bdg_ctx::Slot& sl)
+{
+    int rc = bdg_extract_launch(ctx, static_cast<const uint8_t*>(sl.d_bases.p), static_cast<const uint64_t*>(sl.d_off.p),
+                                sl.n, sl.total, sl.umi_len, static_cast<bdg_extract_rec*>(sl.d_recs.p));
+    if (rc) return rc;
+    sl.qcap = ctx->x_hits_cap_launched;
+    hipStream_t st = ctx->stream;
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(sl.h_recs, sl.d_recs.p, sizeof(bdg_extract_rec) * (size_t)sl.n, hipMemcpyDeviceToHost, st));
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(sl.h_counters, ctx->x_counters.p, bdg_extract_counter_bytes(), hipMemcpyDeviceToHost, st));
+    BDG_HIP_TRY(ctx, hipEventRecord(sl.done, st));
+    return BDG_OK;
+}
+
+int bdg_extract_submit(bdg_ctx* ctx, uint32_t slot, const uint8_t* bases, const uint64_t* off, uint32_t n, uint32_t umi_len)
+{
+    if (!ctx || slot >= BDG_SLOTS) return BDG_E_ARG;
+    bdg_ctx::Slot& sl = ctx->slots[slot];
+    if (sl.busy) return bdg_fail(ctx, BDG_E_ARG, "slot still in flight: collect it first");
+    if (n && (!bases || !off)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    if (umi_len == 0 || umi_len > 64) return bdg_fail(ctx, BDG_E_ARG, "umi_len out of range");
+    sl.n = n; sl.umi_len = umi_len; sl.total = 0;
+    if (n == 0) { sl.busy = true; return BDG_OK; }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (off[i + 1] < off[i]) return bdg_fail(ctx, BDG_E_ARG, "offsets must be non-decreasing");
+        if (off[i + 1] - off[i] >= (1ull << 26)) return bdg_fail(ctx, BDG_E_ARG, "read longer than 2^26 bases");
+    }
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t lo = off[0], total = off[n] - lo;
+    sl.total = total;
+    int rc;
+    if ((rc = bdg_reserve(ctx, sl.d_bases, total + 64))) return rc;
+    if ((rc = bdg_reserve(ctx, sl.d_off, sizeof(uint64_t) * ((size_t)n + 1)))) return rc;
+    if ((rc = bdg_reserve(ctx, sl.d_recs, sizeof(bdg_extract_rec) * (size_t)n))) return rc;
+    if ((rc = pinned_reserve(ctx, sl.h_recs, sl.h_recs_bytes, sizeof(bdg_extract_rec) * (size_t)n))) return rc;
+    if ((rc = pinned_reserve(ctx, sl.h_off, sl.h_off_bytes, sizeof(uint64_t) * ((size_t)n + 1)))) return rc;
+    if (!sl.h_counters) {
+        if (hipHostMalloc(&sl.h_counters, bdg_extract_counter_bytes(), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError(); sl.h_counters = nullptr; return bdg_fail(ctx, BDG_E_NOMEM, "hipHostMalloc failed");
+        }
+    }
+    if (!sl.done) BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    uint64_t* rel = static_cast<uint64_t*>(sl.h_off);
+    for (uint32_t i = 0; i <= n; ++i) rel[i] = off[i] - lo;
+    hipStream_t st = ctx->stream;
+    if (total) BDG_HIP_TRY(ctx, hipMemcpyAsync(sl.d_bases.p, bases + lo, total, hipMemcpyHostToDevice, st));
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(sl.d_off.p, rel, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, st));
+    if ((rc = slot_enqueue(ctx, sl))) return rc;
+    sl.busy = true;
+    return BDG_OK;
+}
+
+int bdg_extract_collect(bdg_ctx* ctx, uint32_t slot, bdg_extract_rec* out)
+{
+    if (!ctx || slot >= BDG_SLOTS) return BDG_E_ARG;
+    bdg_ctx::Slot& sl = ctx->slots[slot];
+    if (!sl.busy) return bdg_fail(ctx, BDG_E_ARG, "nothing submitted to this slot");
+    sl.busy = false;
+    if (sl.n == 0) return BDG_OK;
+    if (!out) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = BDG_OK;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        BDG_HIP_TRY(ctx, hipEventSynchronize(sl.done));
+        uint64_t bad = 0, nwin = 0;
+        rc = bdg_extract_judge_host(ctx, sl.h_counters, sl.qcap, &bad, &nwin);
+        if (rc != BDG_E_CAPACITY) break;
+        // this chunk overflowed a queue: run it again (its input is still on the device) behind whatever is queued
+        int rc2 = slot_enqueue(ctx, sl);
+        if (rc2) return rc2;
+    }
+    if (rc) return rc;
+    memcpy(out, sl.h_recs, sizeof(bdg_extract_rec) * (size_t)sl.n);
     return BDG_OK;
 }
 

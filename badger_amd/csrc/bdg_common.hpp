@@ -42,9 +42,20 @@ struct bdg_ctx {
     DevBuf x_counters;   // uint64 [8]
     uint64_t x_hits_cap = 0;
     uint64_t x_hits_cap_fixed = 0;     // bdg_extract_set_queue_capacity (0 = automatic)
+    uint64_t x_hits_cap_launched = 0;  // capacity the last launch ran with
     void* x_counters_host = nullptr;   // pinned mirror
     // host-buffer staging
     DevBuf s_in0, s_in1, s_out0;
+    // pipelined chunks (bdg_extract_submit / collect)
+    struct Slot {
+        DevBuf d_bases, d_off, d_recs;
+        void* h_recs = nullptr; size_t h_recs_bytes = 0;     // pinned
+        void* h_off = nullptr;  size_t h_off_bytes = 0;      // pinned, offsets rebased to 0
+        void* h_counters = nullptr;                          // pinned snapshot of the batch's counters
+        hipEvent_t done = nullptr;
+        uint32_t n = 0, umi_len = 0; uint64_t total = 0, qcap = 0;
+        bool busy = false;
+    } slots[BDG_SLOTS];
 
     // ---- whitelist index (nearest_kernels.hip)
     DevBuf w_sorted;     // uint32 [nw] ranks ascending

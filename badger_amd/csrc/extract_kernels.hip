@@ -1267,6 +1267,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     if ((rc = bdg_reserve(ctx, ctx->x_hits, sizeof(QEnt) * 3ull * NSH * want))) return rc;
     ctx->x_hits_cap = ctx->x_hits_cap_fixed ? want : ctx->x_hits.bytes / sizeof(QEnt) / (3 * NSH);
     const uint64_t qcap = ctx->x_hits_cap;                     // per segment
+    ctx->x_hits_cap_launched = qcap;
     QEnt* qa = static_cast<QEnt*>(ctx->x_hits.p);
     QEnt* qb = qa + NSH * qcap;
     QEnt* qc = qb + NSH * qcap;
@@ -1321,14 +1322,11 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
 namespace {
 struct CounterSums { uint64_t a_max, b_max, c_max, a, b, c, d, bad, stat[S_N]; };
 
-int read_counters(bdg_ctx* ctx, CounterSums& cs)
+void sum_counters(const uint64_t* c, CounterSums& cs)
 {
-    std::vector<uint64_t> c(COUNTER_BYTES / 8);
-    BDG_HIP_TRY(ctx, hipMemcpyAsync(c.data(), ctx->x_counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
-    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memset(&cs, 0, sizeof(cs));
     for (int sh = 0; sh < NSH; ++sh) {
-        const uint64_t* w = c.data() + (size_t)sh * SH_WORDS;
+        const uint64_t* w = c + (size_t)sh * SH_WORDS;
         const uint64_t a = w[K_NAB * 16] & 0xFFFFFFFFull, b = w[K_NAB * 16] >> 32, cc = w[K_NC * 16];
         cs.a += a; cs.b += b; cs.c += cc; cs.d += w[K_ND * 16];
         cs.a_max = a > cs.a_max ? a : cs.a_max; cs.b_max = b > cs.b_max ? b : cs.b_max; cs.c_max = cc > cs.c_max ? cc : cs.c_max;
@@ -1336,9 +1334,48 @@ int read_counters(bdg_ctx* ctx, CounterSums& cs)
         cs.bad = st[S_BADREAD] > cs.bad ? st[S_BADREAD] : cs.bad;                 // max of ~index = smallest index
         for (int k = 1; k < S_N; ++k) cs.stat[k] += st[k];
     }
+}
+
+int read_counters(bdg_ctx* ctx, CounterSums& cs)
+{
+    std::vector<uint64_t> c(COUNTER_BYTES / 8);
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(c.data(), ctx->x_counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    sum_counters(c.data(), cs);
+    return BDG_OK;
+}
+
+// verdict on one batch from its counters (qcap: the queue capacity that batch ran with); grows the workspace on overflow
+int judge_counters(bdg_ctx* ctx, const CounterSums& cs, uint64_t qcap, uint64_t* bad_read, uint64_t* n_windows)
+{
+    const uint64_t bad = cs.bad ? ~cs.bad : ~0ull;
+    if (bad_read) *bad_read = bad;
+    if (n_windows) *n_windows = cs.stat[S_NWINDOWS];
+    if (cs.a_max > qcap || cs.b_max > qcap || cs.c_max > qcap) {
+        // Queues A and B counted every entry they were offered, so their true sizes are known now; queue C (hits re-queued
+        // by clusters of A) was fed from a truncated A and may be under-counted: leave room, and the caller loops.
+        uint64_t want = cs.a_max > cs.b_max ? cs.a_max : cs.b_max;
+        want = (want > cs.c_max ? want : cs.c_max);
+        want += want / 2 + 4096;           // queue D (filter survivors) never exceeds queue B
+        if (want > ctx->x_hits_cap) ctx->x_hits_cap = want;            // next launch reserves this much per segment
+        ctx->x_hits_cap_fixed = 0;
+        return bdg_fail(ctx, BDG_E_CAPACITY, "window queue overflow: rerun the batch (workspace grown)");
+    }
+    if (bad != ~0ull)
+        return bdg_fail(ctx, BDG_E_BADBASE, "read " + std::to_string(bad) + " holds a byte outside 'ACGTN'");
     return BDG_OK;
 }
 }  // namespace
+
+size_t bdg_extract_counter_bytes() { return COUNTER_BYTES; }
+
+// the same verdict from a host copy of the counters taken right behind a batch (bdg_extract_submit / collect)
+int bdg_extract_judge_host(bdg_ctx* ctx, const void* host_counters, uint64_t qcap, uint64_t* bad_read, uint64_t* n_windows)
+{
+    CounterSums cs;
+    sum_counters(static_cast<const uint64_t*>(host_counters), cs);
+    return judge_counters(ctx, cs, qcap, bad_read, n_windows);
+}
 
 int bdg_extract_status_impl(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_windows)
 {
@@ -1346,22 +1383,7 @@ int bdg_extract_status_impl(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_window
     CounterSums cs;
     int rc;
     if ((rc = read_counters(ctx, cs))) return rc;
-    const uint64_t bad = cs.bad ? ~cs.bad : ~0ull;
-    if (bad_read) *bad_read = bad;
-    if (n_windows) *n_windows = cs.stat[S_NWINDOWS];
-    if (cs.a_max > ctx->x_hits_cap || cs.b_max > ctx->x_hits_cap || cs.c_max > ctx->x_hits_cap) {
-        // Queues A and B counted every entry they were offered, so their true sizes are known now; queue C (hits re-queued
-        // by clusters of A) was fed from a truncated A and may be under-counted: leave room, and the caller loops.
-        uint64_t want = cs.a_max > cs.b_max ? cs.a_max : cs.b_max;
-        want = (want > cs.c_max ? want : cs.c_max);
-        want += want / 2 + 4096;           // queue D (filter survivors) never exceeds queue B
-        ctx->x_hits_cap = want;            // next launch reserves this much per segment
-        ctx->x_hits_cap_fixed = 0;
-        return bdg_fail(ctx, BDG_E_CAPACITY, "window queue overflow: rerun the batch (workspace grown)");
-    }
-    if (bad != ~0ull)
-        return bdg_fail(ctx, BDG_E_BADBASE, "read " + std::to_string(bad) + " holds a byte outside 'ACGTN'");
-    return BDG_OK;
+    return judge_counters(ctx, cs, ctx->x_hits_cap_launched, bad_read, n_windows);
 }
 
 int bdg_extract_counters_impl(bdg_ctx* ctx, uint64_t out[8])

@@ -6,21 +6,27 @@ extract_raw_barcodes.py (reference extract_raw_barcodes.py:360-391), MI355X unde
 
 What differs from the reference, by design:
   * reads are cut into chunks of 100,000 (READ_CHUNK_SIZE, reference :32) and each chunk is
-    ONE call into the HIP library; `--threads` no longer buys CPU parallelism.  It is kept
+    ONE batch on the GPU; `--threads` no longer buys CPU parallelism.  It is kept
     because it selects the reference's two output shapes: threads == 1 writes one header
     and a tab-separated .stats (reference :162-173); threads > 1 writes a header per chunk
     and a space-separated .stats (reference :243-259) -- here always in input order, where
     the reference concatenates chunks in completion order.
-  * new optional flags: --gpus (shard chunks round-robin over that many devices of the node).
-  * FASTA/FASTQ (optionally gzipped) are parsed here; BAM/SAM needs pysam like the reference.
+  * FASTA/FASTQ (optionally gzipped) go through the native pipeline (run_fastx_pipeline): a parser thread
+    fills pinned chunks, chunk k+1 is on its way to / on the GPU while the rows of chunk k are
+    formatted (natively) and written.  BAM/SAM needs pysam like the reference and takes the
+    plain chunk loop.
+  * new optional flag: --gpus N.  Chunk k goes to device k mod N; submission is asynchronous, so
+    the N devices work at the same time; rows are written in chunk order.
 """
 import argparse
 import gzip
 import logging
 import os
 import sys
-from collections import defaultdict
+from collections import defaultdict, deque
 from traceback import print_exc
+
+from . import _native
 
 from .barcode_extraction.barcode_callers import (ReadStats, TenXBarcodeExtractorV2, TenXBarcodeExtractorV3,
                                                  record_to_row)
@@ -105,6 +111,64 @@ def read_chunks(records, size=READ_CHUNK_SIZE):
     yield chunk                      # the reference also yields the trailing (possibly empty) chunk
 
 
+def is_fastx(input_file):
+    """True for [gzipped] FASTA / FASTQ by extension (reference :80-97)"""
+    fname, ext = os.path.splitext(os.path.basename(input_file))
+    if ext.lower() in (".gz", ".gzip"):
+        fname, ext = os.path.splitext(fname)
+    return ext.lower() in (".fq", ".fastq", ".fa", ".fasta")
+
+
+def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None):
+    """file -> native parser thread -> pinned chunks -> GPU(s) -> native row formatter -> on_chunk(rows, recs), in
+    chunk order.  Two chunks per device are in flight (bdg_extract_submit / bdg_extract_collect), chunk k on device
+    k mod N, so parsing, H2D + kernels and formatting / writing overlap and N devices run concurrently from this one
+    thread.  Like the reference's chunk generator (:131-150) a trailing empty chunk is reported when the input ends on
+    a chunk boundary (on_chunk(b"", empty records))."""
+    chunk_size = chunk_size or READ_CHUNK_SIZE
+    ng = len(detectors)
+    ing = _native.Ingest(input_file, chunk_size, ring_chunks=2 * ng + 2)
+    inflight = deque()
+    empty = _native.np.zeros(0, dtype=_native.REC_DTYPE)
+
+    def finish(item):
+        det, slot, ch = item
+        try:
+            recs = det._ctx().extract_collect(slot, ch.n)
+        except _native.BadgerHipError as e:
+            if e.code == _native.E_BADBASE:
+                raise KeyError(str(e))      # the reference raises KeyError in reverese_complement
+            raise
+        rows, _ = _native.format_rows(ch, recs)
+        ing.release(ch)
+        on_chunk(rows, recs)
+
+    try:
+        k, last_n = 0, None
+        while True:
+            ch = ing.next()
+            if ch.n == 0:
+                break
+            if len(inflight) >= 2 * ng:
+                finish(inflight.popleft())
+            det, slot = detectors[k % ng], (k // ng) % 2
+            det._ctx().extract_submit(slot, ch.bases, ch.off, ch.n, det.UMI_LEN_10X)
+            inflight.append((det, slot, ch))
+            k, last_n = k + 1, ch.n
+        while inflight:
+            finish(inflight.popleft())
+        if last_n is None or last_n == chunk_size:
+            on_chunk(b"", empty)
+    finally:
+        # chunks still in flight after an error: wait for the GPU before the pinned buffers go away
+        for det, slot, ch in inflight:
+            try:
+                det._ctx().extract_collect(slot, ch.n)
+            except Exception:
+                pass
+        ing.close()
+
+
 # ----------------------------------------------------------------------------- handlers
 class FileReadHandler:
     def __init__(self, outfile):
@@ -120,6 +184,11 @@ class FileReadHandler:
     def add_rows(self, rows):
         if rows:
             self.output_file.write("\n".join(rows) + "\n")
+
+    def add_text(self, rows_bytes):
+        """rows as the native formatter delivers them: one "\n"-terminated line per read"""
+        if rows_bytes:
+            self.output_file.write(rows_bytes.decode("ascii"))
 
     def dump_stats(self, read_stat):
         with open(self.output_table + ".stats", "w") as f:
@@ -148,6 +217,10 @@ class ListReadHandler:
             f = row.split("\t")
             self.read_storage.append((f[0], f[1], f[2]))
 
+    def add_text(self, rows_bytes):
+        if rows_bytes:
+            self.add_rows(rows_bytes.decode("ascii").split("\n")[:-1])
+
     def dump_stats(self, read_stat):
         pass
 
@@ -169,20 +242,32 @@ class BarcodeCaller:
         self.read_handler.add_rows([record_to_row(rid, s, r) for (rid, s), r in zip(read_chunk, recs)])
         self.read_stat.add_records(recs)
 
-    def process(self, input_file):
+    def process(self, input_file, skip_secondary=False):
         logger.info("Processing " + input_file)
-        records = open_reads(input_file, skip_secondary=False)     # single-thread BAM path keeps all records (:110-118)
-        if records is None:
-            logger.error("Unknown file format " + input_file)
+        if is_fastx(input_file):
+            def on_chunk(rows, recs):
+                self.read_handler.add_text(rows)
+                self.read_stat.add_records(recs)
+            run_fastx_pipeline(input_file, [self.barcode_detector], on_chunk)
         else:
-            for chunk in read_chunks(records):
-                self.process_chunk(chunk)
+            records = open_reads(input_file, skip_secondary=skip_secondary)     # single-thread BAM path keeps all records (:110-118)
+            if records is None:
+                logger.error("Unknown file format " + input_file)
+            else:
+                for chunk in read_chunks(records):
+                    self.process_chunk(chunk)
         logger.info("Finished " + input_file)
 
 
 # ----------------------------------------------------------------------------- drivers
 def _detectors(mode, gpus):
-    return [BARCODE_CALLING_MODES[mode](device=g) for g in range(max(1, gpus))]
+    gpus = max(1, gpus)
+    if gpus > 1:
+        import torch                         # (already loaded by _native; device_count does not initialise the GPU)
+        have = torch.cuda.device_count()
+        if gpus > have:
+            raise SystemExit("--gpus %d: this node shows %d device(s)" % (gpus, have))
+    return [BARCODE_CALLING_MODES[mode](device=g) for g in range(gpus)]
 
 
 def process_single_thread(args):
@@ -199,30 +284,47 @@ def process_single_thread(args):
 
 
 def process_in_parallel(args):
-    """Chunks go round-robin to the node's GPUs; output is written in chunk order, one header per
-    chunk and a space-separated merged .stats (the reference's parallel-mode file shape)."""
+    """Chunk k goes to device k mod N (all N work concurrently); output is written in chunk order, one header per
+    chunk and a space-separated merged .stats (the reference's parallel-mode file shape, :243-259)."""
     logger.info("Processing " + args.input)
-    records = open_reads(args.input, skip_secondary=True)
-    if records is None:
-        logger.error("Unknown file format " + args.input)
-        sys.exit(-1)
+    fastx = is_fastx(args.input)
+    records = None
+    if not fastx:
+        records = open_reads(args.input, skip_secondary=True)
+        if records is None:
+            logger.error("Unknown file format " + args.input)
+            sys.exit(-1)
     detectors = _detectors(args.mode, getattr(args, "gpus", 1))
     logger.info("Barcode caller created")
     stat_dict = defaultdict(int)
     header = detectors[0].result_type().header()
+
+    def merge_stats(stats):
+        for line in str(stats).split("\n"):
+            v = line.strip().split("\t")
+            if len(v) == 2:
+                stat_dict[v[0]] += int(v[1])
+
     with open(args.output, "w") as outf:
-        for k, chunk in enumerate(read_chunks(records)):
-            det = detectors[k % len(detectors)]
-            outf.write(header + "\n")
-            stats = ReadStats()
-            if chunk:
-                recs = det.extract_records([s for _, s in chunk])
-                outf.write("\n".join(record_to_row(rid, s, r) for (rid, s), r in zip(chunk, recs)) + "\n")
-                stats.add_records(recs)
-            for line in str(stats).split("\n"):
-                v = line.strip().split("\t")
-                if len(v) == 2:
-                    stat_dict[v[0]] += int(v[1])
+        if fastx:
+            def on_chunk(rows, recs):
+                outf.write(header + "\n")
+                stats = ReadStats()
+                if len(recs):
+                    outf.write(rows.decode("ascii"))
+                    stats.add_records(recs)
+                merge_stats(stats)
+            run_fastx_pipeline(args.input, detectors, on_chunk)
+        else:
+            for k, chunk in enumerate(read_chunks(records)):
+                det = detectors[k % len(detectors)]
+                outf.write(header + "\n")
+                stats = ReadStats()
+                if chunk:
+                    recs = det.extract_records([s for _, s in chunk])
+                    outf.write("\n".join(record_to_row(rid, s, r) for (rid, s), r in zip(chunk, recs)) + "\n")
+                    stats.add_records(recs)
+                merge_stats(stats)
     with open(args.output + ".stats", "w") as out_stats:
         for k, v in stat_dict.items():
             logger.info("%s %d" % (k, v))
@@ -240,14 +342,11 @@ def extract_barcodes_single_thread(input_file, mode):
 
 def extract_barcodes_in_parallel(input_file, mode, threads):
     logger.info("Extracting from " + input_file)
-    records = open_reads(input_file, skip_secondary=True)
-    if records is None:
+    if not is_fastx(input_file) and open_reads(input_file) is None:
         logger.error("Unknown file format " + input_file)
         sys.exit(-1)
     handler = ListReadHandler()
-    caller = BarcodeCaller(_detectors(mode, 1)[0], handler)
-    for chunk in read_chunks(records):
-        caller.process_chunk(chunk)
+    BarcodeCaller(_detectors(mode, 1)[0], handler).process(input_file, skip_secondary=True)
     logger.info("Finished barcode extraction")
     return handler.read_storage
 

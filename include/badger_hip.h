@@ -44,6 +44,7 @@ extern "C" {
 #define BDG_E_CAPACITY   -4   /* output capacity too small (graph edges: see *n_edges) */
 #define BDG_E_BADBASE    -5   /* a read holds a byte outside "ACGTN" (reference: KeyError,
                                  barcode_extraction/common.py:34-38) */
+#define BDG_E_FORMAT     -6   /* malformed FASTA / FASTQ input (reference: ValueError from Bio.SeqIO) */
 
 typedef struct bdg_ctx bdg_ctx;
 
@@ -129,6 +130,45 @@ int  bdg_extract_set_queue_capacity(bdg_ctx* ctx, uint64_t entries_per_segment);
  * relaxed search had already succeeded, [4] filter survivors, [5] hits re-queued from clusters,
  * [6] alignments run, [7] clusters the hits of [2] arrived in. */
 int  bdg_extract_counters(bdg_ctx* ctx, uint64_t out[8]);
+
+/* Pipelined form of bdg_extract_batch for a stream of chunks (extract_raw_barcodes.py:131-159: chunks of 100,000
+ * reads): submit() enqueues the H2D copy of a chunk (pinned host memory makes it asynchronous), the kernels and the
+ * D2H copy of the records on the context's stream and returns; collect() waits for that chunk, reruns it if a queue
+ * overflowed, and hands over its records.  `slot` (0 .. BDG_SLOTS-1) names one of the context's staging sets: a
+ * chunk may be submitted to a free slot while earlier ones are still in flight, so the device works on chunk k+1
+ * while the host formats chunk k.  Collect in submission order.  bases / off must stay valid until collect(). */
+#define BDG_SLOTS 4
+int  bdg_extract_submit(bdg_ctx* ctx, uint32_t slot, const uint8_t* bases, const uint64_t* off, uint32_t n, uint32_t umi_len);
+int  bdg_extract_collect(bdg_ctx* ctx, uint32_t slot, bdg_extract_rec* out);
+
+/* ---- read ingest and row output (host side) --------------------------------------------- */
+/* [gzipped] FASTA / FASTQ -> chunks of at most chunk_reads reads {concatenated bases, offsets, ids}, parsed by a
+ * background thread into a ring of ring_chunks chunks (>= 2) of pinned host memory (pinned = 0: pageable, for hosts
+ * without a GPU).  Format by extension like the reference (extract_raw_barcodes.py:78-98): .fa .fasta .fq .fastq,
+ * optionally + .gz / .gzip; anything else returns BDG_E_ARG (BAM / SAM stay with the caller's pysam).  Record
+ * semantics are Bio.SeqIO's: id = first word of the header; FASTA sequence = its lines joined. */
+typedef struct bdg_ingest bdg_ingest;
+typedef struct bdg_ingest_chunk {
+    uint32_t        id;           /* ring position, for bdg_ingest_release */
+    uint32_t        n;            /* reads in the chunk; 0 = end of input */
+    const uint8_t*  bases;        /* concatenated ASCII, 64 readable bytes behind the end */
+    const uint64_t* off;          /* n + 1 offsets into bases, off[0] = 0 */
+    uint64_t        total_bytes;  /* off[n] */
+    const char*     ids;          /* concatenated read ids */
+    const uint64_t* id_off;       /* n + 1 offsets into ids */
+} bdg_ingest_chunk;
+int  bdg_ingest_open(const char* path, uint32_t chunk_reads, uint32_t ring_chunks, int pinned, bdg_ingest** out);
+/* Blocks until the next chunk is parsed.  The chunk's memory stays untouched until bdg_ingest_release(id); at most
+ * ring_chunks - 1 chunks can be held.  BDG_E_FORMAT: malformed record (bdg_ingest_error says where). */
+int  bdg_ingest_next(bdg_ingest* g, bdg_ingest_chunk* out);
+int  bdg_ingest_release(bdg_ingest* g, uint32_t id);
+const char* bdg_ingest_error(bdg_ingest* g);
+void bdg_ingest_close(bdg_ingest* g);
+/* TSV rows of a chunk (TenXBarcodeDetectionResult.__str__, barcode_callers.py:40-42,91-93,117-119), one line per read,
+ * "\n"-terminated, into out[cap].  Returns the bytes written, or the bytes needed if cap is too small (nothing
+ * written then; call with out = NULL to size), or < 0.  counts (may be NULL): reads, barcodes detected, polyT
+ * detected, R1 detected (ReadStats, barcode_callers.py:122-143). */
+int64_t bdg_format_rows(const bdg_ingest_chunk* chunk, const bdg_extract_rec* recs, char* out, uint64_t cap, uint64_t counts[4]);
 
 /* ---- B-N: nearest whitelist barcode ----------------------------------- */
 /* Per query: the whitelist entry with the smallest Levenshtein distance (ties ->

@@ -31,6 +31,67 @@ def test_stage1_parallel_shape(tmp_path, golden_dir, monkeypatch):
     assert stats["Total reads:"] == "1000" and stats["Barcode detected:"] == "993"
 
 
+def _fastq_of(tmp_path, n, seed):
+    """n synthetic reads as a FASTQ file + the TSV rows the oracle's records give for them"""
+    import numpy as np
+    from badger_amd import synth
+    from badger_amd.barcode_extraction.barcode_callers import record_to_row
+    from oracle import pyoracle as orc
+    wl = synth.make_whitelist(2000)
+    bases, off = synth.make_reads(n, wl, seed=seed)
+    seqs = synth.reads_to_list(bases, off)
+    path = str(tmp_path / "reads.fastq")
+    with open(path, "w") as f:
+        f.write("".join("@read_%d len=%d\n%s\n+\n%s\n" % (i, len(s), s, "I" * len(s)) for i, s in enumerate(seqs)))
+    recs = orc.extract_batch(bases.numpy(), off.numpy().astype(np.uint64), 12, threads=16)
+    rows = [record_to_row("read_%d" % i, s, r) for i, (s, r) in enumerate(zip(seqs, recs))]
+    return path, rows, recs
+
+
+def test_stage1_fastq_through_the_pipeline(tmp_path):
+    """250,000 reads = three chunks (100K, 100K, 50K) through parser thread -> pinned chunks -> submit / collect ->
+    native formatter: the TSV and .stats the CLI writes must be what the oracle's records give, in both file shapes."""
+    path, rows, recs = _fastq_of(tmp_path, 250000, 21)
+    header = "#read_id\tbarcode\tUMI\tBC_score\tvalid_UMI\tstrand\tpolyT_start\tR1_end"
+    out = str(tmp_path / "o1.tsv")
+    erb.main(["--mode", "tenX_v3", "-i", path, "-o", out, "-t", "1"])
+    assert open(out).read() == "\n".join([header] + rows) + "\n"
+    st = dict(l.split("\t") for l in open(out + ".stats").read().strip().split("\n"))
+    assert st["Total reads:"] == "250000" and st["Barcode detected:"] == str(int(recs["valid"].sum()))
+    assert st["PolyT detected:"] == str(int((recs["polyT"] != -1).sum())) and st["R1 detected:"] == str(int((recs["r1_end"] != -1).sum()))
+    out = str(tmp_path / "o4.tsv")
+    erb.main(["--mode", "tenX_v3", "-i", path, "-o", out, "-t", "4"])
+    want = [header] + rows[:100000] + [header] + rows[100000:200000] + [header] + rows[200000:]
+    assert open(out).read() == "\n".join(want) + "\n"
+
+
+def test_pipeline_over_several_contexts_keeps_chunk_order(tmp_path):
+    """--gpus N: chunk k goes to detector k mod N, two chunks in flight per detector, rows written in chunk order.
+    Rehearsed on one GPU with three independent contexts (own streams and workspaces) standing in for three devices,
+    with chunk sizes that do not divide the input; plus an input that ends exactly on a chunk boundary (the trailing
+    empty chunk of the reference's generator)."""
+    from badger_amd.barcode_extraction.barcode_callers import TenXBarcodeExtractorV3
+    path, rows, recs = _fastq_of(tmp_path, 9000, 22)
+    for ndet, size in ((3, 700), (2, 1000), (1, 4500), (3, 9000)):
+        dets = [TenXBarcodeExtractorV3(device=0, instance=i) for i in range(ndet)]
+        got, sizes = [], []
+
+        def on_chunk(text, r):
+            got.append(text)
+            sizes.append(len(r))
+        erb.run_fastx_pipeline(path, dets, on_chunk, chunk_size=size)
+        assert b"".join(got).decode() == "\n".join(rows) + "\n"
+        full, rest = divmod(9000, size)
+        assert sizes == [size] * full + ([rest] if rest else [0])
+
+
+def test_stage1_bad_base_raises_keyerror(tmp_path):
+    p = tmp_path / "bad.fq"
+    p.write_text("@a\nACGTACGTACGTACGTACGTAC\n+\n" + "I" * 22 + "\n@b\nACGTXCGT\n+\nIIIIIIII\n")
+    with pytest.raises(KeyError):
+        erb.main(["--mode", "tenX_v3", "-i", str(p), "-o", str(tmp_path / "o.tsv"), "-t", "1"])
+
+
 def test_stage2_matches_reference(tmp_path, golden_dir):
     for hs in (False, True):
         prefix = str(tmp_path / ("s2hs" if hs else "s2"))

@@ -1,0 +1,133 @@
+"""Native read ingest and row formatter (include/badger_hip.h bdg_ingest_*, bdg_format_rows) against the Python
+readers that restate Bio.SeqIO's record semantics and against the Python row formatter; no GPU needed (pageable
+buffers, records from the CPU oracle)."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from badger_amd import _native, synth
+from badger_amd import extract_raw_barcodes as erb
+from badger_amd.barcode_extraction.barcode_callers import record_to_row
+from oracle import pyoracle as orc
+
+
+def _chunks(path, size, ring=3):
+    ing = _native.Ingest(path, size, ring, pinned=False)
+    out = []
+    try:
+        while True:
+            ch = ing.next()
+            if ch.n == 0:
+                break
+            off = np.ctypeslib.as_array(C.cast(ch.off, C.POINTER(C.c_uint64)), shape=(ch.n + 1,)).copy()
+            idoff = np.ctypeslib.as_array(C.cast(ch.id_off, C.POINTER(C.c_uint64)), shape=(ch.n + 1,)).copy()
+            bases = C.string_at(ch.bases, int(ch.total_bytes))
+            ids = C.string_at(ch.ids, int(idoff[-1]))
+            recs = [(ids[int(idoff[i]):int(idoff[i + 1])].decode(), bases[int(off[i]):int(off[i + 1])].decode()) for i in range(ch.n)]
+            out.append(recs)
+            ing.release(ch)
+    finally:
+        ing.close()
+    return out
+
+
+def _write(path, text):
+    if str(path).endswith((".gz", ".gzip")):
+        with gzip.open(path, "wt", newline="") as f:
+            f.write(text)
+    else:
+        with open(path, "w", newline="") as f:
+            f.write(text)
+
+
+@pytest.mark.parametrize("name", ["r.fa", "r.fasta.gz", "r.FA", "r.fa.gzip"])
+def test_fasta_records_and_chunks(tmp_path, name):
+    rng = np.random.default_rng(1)
+    rnd = lambda k: "".join("ACGT"[i] for i in rng.integers(0, 4, k))
+    text = "; junk before the first header is ignored\nACGT\n"
+    for i in range(257):
+        s = rnd(int(rng.integers(0, 400)))
+        text += ">read_%d some description\tmore\n" % i
+        w = int(rng.integers(1, 90))
+        for a in range(0, len(s), w):                       # multi-line sequences, some with trailing blanks or CRLF
+            text += s[a:a + w] + ("  \r\n" if (i + a) % 7 == 0 else "\n")
+        if i % 50 == 0:
+            text += "\n"
+    text += ">\n\n>last_no_newline\nACGTN"
+    p = tmp_path / name
+    _write(p, text)
+    want = list(erb.open_reads(str(p)))
+    assert len(want) == 259 and want[-2] == ("", "") and want[-1] == ("last_no_newline", "ACGTN")
+    for size in (1, 7, 100, 259, 1000):
+        got = _chunks(str(p), size)
+        assert [len(c) for c in got] == [len(c) for c in erb.read_chunks(iter(want), size) if c]
+        assert [r for c in got for r in c] == want
+
+
+@pytest.mark.parametrize("name", ["r.fq", "r.fastq.gz"])
+def test_fastq_records_and_errors(tmp_path, name):
+    rng = np.random.default_rng(2)
+    rnd = lambda k: "".join("ACGTN"[i] for i in rng.integers(0, 5, k))
+    text = ""
+    for i in range(300):
+        s = rnd(int(rng.integers(0, 3000)))
+        text += "@r%d extra words\n%s\n+%s\n%s\n" % (i, s, "r%d" % i if i % 3 == 0 else "", "I" * len(s))
+        if i % 40 == 0:
+            text += "\n"                                     # blank line between records
+    p = tmp_path / name
+    _write(p, text)
+    want = list(erb.open_reads(str(p)))
+    assert len(want) == 300
+    got = _chunks(str(p), 64)
+    assert [len(c) for c in got] == [64, 64, 64, 64, 44] and [r for c in got for r in c] == want
+    # a long line crossing the reader's 4 MB blocks
+    big = "@big\n%s\n+\n%s\n" % ("A" * 9000001, "I" * 9000001)
+    _write(p, big + text)
+    got = _chunks(str(p), 1000)
+    assert got[0][0][0] == "big" and len(got[0][0][1]) == 9000001 and got[0][1:] == want
+    for bad in ("r1\nACGT\n+\nIIII\n", "@r1\nACGT\nIIII\n@r2\n", "@r1\nACGT\n+\nIII\n", "@r1\nACGT\n"):
+        _write(p, text[:text.index("@r7 ")] + bad)
+        with pytest.raises(ValueError):
+            _chunks(str(p), 4)
+        with pytest.raises(ValueError):
+            list(erb.open_reads(str(p)))
+    # chunks before the malformed record are still delivered
+    _write(p, text[:text.index("@r9 ")] + "oops\n")
+    ing = _native.Ingest(str(p), 4, 3, pinned=False)
+    assert ing.next().n == 4 and ing.next().n == 4
+    with pytest.raises(ValueError):
+        ing.next()
+    ing.close()
+
+
+def test_unknown_extension_is_refused(tmp_path):
+    p = tmp_path / "reads.bam"
+    p.write_bytes(b"BAM\1")
+    with pytest.raises(_native.BadgerHipError):
+        _native.Ingest(str(p), 10, 2, pinned=False)
+    assert not erb.is_fastx(str(p)) and erb.is_fastx("x.FASTQ.gz") and erb.is_fastx("a/b.fa")
+
+
+def test_format_rows_equals_python_formatter(tmp_path, golden_dir):
+    wl = synth.make_whitelist(500)
+    bases, off = synth.make_reads(700, wl, seed=5)
+    seqs = synth.reads_to_list(bases, off)
+    seqs += ["", "ACGT", "T" * 40, "CTACACGACGCTCTTCCGATCT" + "ACGTACGTACGTACGT" + "AC"]        # short tails: slices clip like Python's
+    p = tmp_path / "x.fastq"
+    _write(p, "".join("@id%d/x y\n%s\n+\n%s\n" % (i, s, "#" * len(s)) for i, s in enumerate(seqs)))
+    ing = _native.Ingest(str(p), 5000, 2, pinned=False)
+    ch = ing.next()
+    assert ch.n == len(seqs)
+    b, o = synth.list_to_reads(seqs)
+    recs = orc.extract_batch(b, o, 12, threads=4).view(_native.REC_DTYPE)
+    assert (recs["flags"] & 1).sum() > 100 and (recs["valid"] == 0).sum() > 0
+    rows, counts = _native.format_rows(ch, recs)
+    want = "".join(record_to_row("id%d/x" % i, s, r) + "\n" for i, (s, r) in enumerate(zip(seqs, recs)))
+    assert rows.decode() == want
+    assert counts == (len(seqs), int(recs["valid"].sum()), int((recs["polyT"] != -1).sum()), int((recs["r1_end"] != -1).sum()))
+    ing.release(ch)
+    assert ing.next().n == 0
+    ing.close()
