@@ -33,7 +33,7 @@ EXPORTS = [
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
-    "bdg_extract_submit", "bdg_extract_collect",
+    "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records",
     "bdg_ingest_open", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error", "bdg_ingest_close", "bdg_format_rows",
 ]
 
@@ -100,6 +100,8 @@ def load():
     L.bdg_distinct_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     L.bdg_extract_submit.argtypes = [vp, u32, vp, vp, u32, u32]
     L.bdg_extract_collect.argtypes = [vp, u32, vp]
+    L.bdg_extract_keep_records.argtypes = [vp, C.c_int]
+    L.bdg_kept_records.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.bdg_ingest_open.argtypes = [C.c_char_p, u32, u32, C.c_int, C.POINTER(vp)]
     L.bdg_ingest_next.argtypes = [vp, C.POINTER(IngestChunk)]
     L.bdg_ingest_release.argtypes = [vp, u32]
@@ -190,6 +192,16 @@ class Context:
         self._check(self.lib.bdg_extract_collect(self.h, slot, out.ctypes.data))
         return out
 
+    def extract_keep_records(self, on=True):
+        """keep (a copy of) every collected chunk's records on the device, in order, for the stage-2 hand-off"""
+        self._check(self.lib.bdg_extract_keep_records(self.h, 1 if on else 0))
+
+    def kept_records(self):
+        """-> (device pointer, count) of the records kept since extract_keep_records(True)"""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self.lib.bdg_kept_records(self.h, C.byref(p), C.byref(n)))
+        return p.value or 0, int(n.value)
+
     def extract_status(self):
         bad, nwin = C.c_uint64(), C.c_uint64()
         rc = self.lib.bdg_extract_status(self.h, C.byref(bad), C.byref(nwin))
@@ -260,7 +272,9 @@ class Context:
         self._check(self.lib.bdg_graph_set_algo(self.h, algo))
 
     def distinct_dev(self, d_recs, n, d_uniq, d_count, d_first, d_n):
-        self._check(self.lib.bdg_distinct_dev(self.h, d_recs.data_ptr(), n, d_uniq.data_ptr(), d_count.data_ptr(),
+        """d_recs: a torch tensor of records or a raw device pointer (kept_records())"""
+        p = d_recs if isinstance(d_recs, int) else d_recs.data_ptr()
+        self._check(self.lib.bdg_distinct_dev(self.h, p, n, d_uniq.data_ptr(), d_count.data_ptr(),
                                               d_first.data_ptr(), d_n.data_ptr()))
 
 

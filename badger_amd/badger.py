@@ -13,8 +13,9 @@ import sys
 from io import StringIO
 from traceback import print_exc
 
+from . import _native
 from .barcode_graph import BarcodeGraph
-from .extract_raw_barcodes import BARCODE_CALLING_MODES, extract_barcodes_in_parallel, extract_barcodes_single_thread
+from .extract_raw_barcodes import BARCODE_CALLING_MODES, extract_barcodes_in_parallel, extract_barcodes_single_thread, is_fastx
 
 logger = logging.getLogger("BarcodeGraph")
 
@@ -103,19 +104,28 @@ def main(args):
         with open(args.barcode_list) as f:
             barcode_list = set(f.read().split("\n"))
 
+    handoff_ctx = None
     if args.reads.endswith("tsv"):
         read_assignment, barcodes = import_tsv(args.reads, bc_len)
         logger.info("Imported barcodes from file")
     else:
+        # FASTA / FASTQ: the records of every chunk also stay on the device (stage 1 -> stage 2 hand-off without host strings)
+        handoff_ctx = _native.default_context(args.device) if is_fastx(args.reads) else None
+        if handoff_ctx is not None:
+            handoff_ctx.extract_keep_records(True)
         if args.threads == 1:
-            read_assignment = extract_barcodes_single_thread(args.reads, args.data_type)
+            read_assignment = extract_barcodes_single_thread(args.reads, args.data_type, device=args.device)
         else:
-            read_assignment = extract_barcodes_in_parallel(args.reads, args.data_type, args.threads)
+            read_assignment = extract_barcodes_in_parallel(args.reads, args.data_type, args.threads, device=args.device)
         barcodes = [ra[1] for ra in read_assignment if ra[1] != "*"]
 
     logger.info("Initializing Graph")
     graph = BarcodeGraph(args.threshold, device=args.device)
-    graph.graph_construction(barcodes, bc_len, args.threads)
+    if handoff_ctx is not None:
+        graph.graph_construction_from_device(handoff_ctx, bc_len)
+        handoff_ctx.extract_keep_records(False)
+    else:
+        graph.graph_construction(barcodes, bc_len, args.threads)
     logger.info("Graph construction done")
     graph.cluster(true_barcodes, barcode_list, args.n_cells, bc_len, args.interval)
     logger.info("Clustering done")

@@ -54,17 +54,63 @@ class BarcodeGraph:
         self.counts = {int(uniq[i]): int(cnt[i]) for i in order}
         return uniq.astype(np.uint32)
 
-    def graph_construction(self, barcodes, bc_len, threads=1):
-        if bc_len != 16:
-            raise ValueError("only 16-base barcodes (tenX) are supported")
-        uniq = self.index_barcodes(barcodes, bc_len)
-        e = self._ctx().graph_edges(uniq, self.threshold, qgram_threshold(self.threshold, bc_len))
-        a, b, d = e["a"].tolist(), e["b"].tolist(), e["dist"].tolist()
+    def _take_edges(self, a, b, d):
         for x, y, z in zip(a, b, d):
             self.edges[x].append(y)
             self.edges[y].append(x)
             self.dists[(x, y)] = z
             self.dists[(y, x)] = z
+
+    def graph_construction(self, barcodes, bc_len, threads=1):
+        if bc_len != 16:
+            raise ValueError("only 16-base barcodes (tenX) are supported")
+        uniq = self.index_barcodes(barcodes, bc_len)
+        e = self._ctx().graph_edges(uniq, self.threshold, qgram_threshold(self.threshold, bc_len))
+        self._take_edges(e["a"].tolist(), e["b"].tolist(), e["dist"].tolist())
+
+    def graph_construction_from_device(self, ctx, bc_len=16):
+        """Same post-conditions as graph_construction, from the extraction records the context kept on the device
+        (extract_keep_records): distinct barcodes and their counts by sort + run-length on the GPU
+        (index_bc_single_thread, reference :192-204), edges straight from that sorted array; only the distinct ranks,
+        counts, first-occurrence indices and the edge list come back to the host.  counts is ordered by first
+        occurrence like the reference's dict (get_cluster_centers depends on it, :253-255)."""
+        import torch
+        if bc_len != 16:
+            raise ValueError("only 16-base barcodes (tenX) are supported")
+        ptr, n = ctx.kept_records()
+        dev = torch.device("cuda", ctx.device)
+        if n == 0:
+            return
+        m = max(n, 1)
+        uniq = torch.zeros(m, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(m, dtype=torch.int32, device=dev)
+        first = torch.zeros(m, dtype=torch.int32, device=dev)
+        dn = torch.zeros(2, dtype=torch.int32, device=dev)
+        ctx.distinct_dev(ptr, n, uniq, cnt, first, dn)
+        ctx.synchronize()
+        nu, nbad = int(dn[0]), int(dn[1])
+        if nbad:
+            raise KeyError("%d extracted barcodes hold a base outside ACGT" % nbad)      # reference: rank() raises KeyError
+        h_uniq = uniq[:nu].cpu().numpy().view(np.uint32)
+        h_cnt = cnt[:nu].cpu().numpy()
+        order = np.argsort(first[:nu].cpu().numpy().view(np.uint32), kind="stable")
+        self.counts = {int(h_uniq[i]): int(h_cnt[i]) for i in order}
+        if nu < 2:
+            return
+        T = qgram_threshold(self.threshold, bc_len)
+        cap = max(1024, 8 * nu)
+        while True:
+            d_edges = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+            d_tot = torch.zeros(1, dtype=torch.int64, device=dev)
+            ctx.graph_edges_dev(uniq, nu, self.threshold, T, d_edges, cap, d_tot)
+            ctx.synchronize()
+            tot = int(d_tot[0])
+            if tot <= cap:
+                break
+            cap = tot
+        e = d_edges[:tot].cpu().numpy().view(np.uint32)
+        e = e[np.lexsort((e[:, 1], e[:, 0]))]               # the order the host-buffer call delivers (neighbour order is free anyway)
+        self._take_edges(e[:, 0].tolist(), e[:, 1].tolist(), e[:, 2].tolist())
 
     # ------------------------------------------------------------------ clustering (host)
     def get_cluster_centers(self, true_barcodes, bc_len, barcode_list, n_cells, interval):

@@ -118,7 +118,7 @@ void bdg_free(bdg_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = { &ctx->x_lut, &ctx->x_polyt, &ctx->x_keys, &ctx->x_hits, &ctx->x_counters, &ctx->s_in0,
                        &ctx->s_in1, &ctx->s_out0, &ctx->w_sorted, &ctx->w_orig, &ctx->w_prefix, &ctx->w_bitmap, &ctx->w_pent, &ctx->w_delmap, &ctx->w_dv,
-                       &ctx->n_list, &ctx->n_counters, &ctx->g_sig, &ctx->g_tmp0, &ctx->g_tmp1, &ctx->g_cnt, &ctx->g_qj };
+                       &ctx->n_list, &ctx->n_counters, &ctx->g_sig, &ctx->g_tmp0, &ctx->g_tmp1, &ctx->g_cnt, &ctx->g_qj, &ctx->x_allrecs };
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& sl : ctx->slots) {
         for (DevBuf* b : { &sl.d_bases, &sl.d_off, &sl.d_recs }) if (b->p) (void)hipFree(b->p);
@@ -330,6 +330,43 @@ int bdg_extract_collect(bdg_ctx* ctx, uint32_t slot, bdg_extract_rec* out)
     }
     if (rc) return rc;
     memcpy(out, sl.h_recs, sizeof(bdg_extract_rec) * (size_t)sl.n);
+    if (ctx->keep_records) {
+        // append the chunk's records to the device-side array (grown by copying: earlier chunks stay)
+        const size_t have = sizeof(bdg_extract_rec) * (size_t)ctx->x_allrecs_n, add = sizeof(bdg_extract_rec) * (size_t)sl.n;
+        if (have + add > ctx->x_allrecs.bytes) {
+            DevBuf nb;
+            size_t want = (have + add) * 2;
+            if (want < (size_t(64) << 20)) want = size_t(64) << 20;
+            if ((rc = bdg_reserve(ctx, nb, want))) return rc;
+            if (have) BDG_HIP_TRY(ctx, hipMemcpyAsync(nb.p, ctx->x_allrecs.p, have, hipMemcpyDeviceToDevice, ctx->stream));
+            BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->x_allrecs.p) (void)hipFree(ctx->x_allrecs.p);
+            ctx->x_allrecs = nb;
+        }
+        BDG_HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(ctx->x_allrecs.p) + have, sl.d_recs.p, add, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->x_allrecs_n += sl.n;
+    }
+    return BDG_OK;
+}
+
+int bdg_extract_keep_records(bdg_ctx* ctx, int on)
+{
+    if (!ctx) return BDG_E_ARG;
+    ctx->keep_records = on != 0;
+    ctx->x_allrecs_n = 0;
+    if (!on && ctx->x_allrecs.p) {
+        BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->x_allrecs.p);
+        ctx->x_allrecs = DevBuf();
+    }
+    return BDG_OK;
+}
+
+int bdg_kept_records(bdg_ctx* ctx, const bdg_extract_rec** d_recs, uint64_t* n)
+{
+    if (!ctx || !d_recs || !n) return BDG_E_ARG;
+    *d_recs = static_cast<const bdg_extract_rec*>(ctx->x_allrecs.p);
+    *n = ctx->x_allrecs_n;
     return BDG_OK;
 }
 

@@ -56,6 +56,9 @@ struct bdg_ctx {
         uint32_t n = 0, umi_len = 0; uint64_t total = 0, qcap = 0;
         bool busy = false;
     } slots[BDG_SLOTS];
+    // records of every collected chunk, kept on the device in submission order (bdg_extract_keep_records)
+    bool keep_records = false;
+    DevBuf x_allrecs; uint64_t x_allrecs_n = 0;
 
     // ---- whitelist index (nearest_kernels.hip)
     DevBuf w_sorted;     // uint32 [nw] ranks ascending

@@ -332,21 +332,21 @@ def process_in_parallel(args):
     logger.info("Finished barcode calling")
 
 
-def extract_barcodes_single_thread(input_file, mode):
+def extract_barcodes_single_thread(input_file, mode, device=0):
     logger.info("Extracting from " + input_file)
     handler = ListReadHandler()
-    BarcodeCaller(_detectors(mode, 1)[0], handler).process(input_file)
+    BarcodeCaller(BARCODE_CALLING_MODES[mode](device=device), handler).process(input_file)
     logger.info("Finished barcode extraction")
     return handler.read_storage
 
 
-def extract_barcodes_in_parallel(input_file, mode, threads):
+def extract_barcodes_in_parallel(input_file, mode, threads, device=0):
     logger.info("Extracting from " + input_file)
     if not is_fastx(input_file) and open_reads(input_file) is None:
         logger.error("Unknown file format " + input_file)
         sys.exit(-1)
     handler = ListReadHandler()
-    BarcodeCaller(_detectors(mode, 1)[0], handler).process(input_file, skip_secondary=True)
+    BarcodeCaller(BARCODE_CALLING_MODES[mode](device=device), handler).process(input_file, skip_secondary=True)
     logger.info("Finished barcode extraction")
     return handler.read_storage
 

@@ -141,6 +141,14 @@ int  bdg_extract_counters(bdg_ctx* ctx, uint64_t out[8]);
 int  bdg_extract_submit(bdg_ctx* ctx, uint32_t slot, const uint8_t* bases, const uint64_t* off, uint32_t n, uint32_t umi_len);
 int  bdg_extract_collect(bdg_ctx* ctx, uint32_t slot, bdg_extract_rec* out);
 
+/* Stage-1 -> stage-2 hand-off on the device (badger.py:112-121 extracts and then builds the graph in one process):
+ * while `on`, bdg_extract_collect also appends each chunk's records to a device-side array, in collection order.
+ * bdg_kept_records gives that array (device pointer, valid until the next collect / keep_records call) for
+ * bdg_distinct_dev -> bdg_graph_edges_dev, so the barcodes never pass through host strings.  Turning it on starts
+ * an empty array; turning it off frees it. */
+int  bdg_extract_keep_records(bdg_ctx* ctx, int on);
+int  bdg_kept_records(bdg_ctx* ctx, const bdg_extract_rec** d_recs, uint64_t* n);
+
 /* ---- read ingest and row output (host side) --------------------------------------------- */
 /* [gzipped] FASTA / FASTQ -> chunks of at most chunk_reads reads {concatenated bases, offsets, ids}, parsed by a
  * background thread into a ring of ring_chunks chunks (>= 2) of pinned host memory (pinned = 0: pageable, for hosts

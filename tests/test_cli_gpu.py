@@ -109,12 +109,99 @@ def test_stage2_matches_reference(tmp_path, golden_dir):
         if not hs:
             assert got == want
         else:
-            # high-sensitivity ties are hash-seed dependent in the reference (set iteration order);
-            # everything else must agree, and an unassigned read stays unassigned in both
+            # High-sensitivity mode sends every unassigned barcode to its nearest centre (barcode_graph.py:370-385).  The
+            # reference walks a set of strings, so among equally near centres its choice follows the hash seed; every
+            # row that differs from the fixture must therefore be exactly such a tie: both centres at the same
+            # Levenshtein distance (< 3) from the observed barcode, and the same centre for every read of that barcode.
+            from oracle import pyoracle as orc
             assert len(got) == len(want)
-            diff = [(g, w) for g, w in zip(got, want) if g != w]
-            assert all(g.split("\t")[1] != "*" and w.split("\t")[1] != "*" for g, w in diff)
-            assert len(diff) <= 0.02 * len(got)
+            observed = {}
+            for line in open(os.path.join(golden_dir, "c1_expected.tsv")).read().split("\n")[1:]:
+                if line:
+                    f = line.split("\t")
+                    observed[f[0]] = f[1]
+            ndiff = 0
+            for g, w in zip(got, want):
+                if g == w:
+                    continue
+                rid, gb = g.split("\t")
+                rid2, wb = w.split("\t")
+                assert rid == rid2 and gb != "*" and wb != "*"
+                obs = observed[rid][:16]
+                dg, dw = orc.levenshtein(obs, gb), orc.levenshtein(obs, wb)
+                assert dg == dw and dg < 3, (rid, obs, gb, wb, dg, dw)
+                ndiff += 1
+            assert ndiff <= 0.02 * len(got)
+
+
+def test_distinct_dev_against_the_references_counts(golden_dir):
+    """bdg_distinct_dev (sort + run-length on the device) against BarcodeGraph.counts as the reference built it
+    (index_bc_single_thread, barcode_graph.py:192-204; fixture from the reference's own run): same distinct ranks, same
+    multiplicities, and - ordered by first occurrence - the same dict order."""
+    import json
+    import numpy as np
+    import torch
+    from badger_amd import _native, synth
+    g = json.load(open(os.path.join(golden_dir, "graph.json")))
+    ctx = _native.Context(0)
+    for key in ("c1_thr1", "cells60_thr1"):
+        case = g[key]
+        recs = np.zeros(len(case["barcodes"]) + 3, dtype=_native.REC_DTYPE)
+        for i, s in enumerate(case["barcodes"]):
+            if len(s) == 17:
+                s = s[:-1]
+            if len(s) == 16:                     # anything else is dropped by the reference (:199-200)
+                recs[i]["valid"], recs[i]["flags"], recs[i]["bc_rank"] = 1, _native.FLAG_RANK_OK | _native.FLAG_BC16, synth.str_to_rank(s)
+            else:
+                recs[i]["valid"], recs[i]["flags"] = 1, 0
+        # three reads without a barcode at the end
+        d_recs = torch.from_numpy(recs.view(np.int32).reshape(-1, 8).copy()).cuda()
+        n = len(recs)
+        uq = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ct = torch.zeros(n, dtype=torch.int32, device="cuda")
+        fi = torch.zeros(n, dtype=torch.int32, device="cuda")
+        dn = torch.zeros(2, dtype=torch.int32, device="cuda")
+        ctx.distinct_dev(d_recs, n, uq, ct, fi, dn)
+        ctx.synchronize()
+        nu = int(dn[0])
+        order = np.argsort(fi[:nu].cpu().numpy(), kind="stable")
+        got = [[int(uq[:nu].cpu().numpy().view(np.uint32)[i]), int(ct[:nu].cpu().numpy()[i])] for i in order]
+        assert got == case["counts"], key
+    ctx.close()
+
+
+def test_stage2_handoff_on_device_equals_the_tsv_route(tmp_path):
+    """badger.py on a FASTQ (extraction records stay on the device -> bdg_distinct_dev -> bdg_graph_edges_dev) must write
+    what it writes from the stage-1 TSV of the same reads (host strings -> rank -> host counting -> bdg_graph_edges),
+    at both thresholds, and must really have taken the device route."""
+    from badger_amd import barcode_graph
+    path, rows, recs = _fastq_of(tmp_path, 30000, 23)
+    tsv = str(tmp_path / "s1.tsv")
+    erb.main(["--mode", "tenX_v3", "-i", path, "-o", tsv, "-t", "1"])
+    wl = str(tmp_path / "wl.txt")
+    from badger_amd import synth
+    with open(wl, "w") as f:
+        f.write("\n".join(synth.rank_to_str(r) for r in synth.make_whitelist(2000)) + "\n")
+    for thr in ("1", "2"):
+        outs = []
+        for k, reads in enumerate((tsv, path)):
+            prefix = str(tmp_path / ("o%s_%d" % (thr, k)))
+            calls = []
+            orig = barcode_graph.BarcodeGraph.graph_construction_from_device
+
+            def spy(self, ctx, bc_len=16, _orig=orig, _calls=calls):
+                _calls.append(1)
+                return _orig(self, ctx, bc_len)
+            barcode_graph.BarcodeGraph.graph_construction_from_device = spy
+            try:
+                with redirect_stdout(io.StringIO()):
+                    badger.main(["-r", reads, "-d", "tenX_v3", "-l", wl, "-c", "300", "-t", thr, "-o", prefix])
+            finally:
+                barcode_graph.BarcodeGraph.graph_construction_from_device = orig
+            assert len(calls) == k                      # TSV: host route; FASTQ: device route
+            outs.append(open(prefix + "_output_file.tsv").read())
+        assert outs[0] == outs[1] and outs[0].count("\n") == 30001
+        assert sum(1 for l in outs[0].split("\n")[1:] if l and not l.endswith("*")) > 10000
 
 
 def test_stage2_from_fastx_input(tmp_path, golden_dir):
