@@ -145,30 +145,30 @@ def test_config3_graph_probe_equals_scan_and_oracle_rows(world):
     assert (e_probe["a"] < e_probe["b"]).all() and (e_probe["dist"] <= 1).all()
     key = e_probe["a"].astype(np.uint64) << np.uint64(32) | e_probe["b"].astype(np.uint64)
     assert (np.diff(key.astype(np.int64)) > 0).all()                                   # sorted, no duplicates
-    # complete rows against the oracle's definition
+    # complete rows.  dmin(a, b) <= 1 puts b in a's 176-string ball: a with one substitution (ed(a, b) = 1), a[:15] with one
+    # base inserted (ed(a[:-1], b) = 1), or a with one base deleted followed by any base (ed(a, b[:-1]) = 1) - built here
+    # from strings, independently of the kernel's rank arithmetic.  Every ball member that is a later row must be an
+    # edge iff the oracle's S and dmin say so, and the kernel may report nothing outside the ball.
     rng = np.random.default_rng(4)
+    present = set(ranks.tolist())
     for a in ranks[rng.integers(0, len(ranks), 40)]:
-        mine = sorted((int(x["b"]), int(x["dist"])) for x in e_probe[e_probe["a"] == a])
-        cand = ranks[ranks > a]
-        x = cand ^ a
-        near = cand[np.array([bin(int((v | (v >> 1)) & 0x55555555)).count("1") for v in x]) <= 8] if False else cand
+        sa = synth.rank_to_str(int(a))
+        ball = set()
+        for p in range(16):
+            for c in "ACGT":
+                ball.add(sa[:p] + c + sa[p + 1:])                    # substitution
+                ball.add(sa[:15][:p] + c + sa[:15][p:])              # insertion into a[:15] (slots 0..14)
+                ball.add(sa[:p] + sa[p + 1:] + c)                    # deletion, then a free last base
+        for c in "ACGT":
+            ball.add(sa[:15] + c)                                    # insertion at slot 15 of a[:15]
+        ball.discard(sa)
         want = []
-        for b in near[:0]:
-            pass
-        # exact row by brute force over the 176-candidate ball is what the kernel does; the independent check is the
-        # oracle's S and dmin on every barcode within Hamming distance 3 of a or of its shifted forms
-        sh1 = ((cand >> np.uint32(2)) ^ (a & np.uint32(0x3FFFFFFF))) & np.uint32(0x3FFFFFFF)
-        sh2 = ((cand & np.uint32(0x3FFFFFFF)) ^ (a >> np.uint32(2)))
-        def pc(v):
-            v = (v | (v >> np.uint32(1))) & np.uint32(0x55555555)
-            return np.array([bin(int(t)).count("1") for t in v])
-        pre = cand[(pc(x) <= 1)]
-        rest = cand[(pc(x) > 1)]
-        rest = rest[:0]
-        want = sorted((int(b), orc.dmin3(int(a), int(b))) for b in pre if orc.qgram_S(int(a), int(b)) >= 5 and orc.dmin3(int(a), int(b)) <= 1)
-        assert set(want) <= set(mine)
-        for b, d in mine:
-            assert orc.dmin3(int(a), b) == d and orc.qgram_S(int(a), b) >= 5
+        for sb in ball:
+            b = synth.str_to_rank(sb)
+            if b > int(a) and b in present and orc.dmin3(int(a), b) <= 1 and orc.qgram_S(int(a), b) >= 5:
+                want.append((b, orc.dmin3(int(a), b)))
+        mine = sorted((int(x["b"]), int(x["dist"])) for x in e_probe[e_probe["a"] == a])
+        assert mine == sorted(want)
 
 
 def test_config2_distinct_on_device_matches_host_counting(world):

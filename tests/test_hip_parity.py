@@ -105,6 +105,36 @@ def test_extract_adversarial(ctx, orc):
     assert (got2 == orc.extract_batch(bases, off, 12, threads=8)[20:]).all()
 
 
+def test_extract_reads_built_around_sw_ties(ctx, orc):
+    """Reads whose adapter region is made of the tie cases of tests/golden/ssw_tie_kats.json (tandem tails, repeated
+    heads, two full copies, N inside, truncated copies): the end / begin cell the packed 16-bit Smith-Waterman of
+    k_sw_clusters reports decides R1_end and with it the barcode slice; every record must equal the oracle's."""
+    import json
+    rng = np.random.default_rng(321)
+    R1 = "CTACACGACGCTCTTCCGATCT"
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))
+    rnd = lambda k: "".join("ACGT"[i] for i in rng.integers(0, 4, k))
+    kats = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ssw_tie_kats.json")))["kats"]
+    pieces = [k["window"] for k in kats if "N" not in k["window"] or len(k["window"]) > 4] + \
+             [R1 + "CCGATCT", R1 + "TCT", R1 + "CT" * 3, "CT" * 4 + R1, R1[:-1], R1[:-2] + "CTCT", R1[3:], R1[:11] + R1[9:], R1[:15] + "N" + R1[16:],
+              R1 + R1[-9:], R1[:8] + R1, "TCTT" + R1[2:], R1[:-4] + "ATCTATCT"]
+    seqs = []
+    for k in range(3000):
+        mid = pieces[int(rng.integers(0, len(pieces)))]
+        if rng.random() < 0.3:                          # one sequencing error inside
+            p = int(rng.integers(0, len(mid)))
+            mid = mid[:p] + ("" if rng.random() < 0.4 else "ACGT"[int(rng.integers(0, 4))]) + mid[p + (0 if rng.random() < 0.3 else 1):]
+        tail = "T" * int(rng.integers(12, 34)) if rng.random() < 0.85 else rnd(8)
+        s = rnd(int(rng.integers(0, 48))) + mid + rnd(16) + rnd(12) + tail + rnd(int(rng.integers(0, 300)))
+        seqs.append(s if rng.random() < 0.5 else rc(s))
+    bases, off = synth.list_to_reads(seqs)
+    got = ctx.extract_batch(bases, off, 12)
+    want = orc.extract_batch(bases, off, 12, threads=8)
+    assert (got == want).all(), _diff(got, want)
+    assert 0.5 < want["valid"].mean() < 1.0
+
+
 def test_extract_queue_overflow_is_contained_and_recovered(orc):
     """Adapter-dense reads (concatemers) against a deliberately tiny candidate queue.  The host-buffer call loops until
     the workspace fits and returns the oracle's records.  The device-resident call cannot loop by itself: an overflowing

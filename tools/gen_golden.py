@@ -27,6 +27,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True          # the reference mount stays read-only: no __pycache__ next to its modules
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
