@@ -28,7 +28,7 @@ E_ARG, E_HIP, E_NOMEM, E_CAPACITY, E_BADBASE, E_FORMAT = -1, -2, -3, -4, -5, -6
 SLOTS = 4
 
 EXPORTS = [
-    "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_set_stream", "bdg_synchronize",
+    "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_set_stream", "bdg_synchronize", "bdg_set_overlap",
     "bdg_profile_enable", "bdg_profile_reset", "bdg_profile_read",
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
@@ -80,6 +80,7 @@ def load():
     L.bdg_version.restype = C.c_char_p
     L.bdg_set_stream.argtypes = [vp, vp]
     L.bdg_synchronize.argtypes = [vp]
+    L.bdg_set_overlap.argtypes = [vp, C.c_int]
     L.bdg_profile_enable.argtypes = [vp, C.c_int]
     L.bdg_profile_reset.argtypes = [vp]
     L.bdg_profile_read.argtypes = [vp, C.POINTER(KernelTime), C.c_int]
@@ -155,6 +156,10 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.bdg_synchronize(self.h))
+
+    def set_overlap(self, on=True):
+        """nearest16_recs_dev on an auxiliary stream: the match of batch i overlaps the extraction of batch i + 1"""
+        self._check(self.lib.bdg_set_overlap(self.h, 1 if on else 0))
 
     def profile(self, on=True):
         self._check(self.lib.bdg_profile_enable(self.h, 1 if on else 0))

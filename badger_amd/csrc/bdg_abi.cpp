@@ -27,6 +27,7 @@ int bdg_reserve(bdg_ctx* ctx, DevBuf& b, size_t bytes)
     if (b.p) {
         // the buffer may still be in use by queued work
         BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->aux_pending) { BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream)); ctx->aux_pending = false; }
         BDG_HIP_TRY(ctx, hipFree(b.p));
         b.p = nullptr; b.bytes = 0;
     }
@@ -60,19 +61,27 @@ static hipEvent_t take_event(bdg_ctx* ctx)
 void bdg_timer_begin(bdg_ctx* ctx, int id)
 {
     hipEvent_t a = take_event(ctx), b = take_event(ctx);
-    (void)hipEventRecord(a, ctx->stream);
+    (void)hipEventRecord(a, ctx->launch_stream ? ctx->launch_stream : ctx->stream);
     ctx->timers[id].pending.emplace_back(a, b);
 }
 
 void bdg_timer_end(bdg_ctx* ctx, int id)
 {
-    (void)hipEventRecord(ctx->timers[id].pending.back().second, ctx->stream);
+    (void)hipEventRecord(ctx->timers[id].pending.back().second, ctx->launch_stream ? ctx->launch_stream : ctx->stream);
     ctx->timers[id].launches++;
+}
+
+static int sync_all(bdg_ctx* ctx)
+{
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_pending) { BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream)); ctx->aux_pending = false; }
+    return BDG_OK;
 }
 
 static int collect_timers(bdg_ctx* ctx)
 {
-    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc0 = sync_all(ctx);
+    if (rc0) return rc0;
     for (auto& t : ctx->timers) {
         for (auto& pr : t.pending) {
             float ms = 0.f;
@@ -116,6 +125,9 @@ void bdg_free(bdg_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+    if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
+    for (hipEvent_t e : ctx->ev_aux) if (e) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &ctx->x_lut, &ctx->x_polyt, &ctx->x_keys, &ctx->x_hits, &ctx->x_counters, &ctx->s_in0,
                        &ctx->s_in1, &ctx->s_out0, &ctx->w_sorted, &ctx->w_orig, &ctx->w_prefix, &ctx->w_bitmap, &ctx->w_pent, &ctx->w_delmap, &ctx->w_dv,
                        &ctx->n_list, &ctx->n_counters, &ctx->g_sig, &ctx->g_tmp0, &ctx->g_tmp1, &ctx->g_cnt, &ctx->g_qj, &ctx->x_allrecs };
@@ -138,7 +150,8 @@ const char* bdg_last_error(bdg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err
 int bdg_set_stream(bdg_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return BDG_E_ARG;
-    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = sync_all(ctx);
+    if (rc) return rc;
     ctx->stream = static_cast<hipStream_t>(hip_stream);      // NULL is the device's default (null) stream
     return BDG_OK;
 }
@@ -146,7 +159,23 @@ int bdg_set_stream(bdg_ctx* ctx, void* hip_stream)
 int bdg_synchronize(bdg_ctx* ctx)
 {
     if (!ctx) return BDG_E_ARG;
-    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return sync_all(ctx);
+}
+
+int bdg_set_overlap(bdg_ctx* ctx, int on)
+{
+    if (!ctx) return BDG_E_ARG;
+    int rc = sync_all(ctx);
+    if (rc) return rc;
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (on && !ctx->aux_stream) {
+        BDG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[0], hipEventDisableTiming));
+        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[1], hipEventDisableTiming));
+    }
+    ctx->aux_count = 0;
+    ctx->overlap = on != 0;
     return BDG_OK;
 }
 
@@ -183,6 +212,9 @@ int bdg_extract_batch_dev(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* 
     if (n && (!d_bases || !d_off || !d_out)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
     if (umi_len == 0 || umi_len > 64) return bdg_fail(ctx, BDG_E_ARG, "umi_len out of range");
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // overlap mode: the caller alternates between two record buffers, so this extraction may overwrite what the match before
+    // the last one read: stay at most one match ahead
+    if (ctx->overlap && ctx->aux_count >= 2) BDG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[ctx->aux_count & 1], 0));
     return bdg_extract_launch(ctx, d_bases, d_off, n, total_bytes, umi_len, d_out);
 }
 
@@ -403,7 +435,20 @@ int bdg_nearest16_recs_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t
     static_assert(sizeof(bdg_extract_rec) == 32 && offsetof(bdg_extract_rec, bc_rank) == 20 && offsetof(bdg_extract_rec, flags) == 27,
                   "record layout the strided query reads");
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return bdg_nearest16_launch(ctx, reinterpret_cast<const uint32_t*>(d_recs) + 5, 8u, 1, n, max_ed, d_best_idx, d_best_ed, d_n_ties);
+    if (ctx->overlap) {
+        // behind everything queued on the main stream so far (the extraction that wrote d_recs), beside whatever comes next
+        BDG_HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+        BDG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_main, 0));
+        ctx->launch_stream = ctx->aux_stream;
+        ctx->aux_pending = true;
+    }
+    const int rc = bdg_nearest16_launch(ctx, reinterpret_cast<const uint32_t*>(d_recs) + 5, 8u, 1, n, max_ed, d_best_idx, d_best_ed, d_n_ties);
+    ctx->launch_stream = nullptr;
+    if (ctx->overlap) {
+        BDG_HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[ctx->aux_count & 1], ctx->aux_stream));
+        ctx->aux_count++;
+    }
+    return rc;
 }
 
 int bdg_nearest16(bdg_ctx* ctx, const uint32_t* q, uint32_t nq, const uint32_t* wl, uint32_t nw,

@@ -373,6 +373,7 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
     const uint64_t fp = nw ? wl_fingerprint(wl, nw) : 0;
     if (nw && ctx->w_n == nw && ctx->w_fp == fp) return BDG_OK;
     // nothing is published until every table of the new list is complete: a failure below leaves "no whitelist loaded"
+    if (ctx->aux_pending) { BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream)); ctx->aux_pending = false; }
     ctx->w_n = 0; ctx->w_fp = 0; ctx->w_probe_ready = false;
     if (nw == 0) return BDG_OK;
     std::vector<uint32_t> order(nw);
@@ -487,7 +488,7 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t qstride, in
 {
     if (nq == 0) return BDG_OK;
     if (ctx->w_n == 0) return bdg_fail(ctx, BDG_E_ARG, "no whitelist loaded (bdg_whitelist_load)");
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->launch_stream ? ctx->launch_stream : ctx->stream;
     const auto* srt = static_cast<const uint32_t*>(ctx->w_sorted.p);
     const auto* org = static_cast<const uint32_t*>(ctx->w_orig.p);
     const bool probe = ctx->n16_algo == 2 || (ctx->n16_algo == 0 && max_ed <= 2);

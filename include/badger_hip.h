@@ -96,7 +96,14 @@ const char* bdg_version(void);
  * caller made its own.  Until this is called the context works on a private non-blocking stream.
  * Lets the caller order the library's kernels with its own work and time with its own events. */
 int  bdg_set_stream(bdg_ctx* ctx, void* hip_stream);
-int  bdg_synchronize(bdg_ctx* ctx);
+int  bdg_synchronize(bdg_ctx* ctx);            /* waits for everything the context has queued (both streams, see below) */
+/* Batch pipelining.  With overlap on, bdg_nearest16_recs_dev runs on an auxiliary stream of the context: ordered behind
+ * everything queued so far on the main stream (the extraction that wrote d_recs), but beside what is queued afterwards -
+ * the whitelist match of batch i (latency-bound gathers) then overlaps the extraction of batch i + 1 (integer-issue bound).
+ * The caller alternates between two record / result buffers (bdg_extract_batch_dev waits for the match before the last
+ * one, so the extraction never runs more than one match ahead); results of a match are complete after
+ * bdg_synchronize() (or a device-wide synchronisation), not merely in main-stream order. */
+int  bdg_set_overlap(bdg_ctx* ctx, int on);
 int  bdg_profile_enable(bdg_ctx* ctx, int on);
 int  bdg_profile_reset(bdg_ctx* ctx);
 /* Synchronises, then writes up to cap entries; returns the number of kernels known. */

@@ -135,6 +135,63 @@ def test_extract_reads_built_around_sw_ties(ctx, orc):
     assert 0.5 < want["valid"].mean() < 1.0
 
 
+def test_overlap_mode_gives_the_same_calls(orc):
+    """bdg_set_overlap: the whitelist match of batch i runs on the context's auxiliary stream beside the extraction of
+    batch i + 1 (two record buffers).  Five different batches through the pipelined loop must give, batch by batch, the
+    records and calls of the plain sequential loop."""
+    import torch
+    dev = torch.device("cuda", 0)
+    wl = synth.make_whitelist(20000)
+    batches = []
+    for k in range(5):
+        bases, off = synth.make_reads(30000 + 1000 * k, wl, seed=50 + k, device=dev)
+        batches.append((torch.cat([bases, torch.zeros(64, dtype=torch.uint8, device=dev)]), off.contiguous(), len(off) - 1, int(off[-1])))
+    nmax = max(b[2] for b in batches)
+    results = {}
+    for overlap in (False, True):
+        c = _native.Context(0)
+        c.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        c.whitelist_load(wl)
+        c.set_overlap(overlap)
+        nb = 2 if overlap else 1
+        recs = [torch.zeros((nmax, 8), dtype=torch.int32, device=dev) for _ in range(nb)]
+        bi = [torch.zeros(nmax, dtype=torch.int32, device=dev) for _ in range(nb)]
+        be = [torch.zeros(nmax, dtype=torch.uint8, device=dev) for _ in range(nb)]
+        bt = [torch.zeros(nmax, dtype=torch.int16, device=dev) for _ in range(nb)]
+        out = []
+        for k, (bases, off, n, total) in enumerate(batches):
+            b = k % nb
+            c.extract_batch_dev(bases, off, n, total, 12, recs[b])
+            c.nearest16_recs_dev(recs[b], n, 2, bi[b], be[b], bt[b])
+            c.synchronize()                      # results of a match are complete after bdg_synchronize (both streams)
+            out.append((recs[b][:n].cpu().numpy().copy(), bi[b][:n].cpu().numpy().copy(), be[b][:n].cpu().numpy().copy(), bt[b][:n].cpu().numpy().copy()))
+        results[overlap] = out
+        assert c.extract_status()[0] == 0
+        c.close()
+    for a, b in zip(results[False], results[True]):
+        assert all((x == y).all() for x, y in zip(a, b))
+    # and without a synchronisation between the batches (the way bench.py runs it): the last two batches' buffers at the end
+    c = _native.Context(0)
+    c.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    c.whitelist_load(wl)
+    c.set_overlap(True)
+    recs = [torch.zeros((nmax, 8), dtype=torch.int32, device=dev) for _ in range(2)]
+    bi = [torch.zeros(nmax, dtype=torch.int32, device=dev) for _ in range(2)]
+    be = [torch.zeros(nmax, dtype=torch.uint8, device=dev) for _ in range(2)]
+    bt = [torch.zeros(nmax, dtype=torch.int16, device=dev) for _ in range(2)]
+    for rep in range(3):
+        for k, (bases, off, n, total) in enumerate(batches):
+            c.extract_batch_dev(bases, off, n, total, 12, recs[k % 2])
+            c.nearest16_recs_dev(recs[k % 2], n, 2, bi[k % 2], be[k % 2], bt[k % 2])
+    c.synchronize()
+    for k in (3, 4):
+        n = batches[k][2]
+        want = results[False][k]
+        assert (recs[k % 2][:n].cpu().numpy() == want[0]).all() and (bi[k % 2][:n].cpu().numpy() == want[1]).all()
+        assert (be[k % 2][:n].cpu().numpy() == want[2]).all() and (bt[k % 2][:n].cpu().numpy() == want[3]).all()
+    c.close()
+
+
 def test_extract_queue_overflow_is_contained_and_recovered(orc):
     """Adapter-dense reads (concatemers) against a deliberately tiny candidate queue.  The host-buffer call loops until
     the workspace fits and returns the oracle's records.  The device-resident call cannot loop by itself: an overflowing
