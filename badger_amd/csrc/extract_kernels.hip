@@ -17,11 +17,11 @@
 //                    of the cluster's windows (all start at the first hit's window start, so the first hit's strict and
 //                    relaxed windows are column prefixes of the union: their results are snapshots of the running key).
 //                    If the union cannot beat the first hit, no later hit of the cluster can replace it as "first
-//                    strictly best" (common.py:102-103) and they are skipped; otherwise they are re-queued (queue C) and
-//                    aligned one by one by a second launch (k_sw_requeued).
+//                    strictly best" (common.py:102-103) and they are skipped; otherwise they are re-queued (queue C).
 //   k_strict_filter  queue B only matters if an alignment reaches score 17, which implies semi-global edit distance <= 5:
 //                    Myers' 22-bit search per hit, after dropping read-strands the relaxed search has already decided;
-//                    survivors (queue D) are aligned by a third launch of k_sw_clusters (k_sw_survivors).
+//                    survivors join queue C.
+//   k_sw_singles     the same alignment kernel over queue C: re-queued hits and filter survivors, one by one.
 //   k_finalize_reads one lane per read: delta checks, reverse pass for strict hits, polyT re-search, barcode/UMI
 //                    slicing, strand choice, 32-byte record.
 // Every queue and every hot counter exists NSH times (see "Counters" below).
@@ -872,7 +872,7 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const unsigned long long m = __ballot(keep);
         if (m) {
             const uint32_t cnt = (uint32_t)__popcll(m);
-            if (nout + cnt > 128u) stage_flush(s_out[wv], nout, lane, qd, seg, shard, ctr(counters, shard, K_ND));
+            if (nout + cnt > 128u) stage_flush(s_out[wv], nout, lane, qd, seg, shard, ctr(counters, shard, K_NC));
             if (keep) s_out[wv][nout + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = h;
             nout += cnt; nkept += cnt;
         }
@@ -916,7 +916,7 @@ void k_strict_filter(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         process(h, on);
     }
     __builtin_amdgcn_wave_barrier();
-    stage_flush(s_out[wv], nout, lane, qd, seg, shard, ctr(counters, shard, K_ND));
+    stage_flush(s_out[wv], nout, lane, qd, seg, shard, ctr(counters, shard, K_NC));
     unsigned long long* const stat = ctr(counters, shard, K_STAT);
     if (lane == 0 && nkept) atomicAdd(&stat[S_NKEPT], (unsigned long long)nkept);
 #pragma unroll
@@ -1294,20 +1294,18 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
                            qa, (int)K_NAB, qcap, qc, counters, keys);
     }
     {
-        ScopedKernelTimer tm(ctx, "k_sw_requeued");
-        hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 2), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,
-                           qc, (int)K_NC, qcap, qa, counters, keys);      // single hits: nothing is re-queued
-    }
-    {
-        // every relaxed candidate is aligned now; queue A is consumed and its buffer receives the filter's survivors (queue D)
+        // Every candidate of the relaxed search that queue A's clusters hold is aligned now.  The hits those clusters re-queued
+        // (queue C) wait: the filter appends its survivors to the same queue and ONE more launch aligns both kinds (two
+        // latency-bound launches otherwise).  The filter's "relaxed search already succeeded" shortcut then only sees the
+        // first-hit alignments, which is all it needs: skipping is an optimisation, never a condition of correctness.
         ScopedKernelTimer tm(ctx, "k_strict_filter");
         hipLaunchKernelGGL(k_strict_filter, dim3(256 * 8), dim3(256), 0, st, d_bases, total_rounded, d_off,
-                           qb, qa, qcap, counters, keys);
+                           qb, qc, qcap, counters, keys);
     }
     {
-        ScopedKernelTimer tm(ctx, "k_sw_survivors");
+        ScopedKernelTimer tm(ctx, "k_sw_singles");
         hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 2), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,
-                           qa, (int)K_ND, qcap, qc, counters, keys);
+                           qc, (int)K_NC, qcap, qa, counters, keys);      // single hits: nothing is re-queued
     }
     {
         ScopedKernelTimer tm(ctx, "k_finalize_reads");
@@ -1394,6 +1392,6 @@ int bdg_extract_counters_impl(bdg_ctx* ctx, uint64_t out[8])
     int rc;
     if ((rc = read_counters(ctx, cs))) return rc;
     out[0] = cs.stat[S_NHITS]; out[1] = cs.a; out[2] = cs.stat[S_NBHITS]; out[3] = cs.stat[S_NSKIPPED];
-    out[4] = cs.stat[S_NKEPT]; out[5] = cs.c; out[6] = cs.stat[S_NWINDOWS]; out[7] = cs.b;
+    out[4] = cs.stat[S_NKEPT]; out[5] = cs.c - cs.stat[S_NKEPT]; out[6] = cs.stat[S_NWINDOWS]; out[7] = cs.b;    // queue C = re-queued + survivors
     return BDG_OK;
 }

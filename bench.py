@@ -2,7 +2,7 @@
 """Headline benchmark: barcode calls/s against the 737K-entry whitelist (BASELINE.json).
 
 One step = one pass of the hot path over one device-resident batch of synthetic ONT reads:
-  K1 extract (k_scan_reads, k_sw_clusters x3, k_strict_filter, k_finalize_reads)  -> 32-byte record per read
+  K1 extract (k_scan_reads, k_sw_clusters, k_strict_filter, k_sw_singles, k_finalize_reads)  -> 32-byte record per read
   K2 nearest16 (probe path, max_ed 2) of every extracted barcode against the whitelist
 A "call" is one read taken through both.  Reads are sharded per GPU (weak scaling, no
 collective on the data path); the process group is only used for the barrier and the
@@ -370,7 +370,7 @@ def bench_calls(args, rank, world, dev, local_dev):
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n / (elapsed / args.steps)
         # roofline of the dominant kernel: algorithmic bytes of the unit it serves / its own launch time
-        k1 = ("k_scan_reads", "k_sw_clusters", "k_sw_requeued", "k_sw_survivors", "k_strict_filter", "k_finalize_reads")
+        k1 = ("k_scan_reads", "k_sw_clusters", "k_sw_singles", "k_strict_filter", "k_finalize_reads")
         per_launch_ms = {k: v[1] / max(1, v[0]) for k, v in prof.items() if v[0]}
         dom = max(per_launch_ms, key=per_launch_ms.get)
         k1_bytes = total_bytes + 40 * n                # sum(L_i) + 8 (offset) + 32 (record) per read
