@@ -135,6 +135,18 @@ def test_extract_reads_built_around_sw_ties(ctx, orc):
     assert 0.5 < want["valid"].mean() < 1.0
 
 
+def test_synthetic_reads_are_the_same_on_cpu_and_gpu():
+    """bench.py builds its workload on the GPU; the same call on the CPU must give the same bytes (the workload can be
+    regenerated without a GPU; tests/test_host_mirror.py pins the CPU bytes)."""
+    import torch
+    wl = synth.make_whitelist(5000)
+    for seed in (1, 7):
+        bc, oc, tc = synth.make_reads(30000, wl, seed=seed, with_truth=True)
+        bg, og, tg = synth.make_reads(30000, wl, seed=seed, device="cuda", with_truth=True)
+        assert bool((oc == og.cpu()).all()) and bool((bc == bg.cpu()).all())
+        assert bool((tc["barcode"] == tg["barcode"].cpu()).all()) and bool((tc["revcomp"] == tg["revcomp"].cpu()).all())
+
+
 def test_overlap_mode_gives_the_same_calls(orc):
     """bdg_set_overlap: the whitelist match of batch i runs on the context's auxiliary stream beside the extraction of
     batch i + 1 (two record buffers).  Five different batches through the pipelined loop must give, batch by batch, the
