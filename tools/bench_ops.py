@@ -13,29 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from badger_amd import _native, synth  # noqa: E402
-
-
-def observed_barcodes(n_distinct, wl, seed=3):
-    """distinct 16-mers as extraction would see them: cell barcodes with ONT-like errors"""
-    rng = np.random.default_rng(seed)
-    cells = wl[rng.permutation(len(wl))[:5000]].astype(np.uint64)
-    out = np.zeros(0, dtype=np.uint32)
-    while len(out) < n_distinct:
-        m = 2 * n_distinct
-        r = cells[rng.integers(0, len(cells), m)]
-        # substitutions
-        for _ in range(2):
-            hit = rng.random(m) < 0.35
-            r = np.where(hit, r ^ (rng.integers(1, 4, m).astype(np.uint64) << (2 * rng.integers(0, 16, m).astype(np.uint64))), r)
-        # one deletion (shift the tail down, random new last base)
-        hit = rng.random(m) < 0.25
-        pos = rng.integers(0, 16, m).astype(np.uint64)
-        low = (np.uint64(1) << (2 * pos)) - np.uint64(1)
-        d = (r & low) | ((r >> np.uint64(2)) & ~low & np.uint64(0xFFFFFFFF)) | (rng.integers(0, 4, m).astype(np.uint64) << np.uint64(30))
-        r = np.where(hit, d, r)
-        out = np.unique(np.concatenate([out, (r & np.uint64(0xFFFFFFFF)).astype(np.uint32)]))
-    rng.shuffle(out)
-    return np.sort(out[:n_distinct])
+from bench import observed_barcodes  # noqa: E402  (the config-3 / 5 input of bench.py)
 
 
 def main():
@@ -99,6 +77,28 @@ def main():
         print(json.dumps({"op": "nearest16", "algo": {1: "scan", 2: "probe"}[algo], "max_ed": max_ed, "nq": m, "nw": len(wl), "ms": round(ms, 3),
                           "calls_per_s": m / ms * 1e3, "pair_evals_per_s": m * len(wl) / ms * 1e3 if algo == 1 else None}))
     ctx.nearest16_set_algo(0)
+    # distinct-barcode counting on the device (stage 1 -> 2 hand-off): 1M extraction records
+    n = 1000000
+    bases, off = synth.make_reads(n, wl, seed=1, device=dev)
+    total = int(off[-1])
+    bases = torch.cat([bases, torch.zeros(64, dtype=torch.uint8, device=dev)])
+    recs = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    ctx.extract_batch_dev(bases, off.contiguous(), n, total, 12, recs)
+    uq = torch.zeros(n, dtype=torch.int32, device=dev); ct = torch.zeros(n, dtype=torch.int32, device=dev)
+    fi = torch.zeros(n, dtype=torch.int32, device=dev); dn = torch.zeros(2, dtype=torch.int32, device=dev)
+    ctx.distinct_dev(recs, n, uq, ct, fi, dn)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.distinct_dev(recs, n, uq, ct, fi, dn)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    h = recs.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+    ok = (h["valid"] == 1) & ((h["flags"] & 2) != 0)
+    wu, wc = np.unique(h["bc_rank"][ok], return_counts=True)
+    nu = int(dn[0])
+    same = nu == len(wu) and bool((uq[:nu].cpu().numpy().view(np.uint32) == wu).all()) and bool((ct[:nu].cpu().numpy() == wc).all())
+    print(json.dumps({"op": "distinct_dev", "records": n, "distinct": nu, "ms": round(ms, 3), "records_per_s": n / ms * 1e3, "checks_ok": same}))
 
 
 if __name__ == "__main__":
