@@ -29,6 +29,7 @@ struct Chunk {
     uint64_t  bases_bytes = 0, ids_bytes = 0;
     int state = 0;              // 0 free, 1 filled, 2 handed to the consumer
     bool bad = false;           // the parser failed while filling this chunk
+    bool nomem = false;         // ... because a buffer could not be allocated (not because of the input)
 };
 
 void* pinned_alloc(size_t bytes, bool pinned)
@@ -169,7 +170,7 @@ void parse_loop(bdg_ingest* g)
             if (g->stop) return;
             c = &g->ring[tail];
         }
-        c->n = 0; c->bases_bytes = 0; c->ids_bytes = 0; c->bad = false;
+        c->n = 0; c->bases_bytes = 0; c->ids_bytes = 0; c->bad = false; c->nomem = false;
         // sized for a typical chunk up front (pinned allocations are slow), grown on demand
         bool ok = grow(c->off, c->off_cap, 0, (size_t)g->chunk_reads + 2, g->pinned) && grow(c->id_off, c->id_off_cap, 0, (size_t)g->chunk_reads + 2, false) &&
                   grow(c->bases, c->bases_cap, 0, (size_t)g->chunk_reads * 1200 + 64, g->pinned) && grow(c->ids, c->ids_cap, 0, (size_t)g->chunk_reads * 40 + 64, false);
@@ -206,7 +207,7 @@ void parse_loop(bdg_ingest* g)
                 chunk_end_read(*c);
             }
         }
-        if (!ok && !g->failed) { g->err = "out of host memory while reading"; g->failed = true; }
+        if (!ok && !g->failed) { g->err = "out of (pinned) host memory while reading"; g->failed = true; c->nomem = true; }
         if (g->failed) { eof = true; c->bad = true; }
         {
             std::lock_guard<std::mutex> lk(g->mu);
@@ -262,7 +263,7 @@ int bdg_ingest_next(bdg_ingest* g, bdg_ingest_chunk* out)
     g->cv.wait(lk, [&] { return g->ring[g->head].state == 1 || (g->done && g->ring[g->head].state != 1); });
     Chunk& c = g->ring[g->head];
     if (c.state != 1) return BDG_OK;                                          // end of file: n = 0
-    if (c.bad) return BDG_E_FORMAT;                                           // chunks before the failure were good
+    if (c.bad) return c.nomem ? BDG_E_NOMEM : BDG_E_FORMAT;                   // chunks before the failure were good
     c.state = 2;
     out->id = (uint32_t)g->head;
     out->n = c.n; out->bases = c.bases; out->off = c.off; out->total_bytes = c.bases_bytes;
