@@ -33,7 +33,7 @@ EXPORTS = [
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
-    "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records",
+    "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host",
     "bdg_ingest_open", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error", "bdg_ingest_close", "bdg_format_rows",
 ]
 
@@ -103,6 +103,7 @@ def load():
     L.bdg_extract_collect.argtypes = [vp, u32, vp]
     L.bdg_extract_keep_records.argtypes = [vp, C.c_int]
     L.bdg_kept_records.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.bdg_kept_records_to_host.argtypes = [vp, vp, u64]
     L.bdg_ingest_open.argtypes = [C.c_char_p, u32, u32, C.c_int, C.POINTER(vp)]
     L.bdg_ingest_next.argtypes = [vp, C.POINTER(IngestChunk)]
     L.bdg_ingest_release.argtypes = [vp, u32]
@@ -206,6 +207,14 @@ class Context:
         p, n = C.c_void_p(), C.c_uint64()
         self._check(self.lib.bdg_kept_records(self.h, C.byref(p), C.byref(n)))
         return p.value or 0, int(n.value)
+
+    def kept_records_to_host(self):
+        """the kept records as a numpy array (synchronises)"""
+        _, n = self.kept_records()
+        out = np.zeros(n, dtype=REC_DTYPE)
+        if n:
+            self._check(self.lib.bdg_kept_records_to_host(self.h, out.ctypes.data, n))
+        return out
 
     def extract_status(self):
         bad, nwin = C.c_uint64(), C.c_uint64()

@@ -15,7 +15,8 @@ from traceback import print_exc
 
 from . import _native
 from .barcode_graph import BarcodeGraph
-from .extract_raw_barcodes import BARCODE_CALLING_MODES, extract_barcodes_in_parallel, extract_barcodes_single_thread, is_fastx
+from .extract_raw_barcodes import (BARCODE_CALLING_MODES, extract_barcodes_in_parallel, extract_barcodes_single_thread,
+                                   extract_read_ids, is_fastx)
 
 logger = logging.getLogger("BarcodeGraph")
 
@@ -104,33 +105,46 @@ def main(args):
         with open(args.barcode_list) as f:
             barcode_list = set(f.read().split("\n"))
 
-    handoff_ctx = None
+    from .stage2 import Stage2, observed_from_strings
+    st2 = Stage2(args.threshold, device=args.device)
     if args.reads.endswith("tsv"):
-        read_assignment, barcodes = import_tsv(args.reads, bc_len)
+        read_assignment, _ = import_tsv(args.reads, bc_len)
         logger.info("Imported barcodes from file")
+        read_ids = [ra[0] for ra in read_assignment]
+        obs_rank, usable = observed_from_strings([ra[1] for ra in read_assignment], bc_len)
+        logger.info("Initializing Graph")
+        st2.count_host(obs_rank, usable)
+        st2.build_edges()
+    elif is_fastx(args.reads):
+        # FASTA / FASTQ: the records of every chunk stay on the device (stage 1 -> stage 2 hand-off without host strings):
+        # counting and the edge build run there, the host only gets the per-read ranks for the output file
+        import numpy as np
+        ctx = _native.default_context(args.device)
+        ctx.extract_keep_records(True)
+        read_ids = extract_read_ids(args.reads, args.data_type, device=args.device, skip_secondary=args.threads != 1)
+        logger.info("Initializing Graph")
+        st2.count_device(ctx)
+        st2.build_edges(ctx, on_device=True)
+        host = ctx.kept_records_to_host()
+        usable = (host["valid"] == 1) & ((host["flags"] & _native.FLAG_RANK_OK) != 0)
+        obs_rank = host["bc_rank"].astype(np.uint32)
+        ctx.extract_keep_records(False)
     else:
-        # FASTA / FASTQ: the records of every chunk also stay on the device (stage 1 -> stage 2 hand-off without host strings)
-        handoff_ctx = _native.default_context(args.device) if is_fastx(args.reads) else None
-        if handoff_ctx is not None:
-            handoff_ctx.extract_keep_records(True)
+        # BAM / SAM: the reference's chunk loop (pysam), barcodes as strings
         if args.threads == 1:
             read_assignment = extract_barcodes_single_thread(args.reads, args.data_type, device=args.device)
         else:
             read_assignment = extract_barcodes_in_parallel(args.reads, args.data_type, args.threads, device=args.device)
-        barcodes = [ra[1] for ra in read_assignment if ra[1] != "*"]
-
-    logger.info("Initializing Graph")
-    graph = BarcodeGraph(args.threshold, device=args.device)
-    if handoff_ctx is not None:
-        graph.graph_construction_from_device(handoff_ctx, bc_len)
-        handoff_ctx.extract_keep_records(False)
-    else:
-        graph.graph_construction(barcodes, bc_len, args.threads)
+        read_ids = [ra[0] for ra in read_assignment]
+        obs_rank, usable = observed_from_strings([ra[1] for ra in read_assignment], bc_len)
+        logger.info("Initializing Graph")
+        st2.count_host(obs_rank, usable)
+        st2.build_edges()
     logger.info("Graph construction done")
-    graph.cluster(true_barcodes, barcode_list, args.n_cells, bc_len, args.interval)
+    st2.cluster(true_barcodes, barcode_list, args.n_cells, bc_len, args.interval)
     logger.info("Clustering done")
-    graph.output_file(read_assignment, args.output, true_barcodes, bc_len, args.high_sens)
-    print(len(graph.counts) - len(graph.edges))          # "disconnected" count (reference :131-132)
+    st2.output_file(read_ids, obs_rank, usable, args.output, args.high_sens)
+    print(st2.disconnected())          # "disconnected" count (reference :131-132)
 
 
 if __name__ == "__main__":

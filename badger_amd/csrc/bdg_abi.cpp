@@ -394,6 +394,16 @@ int bdg_extract_keep_records(bdg_ctx* ctx, int on)
     return BDG_OK;
 }
 
+int bdg_kept_records_to_host(bdg_ctx* ctx, bdg_extract_rec* out, uint64_t cap)
+{
+    if (!ctx || (cap && !out)) return BDG_E_ARG;
+    const uint64_t n = ctx->x_allrecs_n < cap ? ctx->x_allrecs_n : cap;
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n) BDG_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->x_allrecs.p, sizeof(bdg_extract_rec) * n, hipMemcpyDeviceToHost, ctx->stream));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDG_OK;
+}
+
 int bdg_kept_records(bdg_ctx* ctx, const bdg_extract_rec** d_recs, uint64_t* n)
 {
     if (!ctx || !d_recs || !n) return BDG_E_ARG;

@@ -351,6 +351,38 @@ def extract_barcodes_in_parallel(input_file, mode, threads, device=0):
     return handler.read_storage
 
 
+class IdListHandler:
+    """collects the read ids only (stage 2 takes the barcodes from the device records)"""
+
+    def __init__(self):
+        self.read_ids = []
+
+    def add_header(self, header):
+        pass
+
+    def add_read(self, r):
+        self.read_ids.append(r.read_id)
+
+    def add_rows(self, rows):
+        self.read_ids.extend(row.split("\t", 1)[0] for row in rows)
+
+    def add_text(self, rows_bytes):
+        if rows_bytes:
+            self.read_ids.extend(line.split("\t", 1)[0] for line in rows_bytes.decode("ascii").split("\n")[:-1])
+
+    def dump_stats(self, read_stat):
+        pass
+
+
+def extract_read_ids(input_file, mode, device=0, skip_secondary=False):
+    """run the extraction (records stay with the context if it keeps them) and return the read ids in order"""
+    logger.info("Extracting from " + input_file)
+    handler = IdListHandler()
+    BarcodeCaller(BARCODE_CALLING_MODES[mode](device=device), handler).process(input_file, skip_secondary=skip_secondary)
+    logger.info("Finished barcode extraction")
+    return handler.read_ids
+
+
 def set_logger(logger_instance):
     logger_instance.setLevel(logging.INFO)
     if not logger_instance.handlers:

@@ -1,0 +1,246 @@
+"""Stage 2 on arrays: the same results as badger_amd.barcode_graph.BarcodeGraph (the dictionary mirror of the reference's
+barcode_graph.py), computed with numpy over rank-packed barcodes instead of Python dictionaries of strings.
+
+    counts            distinct barcodes, multiplicities, first-occurrence order   (index_bc_single_thread, :192-204)
+    graph             edge list from the GPU (bdg_graph_edges / bdg_graph_edges_dev)                  (:207-249)
+    cluster centres   get_cluster_centers                                                             (:252-277)
+    cluster           two breadth-first levels, conflicts dropped                                      (:279-301)
+    assignment        assign_by_cluster (+ postprocessing with --high_sens: bdg_nearest16)     (:322-329,:370-385)
+    output            <out>_output_file.tsv                                                            (:388-410)
+
+Why it can be done level by level without visiting order: a barcode reached on one level by two different centres
+belongs to nobody whatever the order; so level 1 is "non-centres adjacent to exactly one centre" and
+level 2 "unclustered barcodes adjacent to level-1 members of exactly one centre".  tests/test_stage2_arrays.py checks this
+module against the dictionary mirror on random graphs, tests/test_cli_gpu.py against the reference's own output files.
+"""
+import logging
+from statistics import mean
+
+import numpy as np
+
+from . import _native
+from .barcode_graph import qgram_threshold
+from .common import RANK, rank, rank_many
+
+logger = logging.getLogger("BarcodeGraph")
+NONE = np.uint32(0xFFFFFFFF)
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def unrank_many(ranks, length=16):
+    """uint32 ranks -> list[str] (common.py:27-38, vectorised)"""
+    r = np.asarray(ranks, dtype=np.uint64)
+    if len(r) == 0:
+        return []
+    codes = ((r[:, None] >> (2 * np.arange(length, dtype=np.uint64))) & np.uint64(3)).astype(np.intp)
+    raw = _ACGT[codes].tobytes().decode("ascii")
+    return [raw[i * length:(i + 1) * length] for i in range(len(r))]
+
+
+def observed_from_strings(barcodes_per_read, bc_len=16):
+    """Per read: the observed barcode as the reference sees it (badger.py:104-111: '*' = none; a bc_len + 1 string loses
+    its last base) -> (rank uint32[n], usable bool[n]).  usable = a bc_len-base barcode; a usable barcode with a base
+    outside ACGT raises KeyError like the reference's rank()."""
+    n = len(barcodes_per_read)
+    usable = np.zeros(n, dtype=bool)
+    kept, where = [], []
+    for i, s in enumerate(barcodes_per_read):
+        if s == "*":
+            continue
+        if len(s) == bc_len + 1:
+            s = s[:-1]
+        if len(s) == bc_len:
+            kept.append(s)
+            where.append(i)
+    ranks = np.zeros(n, dtype=np.uint32)
+    if kept:
+        idx = np.array(where, dtype=np.intp)
+        ranks[idx] = rank_many(kept, bc_len).astype(np.uint32)
+        usable[idx] = True
+    return ranks, usable
+
+
+class Stage2:
+    def __init__(self, threshold, device=0):
+        self.threshold = threshold
+        self.device = device
+        self.uniq = np.zeros(0, np.uint32)       # distinct barcodes, ascending
+        self.count = np.zeros(0, np.int64)
+        self.first = np.zeros(0, np.int64)       # position of the first occurrence among the counted barcodes
+        self.ea = self.eb = np.zeros(0, np.intp)  # edges as indices into uniq
+        self.owner = np.zeros(0, np.int64)       # per distinct barcode: index of its centre, -1 conflict, -2 unclustered
+        self.centers = []
+
+    def _ctx(self):
+        return _native.default_context(self.device)
+
+    # ------------------------------------------------------------------ counting
+    def count_host(self, obs_rank, usable):
+        """distinct barcodes of the usable reads, in read order (counts in first-occurrence order = argsort(first))"""
+        r = obs_rank[usable]
+        self.uniq, self.first, self.count = np.unique(r, return_index=True, return_counts=True)
+        self.uniq = self.uniq.astype(np.uint32)
+
+    def count_device(self, ctx):
+        """the same from the extraction records the context kept on the device (bdg_distinct_dev)"""
+        import torch
+        ptr, n = ctx.kept_records()
+        dev = torch.device("cuda", ctx.device)
+        m = max(n, 1)
+        uniq = torch.zeros(m, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(m, dtype=torch.int32, device=dev)
+        first = torch.zeros(m, dtype=torch.int32, device=dev)
+        dn = torch.zeros(2, dtype=torch.int32, device=dev)
+        if n:
+            ctx.distinct_dev(ptr, n, uniq, cnt, first, dn)
+            ctx.synchronize()
+        nu, nbad = int(dn[0]), int(dn[1])
+        if nbad:
+            raise KeyError("%d extracted barcodes hold a base outside ACGT" % nbad)      # reference: rank() raises KeyError
+        self.uniq = uniq[:nu].cpu().numpy().view(np.uint32).copy()
+        self.count = cnt[:nu].cpu().numpy().astype(np.int64)
+        self.first = first[:nu].cpu().numpy().view(np.uint32).astype(np.int64)
+        self._d_uniq = uniq                                    # stays on the device for the edge build
+        return nu
+
+    # ------------------------------------------------------------------ graph
+    def build_edges(self, ctx=None, on_device=False):
+        nu = len(self.uniq)
+        T = qgram_threshold(self.threshold, 16)
+        if nu < 2:
+            self.ea = self.eb = np.zeros(0, np.intp)
+            return
+        if on_device:
+            import torch
+            dev = torch.device("cuda", ctx.device)
+            cap = max(1024, 8 * nu)
+            while True:
+                d_edges = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+                d_tot = torch.zeros(1, dtype=torch.int64, device=dev)
+                ctx.graph_edges_dev(self._d_uniq, nu, self.threshold, T, d_edges, cap, d_tot)
+                ctx.synchronize()
+                tot = int(d_tot[0])
+                if tot <= cap:
+                    break
+                cap = tot
+            e = d_edges[:tot].cpu().numpy().view(np.uint32)
+            a, b = e[:, 0], e[:, 1]
+        else:
+            e = self._ctx().graph_edges(self.uniq, self.threshold, T)
+            a, b = e["a"], e["b"]
+        self.ea = np.searchsorted(self.uniq, a).astype(np.intp)
+        self.eb = np.searchsorted(self.uniq, b).astype(np.intp)
+
+    # ------------------------------------------------------------------ centres
+    def get_cluster_centers(self, true_barcodes, bc_len, barcode_list, n_cells, interval):
+        """reference :252-277, on arrays.  Returns the centres as ranks, in the reference's order."""
+        order = np.argsort(self.first, kind="stable")                     # insertion order of the counts dict
+        cnt_ins = self.count[order]
+        by_count = order[np.argsort(-cnt_ins, kind="stable")]             # sorted(..., reverse=True) keeps ties in insertion order
+        cutoff = max(mean([int(x) for x in cnt_ins[:n_cells]]) / 5.0, 5)
+        hi, lo = n_cells + n_cells * interval * 0.01, n_cells - n_cells * interval * 0.01
+        tbcs, n, i = [], 0, 0
+        cnt = self.count
+        if true_barcodes:
+            tbcs = [rank(bc, bc_len) for bc in true_barcodes]
+        elif barcode_list:
+            ok = [s for s in barcode_list if len(s) == bc_len and all(ch in RANK for ch in s)]
+            listed = np.isin(self.uniq, rank_many(ok, bc_len).astype(np.uint32)) if ok else np.zeros(len(self.uniq), bool)
+            while i < len(by_count) and cnt[by_count[i]] > cutoff and n <= hi:
+                if listed[by_count[i]]:
+                    tbcs.append(int(self.uniq[by_count[i]]))
+                    n += 1
+                i += 1
+        else:
+            while cnt[by_count[i]] > cutoff and n <= hi:
+                tbcs.append(int(self.uniq[by_count[i]]))
+                i += 1
+                n += 1
+        while n < lo:
+            tbcs.append(int(self.uniq[by_count[i]]))
+            i += 1
+            n += 1
+        return tbcs
+
+    # ------------------------------------------------------------------ clustering
+    def cluster(self, true_barcodes, barcode_list, n_cells, bc_len, interval):
+        self.centers = self.get_cluster_centers(true_barcodes, bc_len, barcode_list, n_cells, interval)
+        nu = len(self.uniq)
+        owner = np.full(nu, -2, dtype=np.int64)
+        cr = np.array(self.centers, dtype=np.uint32)
+        pos = np.searchsorted(self.uniq, cr)
+        present = ((pos < nu) & (self.uniq[np.minimum(pos, nu - 1)] == cr)) if nu else np.zeros(len(cr), bool)
+        cidx = pos[present]                                               # centres that were observed (the others have no edges)
+        owner[cidx] = cidx
+        u = np.concatenate([self.ea, self.eb])
+        v = np.concatenate([self.eb, self.ea])                            # every edge in both directions: u expands, v is reached
+        for level in (1, 2):
+            print(level)                                                  # the reference prints the level number (:289)
+            if level == 1:
+                expanding = np.zeros(nu, bool)
+                expanding[cidx] = True
+            else:
+                expanding = reached_once                                  # level-1 members that belong to a centre
+            sel = expanding[u] & (owner[v] == -2)
+            if not sel.any():
+                reached_once = np.zeros(nu, bool)
+                continue
+            node, cen = v[sel], owner[u[sel]]
+            pairs = np.unique(node * np.int64(nu) + cen)                  # distinct (barcode, centre) contacts
+            node_u = pairs // nu
+            first_of = np.concatenate([[True], node_u[1:] != node_u[:-1]])
+            cnt_c = np.add.reduceat(np.ones(len(pairs), np.int64), np.nonzero(first_of)[0])
+            nodes = node_u[first_of]
+            cen_first = (pairs % nu)[first_of]
+            single = cnt_c == 1
+            owner[nodes[single]] = cen_first[single]
+            owner[nodes[~single]] = -1                                    # reached by two centres on this level: nobody's
+            reached_once = np.zeros(nu, bool)
+            reached_once[nodes[single]] = True
+        self.owner = owner
+
+    def disconnected(self):
+        """what badger.py prints at the end (:131-132): len(counts) - len(edges).  The reference's `edges` is a defaultdict:
+        besides the barcodes that have an edge it holds a key for every barcode whose neighbours were looked up while
+        clustering, i.e. for every centre (observed or not)."""
+        keys = set(np.concatenate([self.ea, self.eb]).tolist())
+        unobserved = 0
+        for c in self.centers:
+            i = int(np.searchsorted(self.uniq, np.uint32(c)))
+            if i < len(self.uniq) and int(self.uniq[i]) == int(c):
+                keys.add(i)
+            else:
+                unobserved += 1
+        return len(self.uniq) - (len(keys) + unobserved)
+
+    # ------------------------------------------------------------------ assignment and output
+    def assigned_rank(self, high_sens=False):
+        """per distinct barcode: rank of the barcode it is corrected to, NONE if unassigned"""
+        out = np.full(len(self.uniq), NONE, dtype=np.uint32)
+        ok = self.owner >= 0
+        out[ok] = self.uniq[self.owner[ok]]
+        if high_sens:
+            centers = np.unique(out[ok])                                  # the centres in use, ascending: ties -> lowest rank
+            todo = np.nonzero(~ok)[0]
+            if len(centers) and len(todo):
+                idx, ed, _ = self._ctx().nearest16(self.uniq[todo], centers, 2)
+                near = ed < 3
+                out[todo[near]] = centers[idx[near]]
+        return out
+
+    def output_file(self, read_ids, obs_rank, usable, out, high_sens):
+        """<out>_output_file.tsv with columns readID, barcode (reference :388-410)"""
+        assigned = self.assigned_rank(high_sens)
+        per_read = np.full(len(read_ids), NONE, dtype=np.uint32)
+        if usable.any():
+            pos = np.searchsorted(self.uniq, obs_rank[usable])
+            per_read[usable] = assigned[pos]
+        got = per_read != NONE
+        names = np.empty(len(read_ids), dtype=object)
+        names[:] = "*"
+        if got.any():
+            distinct, inv = np.unique(per_read[got], return_inverse=True)
+            names[got] = np.array(unrank_many(distinct), dtype=object)[inv]
+        with open(out + "_output_file.tsv", "w") as f:
+            f.write("readID\tbarcode\n")
+            f.write("".join("%s\t%s\n" % (rid, bc) for rid, bc in zip(read_ids, names)))

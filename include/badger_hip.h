@@ -155,6 +155,9 @@ int  bdg_extract_collect(bdg_ctx* ctx, uint32_t slot, bdg_extract_rec* out);
  * an empty array; turning it off frees it. */
 int  bdg_extract_keep_records(bdg_ctx* ctx, int on);
 int  bdg_kept_records(bdg_ctx* ctx, const bdg_extract_rec** d_recs, uint64_t* n);
+/* The kept records copied to host memory (the first min(n, cap) of them); synchronises.  output_file
+ * (barcode_graph.py:388-410) needs every read's observed barcode once more, as a rank. */
+int  bdg_kept_records_to_host(bdg_ctx* ctx, bdg_extract_rec* out, uint64_t cap);
 
 /* ---- read ingest and row output (host side) --------------------------------------------- */
 /* [gzipped] FASTA / FASTQ -> chunks of at most chunk_reads reads {concatenated bases, offsets, ids}, parsed by a

@@ -174,7 +174,7 @@ def test_stage2_handoff_on_device_equals_the_tsv_route(tmp_path):
     """badger.py on a FASTQ (extraction records stay on the device -> bdg_distinct_dev -> bdg_graph_edges_dev) must write
     what it writes from the stage-1 TSV of the same reads (host strings -> rank -> host counting -> bdg_graph_edges),
     at both thresholds, and must really have taken the device route."""
-    from badger_amd import barcode_graph
+    from badger_amd import stage2
     path, rows, recs = _fastq_of(tmp_path, 30000, 23)
     tsv = str(tmp_path / "s1.tsv")
     erb.main(["--mode", "tenX_v3", "-i", path, "-o", tsv, "-t", "1"])
@@ -187,17 +187,17 @@ def test_stage2_handoff_on_device_equals_the_tsv_route(tmp_path):
         for k, reads in enumerate((tsv, path)):
             prefix = str(tmp_path / ("o%s_%d" % (thr, k)))
             calls = []
-            orig = barcode_graph.BarcodeGraph.graph_construction_from_device
+            orig = stage2.Stage2.count_device
 
-            def spy(self, ctx, bc_len=16, _orig=orig, _calls=calls):
+            def spy(self, ctx, _orig=orig, _calls=calls):
                 _calls.append(1)
-                return _orig(self, ctx, bc_len)
-            barcode_graph.BarcodeGraph.graph_construction_from_device = spy
+                return _orig(self, ctx)
+            stage2.Stage2.count_device = spy
             try:
                 with redirect_stdout(io.StringIO()):
-                    badger.main(["-r", reads, "-d", "tenX_v3", "-l", wl, "-c", "300", "-t", thr, "-o", prefix])
+                    badger.main(["-r", reads, "-d", "tenX_v3", "-l", wl, "-c", "300", "-t", thr, "-o", prefix] + (["-hs"] if thr == "2" else []))
             finally:
-                barcode_graph.BarcodeGraph.graph_construction_from_device = orig
+                stage2.Stage2.count_device = orig
             assert len(calls) == k                      # TSV: host route; FASTQ: device route
             outs.append(open(prefix + "_output_file.tsv").read())
         assert outs[0] == outs[1] and outs[0].count("\n") == 30001

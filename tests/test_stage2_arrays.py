@@ -1,0 +1,116 @@
+"""badger_amd.stage2 (stage 2 on arrays) against the dictionary mirror of the reference's BarcodeGraph
+(badger_amd.barcode_graph) and against the reference's own output fixture; edges come from the CPU oracle, no GPU."""
+import io
+import json
+import os
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from badger_amd import badger, synth
+from badger_amd.barcode_graph import BarcodeGraph
+from badger_amd.stage2 import Stage2, observed_from_strings, unrank_many
+from oracle import pyoracle as orc
+
+
+def _edges_from_oracle(st2, thr):
+    e = orc.graph_edges(st2.uniq, thr, threads=4)
+    st2.ea = np.searchsorted(st2.uniq, e["a"]).astype(np.intp)
+    st2.eb = np.searchsorted(st2.uniq, e["b"]).astype(np.intp)
+    return e
+
+
+def _dict_graph(barcodes, e, thr):
+    g = BarcodeGraph(thr)
+    g.index_barcodes(barcodes, 16)
+    g._take_edges(e["a"].tolist(), e["b"].tolist(), e["dist"].tolist())
+    return g
+
+
+def _reads(n_cells, n_reads, seed, extra=()):
+    rng = np.random.default_rng(seed)
+    cells = rng.integers(0, 1 << 32, n_cells, dtype=np.uint64)
+    # every other cell is one or two substitutions off its predecessor: neighbouring clusters that fight over barcodes
+    for k in range(1, n_cells, 2):
+        c = cells[k - 1] ^ (np.uint64(1 + k % 3) << np.uint64(2 * (k % 16)))
+        cells[k] = c ^ (np.uint64(2) << np.uint64(2 * ((k + 5) % 16))) if k % 4 == 1 else c
+    # skewed cell sizes, a substitution or two, sometimes a deletion: a graph with conflicts on both levels
+    w = np.exp(rng.standard_normal(n_cells))
+    pick = cells[rng.choice(n_cells, n_reads, p=w / w.sum())]
+    for _ in range(2):
+        hit = rng.random(n_reads) < 0.3
+        pick = np.where(hit, pick ^ (rng.integers(1, 4, n_reads).astype(np.uint64) << (2 * rng.integers(0, 16, n_reads).astype(np.uint64))), pick)
+    bcs = unrank_many(pick.astype(np.uint32))
+    out = []
+    for i, s in enumerate(bcs):
+        u = rng.random()
+        out.append("*" if u < 0.03 else (s + "A" if u < 0.06 else (s[:9] if u < 0.07 else s)))
+    return ["r%d" % i for i in range(n_reads)], out + list(extra)
+
+
+def test_unrank_many_and_observed():
+    rng = np.random.default_rng(0)
+    r = rng.integers(0, 1 << 32, 50, dtype=np.uint64).astype(np.uint32)
+    assert unrank_many(r) == [synth.rank_to_str(x) for x in r] and unrank_many(np.zeros(0, np.uint32)) == []
+    ranks, usable = observed_from_strings(["*", "ACGTACGTACGTACGT", "ACGTACGTACGTACGTA", "ACG", ""])
+    assert usable.tolist() == [False, True, True, False, False] and ranks[1] == ranks[2] == synth.str_to_rank("ACGTACGTACGTACGT")
+    with pytest.raises(KeyError):
+        observed_from_strings(["ACGTACGTACGTACGN"])
+
+
+@pytest.mark.parametrize("seed,thr,n_cells,hs_wl", [(1, 1, 40, "list"), (2, 2, 25, "list"), (3, 1, 30, "none"), (4, 2, 60, "true"), (5, 1, 8, "list")])
+def test_arrays_equal_dictionary_mirror(tmp_path, seed, thr, n_cells, hs_wl):
+    ids, bcs = _reads(n_cells, 6000, seed)
+    obs_rank, usable = observed_from_strings(bcs)
+    st2 = Stage2(thr)
+    st2.count_host(obs_rank, usable)
+    e = _edges_from_oracle(st2, thr)
+    read_assignment = [(i, b[:-1] if len(b) == 17 else b) for i, b in zip(ids, bcs)]
+    g = _dict_graph([b for b in bcs if b != "*"], e, thr)
+    assert [int(st2.uniq[i]) for i in np.argsort(st2.first, kind="stable")] == list(g.counts.keys())
+    assert [int(st2.count[i]) for i in np.argsort(st2.first, kind="stable")] == list(g.counts.values())
+    rng = np.random.default_rng(seed)
+    top = [synth.rank_to_str(k) for k, _ in sorted(g.counts.items(), key=lambda kv: -kv[1])[:200]]
+    wl = set(top[::2]) | {"", "ACGT"} if hs_wl == "list" else None
+    true_bcs = set(top[:15]) | {synth.rank_to_str(int(rng.integers(0, 1 << 32)))} if hs_wl == "true" else None
+    n_c = max(4, n_cells // 2)
+    with redirect_stdout(io.StringIO()) as o1:
+        st2.cluster(true_bcs, wl, n_c, 16, 25)
+    with redirect_stdout(io.StringIO()) as o2:
+        g.cluster(true_bcs, wl, n_c, 16, 25)
+    assert o1.getvalue() == o2.getvalue() == "1\n2\n"
+    assert st2.centers == g.get_cluster_centers(true_bcs, 16, wl, n_c, 25)
+    # per-barcode assignment
+    want = g.assign_by_cluster(16)
+    got = st2.assigned_rank(False)
+    for i, r in enumerate(st2.uniq):
+        s = synth.rank_to_str(int(r))
+        assert (synth.rank_to_str(int(got[i])) if got[i] != 0xFFFFFFFF else "") == want[s]
+    assert (got != 0xFFFFFFFF).sum() > 50 and (st2.owner == -1).sum() > 0           # both outcomes occur, conflicts too
+    # output file and the printed count
+    p1, p2 = str(tmp_path / "a"), str(tmp_path / "b")
+    st2.output_file(ids, obs_rank, usable, p1, False)
+    g.output_file(read_assignment, p2, true_bcs, 16, False)
+    assert open(p1 + "_output_file.tsv").read() == open(p2 + "_output_file.tsv").read()
+    assert st2.disconnected() == len(g.counts) - len(g.edges)
+
+
+def test_arrays_reproduce_the_references_stage2_fixture(tmp_path, golden_dir):
+    """the reference's own run (tests/golden): stage-1 TSV in, its edge list, its output file and its printed count out"""
+    g = json.load(open(os.path.join(golden_dir, "graph.json")))["c1_thr1"]
+    ra, _ = badger.import_tsv(os.path.join(golden_dir, "c1_expected.tsv"), 16)
+    obs_rank, usable = observed_from_strings([b for _, b in ra])
+    st2 = Stage2(1)
+    st2.count_host(obs_rank, usable)
+    assert [[int(st2.uniq[i]), int(st2.count[i])] for i in np.argsort(st2.first, kind="stable")] == g["counts"]
+    ed = np.array(g["edges"], dtype=np.int64)
+    st2.ea = np.searchsorted(st2.uniq, ed[:, 0].astype(np.uint32)).astype(np.intp)
+    st2.eb = np.searchsorted(st2.uniq, ed[:, 1].astype(np.uint32)).astype(np.intp)
+    wl = set(open(os.path.join(golden_dir, "c1_whitelist.txt")).read().split("\n"))
+    with redirect_stdout(io.StringIO()):
+        st2.cluster(None, wl, 50, 16, 25)
+    prefix = str(tmp_path / "o")
+    st2.output_file([r for r, _ in ra], obs_rank, usable, prefix, False)
+    assert open(prefix + "_output_file.tsv").read() == open(os.path.join(golden_dir, "c1_stage2_output_file.tsv")).read()
+    assert str(st2.disconnected()) == open(os.path.join(golden_dir, "c1_stage2_stdout_tail.txt")).read().strip()
