@@ -85,6 +85,33 @@ def test_pipeline_over_several_contexts_keeps_chunk_order(tmp_path):
         assert sizes == [size] * full + ([rest] if rest else [0])
 
 
+def test_stage1_empty_and_tiny_inputs(tmp_path):
+    """no reads at all, one read, reads with N and of length 0: the pipeline must write what the chunk loop of the
+    reference writes (a header, the rows, a .stats with the right totals)"""
+    from badger_amd import synth
+    from badger_amd.barcode_extraction.barcode_callers import record_to_row
+    from oracle import pyoracle as orc
+    header = "#read_id\tbarcode\tUMI\tBC_score\tvalid_UMI\tstrand\tpolyT_start\tR1_end\n"
+    empty = tmp_path / "e.fastq"
+    empty.write_text("")
+    for t in ("1", "3"):
+        out = str(tmp_path / ("e%s.tsv" % t))
+        erb.main(["--mode", "tenX_v3", "-i", str(empty), "-o", out, "-t", t])
+        assert open(out).read() == header
+        assert "Total reads:" in open(out + ".stats").read() and " 0" in open(out + ".stats").read().replace("\t", " ")
+    seqs = ["", "ACGTNACGT", "N" * 50,
+            "GATTACA" * 3 + "CTACACGACGCTCTTCCGATCT" + "ACGTACGTACGTACGT" + "AACCGGTTAACC" + "T" * 25 + "GATTACAGATTACA" * 4,
+            "GATTACA" * 3 + "CTACACGACGCTCTTCCGATCT" + "ACGTACGTNCGTACGT" + "AACCGGTTAACC" + "T" * 25 + "GATTACAGATTACA" * 4]
+    fa = tmp_path / "t.fa"
+    fa.write_text("".join(">s%d\n%s\n" % (i, s) for i, s in enumerate(seqs)))
+    out = str(tmp_path / "t.tsv")
+    erb.main(["--mode", "tenX_v3", "-i", str(fa), "-o", out, "-t", "1"])
+    b, o = synth.list_to_reads(seqs)
+    recs = orc.extract_batch(b, o, 12, threads=2)
+    assert open(out).read() == header + "".join(record_to_row("s%d" % i, s, r) + "\n" for i, (s, r) in enumerate(zip(seqs, recs)))
+    assert recs["valid"].tolist() == [0, 0, 0, 1, 1]
+
+
 def test_stage1_bad_base_raises_keyerror(tmp_path):
     p = tmp_path / "bad.fq"
     p.write_text("@a\nACGTACGTACGTACGTACGTAC\n+\n" + "I" * 22 + "\n@b\nACGTXCGT\n+\nIIIIIIII\n")
