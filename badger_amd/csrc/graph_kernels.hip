@@ -353,8 +353,7 @@ void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
 // is verified entry by entry in closed form (qgram_S + "is this the first matching position pair").
 // ---------------------------------------------------------------------------
 constexpr int QJ_NQ = 11;                        // six-mers per 16-mer
-constexpr int QJ_TAB_BITS = 12;                  // table slots (LDS: 16 KiB of a block's ~26 KiB, 6 blocks per CU)
-constexpr uint32_t QJ_PMAX = 1024;               // parts of a slice
+constexpr uint32_t QJ_W = 32768;                 // rows per slice = bytes of LDS counters per block
 
 __global__ __launch_bounds__(256)
 void k_qj_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
@@ -445,32 +444,31 @@ __device__ __forceinline__ uint32_t qgram_first_match(uint32_t a, uint32_t b)
     return best;
 }
 
-constexpr uint32_t QJ_GMAX = 64;      // slices per row (their bounds are kept in LDS; the launcher widens W to keep G <= QJ_GMAX)
+constexpr uint32_t QJ_GMAX = 64;      // slices whose bounds are kept in LDS at a time (a row walks its slices in groups of this many)
 constexpr uint32_t QJ_HCAP = 1024;    // rows j with S >= T waiting for their Myers pass (verified once per row)
 
+// One block per row i.  The later rows are taken in slices of W consecutive rows; within a slice S(i, j) lives in ONE BYTE
+// of LDS per row j (S <= 121 fits), addressed directly by j - slice start: counting a candidate entry is a single returning
+// ds_add, and the add that lifts a byte to T lists j for the Myers pass (a count passes T exactly once).  No keys, no probing,
+// no capacity to overflow: every slice takes any number of entries.
+template <uint32_t W>
 __global__ __launch_bounds__(256)
 void k_graph_qjoin(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_begin, uint32_t row_end,
                    const uint32_t* __restrict__ vals, const uint32_t* __restrict__ pos_of,
-                   const uint32_t* __restrict__ split, uint32_t G, uint32_t W,
-                   uint32_t thr, int32_t T, int force_closed_form,
+                   const uint32_t* __restrict__ split, uint32_t G,
+                   uint32_t thr, int32_t T, int closed_form,
                    bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges)
 {
-    constexpr uint32_t QJ_TAB = 1u << QJ_TAB_BITS;   // slots: (j + 1) << 7 | count
-    constexpr uint32_t QJ_CAP = QJ_TAB / 2;          // entries per pass (load <= 50 %)
-    __shared__ __attribute__((aligned(16))) uint32_t s_tab[QJ_TAB];
-    uint32_t* const s_pcnt = s_tab;                  // the parts are counted while the table is empty (and zeroed again)
-    static_assert(QJ_PMAX <= QJ_TAB, "part counters live in the table");
-    __shared__ uint32_t s_split[QJ_NQ][QJ_GMAX + 1]; // bounds of the row's 11 bucket tails, slice by slice
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[W / 4];   // S(i, j) for the rows j of the current slice, one byte each
+    __shared__ uint32_t s_split[QJ_NQ][QJ_GMAX + 1];                 // bounds of the row's 11 bucket tails, slice by slice
     __shared__ uint32_t s_hit[QJ_HCAP];
-    __shared__ uint32_t s_dummy[256];                // never 0, never a key: what idle lanes aim their atomics at
-    __shared__ uint32_t s_nh, s_pmax, s_over;
+    __shared__ uint32_t s_nh, s_over;
     __shared__ EdgeStage s_edges[4];
     __shared__ uint32_t s_ecnt[4];
     __shared__ unsigned long long s_ebase;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t ne = 0;
-    for (uint32_t k = tid; k < QJ_TAB; k += 256u) s_tab[k] = 0u;
-    s_dummy[tid] = 0xFFFFFFFFu;
+    for (uint32_t k = tid; k < W / 4; k += 256u) s_cnt[k] = 0u;
     const uint32_t Tc = T < 1 ? 1u : (uint32_t)T;
 
     for (uint32_t i = row_begin + blockIdx.x; i < row_end; i += gridDim.x) {
@@ -497,163 +495,101 @@ void k_graph_qjoin(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
             if (tid == 0) s_nh = 0u;
             __syncthreads();
         };
-        uint32_t nh0 = 0;                                            // list length when the current pass began
+        uint32_t nh0 = 0;                                            // list length when the current slice began
         __syncthreads();                                             // previous row done with s_split / s_hit
-        // the bounds of all the row's slices in one round trip: row i lies in slice g0, its candidates in slices g0 .. G-1
-        const uint32_t g0 = i / W, ng = G - g0;
-        for (uint32_t t = tid; t < QJ_NQ * (ng + 1u); t += 256u) {
-            const uint32_t sg = t / (ng + 1u), gi = t % (ng + 1u);
-            uint32_t v = split[(size_t)((a >> (2u * sg)) & 0xFFFu) * (G + 1u) + g0 + gi];
-            if (gi == 0u) { const uint32_t tail = pos_of[(size_t)i * QJ_NQ + sg] + 1u; v = v > tail ? v : tail; }   // behind row i's own entry
-            s_split[sg][gi] = v;
-        }
         if (tid == 0) { s_nh = 0u; s_over = 0u; }
-        __syncthreads();
-        for (uint32_t gi = 0; gi < ng; ++gi) {
-            // the slice's candidates are 11 runs of the sorted entry array (one per six-mer of row i); wave w walks runs
-            // w, w + 4, w + 8 in strides of 64
-            uint32_t total = 0;
+        const uint32_t g0 = i / W;                                   // row i lies in slice g0, its candidates in slices g0 .. G-1
+        for (uint32_t gg = g0; gg < G; gg += QJ_GMAX) {
+            // the bounds of up to QJ_GMAX slices in one round trip
+            const uint32_t ng = G - gg < QJ_GMAX ? G - gg : QJ_GMAX;
+            __syncthreads();
+            for (uint32_t t = tid; t < QJ_NQ * (ng + 1u); t += 256u) {
+                const uint32_t sg = t / (ng + 1u), gi = t % (ng + 1u);
+                uint32_t v = split[(size_t)((a >> (2u * sg)) & 0xFFFu) * (G + 1u) + gg + gi];
+                if (gg + gi == g0) { const uint32_t tail = pos_of[(size_t)i * QJ_NQ + sg] + 1u; v = v > tail ? v : tail; }   // behind row i's own entry
+                s_split[sg][gi] = v;
+            }
+            __syncthreads();
+            for (uint32_t gi = 0; gi < ng; ++gi) {
+                uint32_t total = 0;
 #pragma unroll
-            for (int sg = 0; sg < QJ_NQ; ++sg) {
-                const uint32_t lo = s_split[sg][gi], hi = s_split[sg][gi + 1];
-                total += hi > lo ? hi - lo : 0u;
-            }
-            if (total == 0) continue;
-            // number of parts: 1 if the slice fits, else counted (a part never exceeds 3/4 of the table)
-            uint32_t P = 1;
-            bool closed = force_closed_form != 0;
-            if (!closed && total > QJ_CAP) {
-                P = (total + QJ_CAP - 1u) / QJ_CAP;
-                for (;;) {
-                    if (P > QJ_PMAX) { closed = true; break; }
-                    for (uint32_t k = tid; k < P; k += 256u) s_pcnt[k] = 0u;
-                    if (tid == 0) s_pmax = 0u;
-                    __syncthreads();
-                    for (int sg = wv; sg < QJ_NQ; sg += 4) {
-                        const uint32_t hi = s_split[sg][gi + 1];
-                        for (uint32_t k = s_split[sg][gi] + (uint32_t)lane; k < hi; k += 64u) {
-                            const uint32_t j = vals[k] >> 4;
-                            if (j > i) atomicAdd(&s_pcnt[((j * 0x85EBCA6Bu) >> 12) % P], 1u);
-                        }
-                    }
-                    __syncthreads();
-                    uint32_t mx = 0;
-                    for (uint32_t k = tid; k < P; k += 256u) mx = s_pcnt[k] > mx ? s_pcnt[k] : mx;
-                    if (mx) atomicMax(&s_pmax, mx);
-                    __syncthreads();
-                    const uint32_t pm = s_pmax;
-                    __syncthreads();
-                    if (pm <= QJ_TAB / 4u * 3u) break;
-                    P *= 2u;
-                }
-                for (uint32_t k = tid; k < (P < QJ_PMAX ? P : QJ_PMAX); k += 256u) s_pcnt[k] = 0u;
-                __syncthreads();
-            }
-            if (closed) {
-                // entry by entry: the pair is reported by its first matching position pair only
-                for (int sg = wv; sg < QJ_NQ; sg += 4) {
+                for (int sg = 0; sg < QJ_NQ; ++sg) {
                     const uint32_t lo = s_split[sg][gi], hi = s_split[sg][gi + 1];
-                    for (uint32_t k0 = lo; k0 < hi; k0 += 64u) {
-                        const uint32_t k = k0 + (uint32_t)lane;
+                    total += hi > lo ? hi - lo : 0u;
+                }
+                if (total == 0) continue;
+                const uint32_t base_row = (gg + gi) * W;
+                // this wave's share of the slice: the runs of six-mers wv, wv + 4, wv + 8 as one flat list (entry t lies at
+                // vals[t + off]), eight loads in flight per lane
+                const uint32_t loA = s_split[wv][gi], hiA = s_split[wv][gi + 1];
+                const uint32_t loB = s_split[wv + 4][gi], hiB = s_split[wv + 4][gi + 1];
+                const bool hasC = wv + 8 < QJ_NQ;
+                const uint32_t loC = hasC ? s_split[hasC ? wv + 8 : 0][gi] : 0u, hiC = hasC ? s_split[hasC ? wv + 8 : 0][gi + 1] : 0u;
+                const uint32_t lenA = hiA > loA ? hiA - loA : 0u, lenB = hiB > loB ? hiB - loB : 0u, lenC = hiC > loC ? hiC - loC : 0u;
+                const uint32_t eB = lenA + lenB, wt = eB + lenC;
+                const uint32_t offA = loA, offB = loB - lenA, offC = loC - eB;
+                if (closed_form) {
+                    // cross-check path: every entry verified by itself; a pair is reported by its first matching position pair only
+                    for (uint32_t t0 = 0; t0 < wt; t0 += 64u) {
+                        const uint32_t t = t0 + (uint32_t)lane;
                         uint32_t b = 0, d = 99u; bool on = false;
-                        if (k < hi) {
-                            const uint32_t v = vals[k];
+                        if (t < wt) {
+                            const uint32_t sgi = t < lenA ? (uint32_t)wv : (t < eB ? (uint32_t)wv + 4u : (uint32_t)wv + 8u);
+                            const uint32_t v = vals[t + (t < lenA ? offA : (t < eB ? offB : offC))];
                             const uint32_t j = v >> 4;
                             if (j > i) {
                                 b = ranks[j];
-                                on = qgram_first_match(a, b) == (uint32_t)sg * 16u + (v & 15u) && qgram_S(a, b) >= Tc;
+                                on = qgram_first_match(a, b) == sgi * 16u + (v & 15u) && qgram_S(a, b) >= Tc;
                                 if (on) d = dmin3_peq(peq, b);
                             }
                         }
                         edge_push(on && d <= thr, a, b, d, s_edges[wv], ne, lane, out, cap, n_edges);
                     }
+                    continue;
                 }
-                continue;
-            }
-            for (uint32_t part = 0; part < P; ++part) {
-                // table size for this pass: at least twice the entries (P == 1), the whole table otherwise
-                uint32_t tb = QJ_TAB_BITS;
-                if (P == 1) { tb = 6; while ((1u << tb) < 2u * total) ++tb; }
-                const uint32_t mask = (1u << tb) - 1u;
-                {
-                    // this wave's runs (six-mers wv, wv + 4, wv + 8) as one flat list: entry t lies at vals[t + off]
-                    const uint32_t loA = s_split[wv][gi], hiA = s_split[wv][gi + 1];
-                    const uint32_t loB = s_split[wv + 4][gi], hiB = s_split[wv + 4][gi + 1];
-                    const bool hasC = wv + 8 < QJ_NQ;
-                    const uint32_t loC = hasC ? s_split[hasC ? wv + 8 : 0][gi] : 0u, hiC = hasC ? s_split[hasC ? wv + 8 : 0][gi + 1] : 0u;
-                    const uint32_t lenA = hiA > loA ? hiA - loA : 0u, lenB = hiB > loB ? hiB - loB : 0u, lenC = hiC > loC ? hiC - loC : 0u;
-                    const uint32_t eB = lenA + lenB, wt = eB + lenC;
-                    const uint32_t offA = loA, offB = loB - lenA, offC = loC - eB;
-                    for (uint32_t t0 = 0; t0 < wt; t0 += 512u) {
-                        uint32_t jv[8];
+                for (uint32_t t0 = 0; t0 < wt; t0 += 512u) {
+                    uint32_t jv[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {                // eight loads in flight per lane: one round trip per 512 entries
-                            const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
-                            const uint32_t o = t < lenA ? offA : (t < eB ? offB : offC);
-                            jv[u] = t < wt ? vals[t + o] >> 4 : 0u;
-                        }
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
+                        const uint32_t o = t < lenA ? offA : (t < eB ? offB : offC);
+                        jv[u] = t < wt ? vals[t + o] >> 4 : 0u;
+                    }
 #pragma unroll
-                        for (int grp = 0; grp < 2; ++grp) {
-                            // four entries per lane probe the table in lock step (four LDS atomics in flight)
-                            uint32_t hh[4], jj[4]; bool pend[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const uint32_t j = jv[4 * grp + u];
-                                jj[u] = j;
-                                pend[u] = j > i && (P == 1 || ((j * 0x85EBCA6Bu) >> 12) % P == part);   // j <= i: nothing, or row i's own repeat
-                                hh[u] = (j * 0x9E3779B1u) >> (32 - tb);
-                            }
-                            // Branch-free probing: a lane with nothing to do aims its compare-and-swap at a private dummy word
-                            // that can neither be claimed nor match; every branch below is wave-uniform.
-                            while (__ballot(pend[0] || pend[1] || pend[2] || pend[3])) {
-                                uint32_t cur[4];
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    uint32_t* const slot = pend[u] ? &s_tab[hh[u]] : &s_dummy[tid];
-                                    cur[u] = atomicCAS(slot, 0u, ((jj[u] + 1u) << 7) | 1u);
-                                }
-                                bool reached[4];
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const bool fresh = cur[u] == 0u;                                    // claimed an empty slot: S = 1
-                                    const bool same = (cur[u] >> 7) == jj[u] + 1u;                      // the slot is j's: S += 1
-                                    reached[u] = fresh && Tc == 1u;
-                                    if (__ballot(same)) {
-                                        uint32_t* const slot = same ? &s_tab[hh[u]] : &s_dummy[tid];
-                                        const uint32_t old = atomicAdd(slot, same ? 1u : 0u);
-                                        reached[u] = reached[u] || (same && (old & 127u) + 1u == Tc);   // a count passes T exactly once
-                                    }
-                                    pend[u] = pend[u] && !fresh && !same;
-                                    hh[u] = (hh[u] + 1u) & mask;
-                                }
-                                if (__ballot(reached[0] || reached[1] || reached[2] || reached[3])) {
-#pragma unroll
-                                    for (int u = 0; u < 4; ++u) {
-                                        if (reached[u]) {                                                // lists j for the Myers pass
-                                            const uint32_t at = atomicAdd(&s_nh, 1u);
-                                            if (at < QJ_HCAP) s_hit[at] = jj[u]; else s_over = 1u;
-                                        }
-                                    }
-                                }
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t j = jv[u];
+                        if (j > i) {                                              // (nothing, or row i's own repeat of the six-mer, otherwise)
+                            const uint32_t off = j - base_row, sh = (off & 3u) * 8u;
+                            const uint32_t old = atomicAdd(&s_cnt[off >> 2], 1u << sh);
+                            if (((old >> sh) & 0xFFu) + 1u == Tc) {               // this entry lifts S(i, j) to T: list j
+                                const uint32_t at = atomicAdd(&s_nh, 1u);
+                                if (at < QJ_HCAP) s_hit[at] = j; else s_over = 1u;
                             }
                         }
                     }
                 }
                 __syncthreads();
-                if (s_over) {
-                    // the list overflowed during this pass: drop what the pass listed and take its hits from the table instead
-                    __syncthreads();
+                const bool over = s_over != 0u;
+                const uint32_t nh1 = s_nh;
+                if (over) {
+                    // the list overflowed during this slice: drop what the slice listed and take its rows from the counters
+                    // instead (each lane clears the words it has read: no other wave touches them before the barrier below)
+                    __syncthreads();                                              // everyone has read s_over / s_nh
                     if (tid == 0) { s_nh = nh0; s_over = 0u; }
-                    for (uint32_t s0 = (uint32_t)wv * 64u; s0 <= mask; s0 += 256u) {
-                        const uint32_t cur = s_tab[s0 + lane];
-                        const bool hit = cur != 0u && (cur & 127u) >= Tc;
-                        if (__ballot(hit)) verify(hit, (cur >> 7) - 1u);
+                    for (uint32_t k0 = (uint32_t)wv * 64u; k0 < W / 4; k0 += 256u) {
+                        const uint32_t w = s_cnt[k0 + lane];
+                        s_cnt[k0 + lane] = 0u;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool hit = ((w >> (8 * q)) & 0xFFu) >= Tc;
+                            if (__ballot(hit)) verify(hit, base_row + 4u * (k0 + (uint32_t)lane) + (uint32_t)q);
+                        }
                     }
+                } else {
+                    nh0 = nh1;                                                    // (< QJ_HCAP: the list did not overflow)
+                    for (uint32_t k = (uint32_t)tid * 4u; k < W / 4; k += 1024u) *reinterpret_cast<uint4*>(&s_cnt[k]) = make_uint4(0u, 0u, 0u, 0u);
                 }
-                // clear the part of the table this pass used
-                for (uint32_t k = (uint32_t)tid * 4u; k <= mask; k += 1024u) *reinterpret_cast<uint4*>(&s_tab[k]) = make_uint4(0u, 0u, 0u, 0u);
                 __syncthreads();
-                nh0 = s_nh < QJ_HCAP ? s_nh : QJ_HCAP;
                 if (nh0 > QJ_HCAP / 2u) { flush_hits(nh0); nh0 = 0u; }
             }
         }
@@ -683,11 +619,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
     int rc;
     if (qjoin) {
         const size_t m = (size_t)n * QJ_NQ;
-        // slices of W rows: a row meets ~0.03 W entries per slice (11 buckets x 11 W / 4096); aim at half a table
-        // slices of W rows: a row meets ~0.03 W entries per slice (11 buckets x 11 W / 4096), i.e. about half a pass
-        // (measured at 500K rows: W = 32K 27.6 ms, 16K 36 ms, 64K 28 ms; 8K- and 16K-slot tables 32 - 40 ms)
-        uint32_t W = (1u << QJ_TAB_BITS) * 8u;
-        while ((n + W - 1) / W > QJ_GMAX) W *= 2u;
+        const uint32_t W = QJ_W;
         const uint32_t G = (n + W - 1) / W;
         size_t t_sort = 0;
         uint32_t* nul = nullptr;
@@ -711,7 +643,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
         }
         {
             ScopedKernelTimer tm(ctx, "k_graph_qjoin");
-            auto kern = k_graph_qjoin;
+            auto kern = k_graph_qjoin<QJ_W>;
             int per_cu = 0;
             BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0));
             if (per_cu < 1) per_cu = 1;
@@ -719,7 +651,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             BDG_HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
             uint32_t grid = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;      // resident grid, rows interleaved
             if (grid > row_end - row_begin) grid = row_end - row_begin;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, d_ranks, n, row_begin, row_end, v_out, pos_of, split, G, W,
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, d_ranks, n, row_begin, row_end, v_out, pos_of, split, G,
                                thr, qgram_T, ctx->graph_algo == 4 ? 1 : 0, d_out, cap, reinterpret_cast<unsigned long long*>(d_n_edges));
         }
         BDG_HIP_TRY(ctx, hipGetLastError());
