@@ -128,21 +128,23 @@ __device__ __forceinline__ uint32_t range_mask16(int32_t lo, int32_t hi)
 // Clusters are staged in a per-wave LDS region and flushed to the global queues with ONE packed
 // 64-bit reservation (A count | B count << 32) every few tasks.
 // ---------------------------------------------------------------------------
-constexpr int TASK_READS = 8;
+constexpr int TASK_READS = 16;
 constexpr uint32_t WENT = 256;             // per-wave staging (2 KiB)
-constexpr uint32_t WFLUSH = 128;           // flush once this many clusters are staged
 constexpr int TASK_SHARDS = NSH;
 
 struct TaskTab {                           // per wave, double buffered
-    uint4    rd[TASK_READS];               // per read {A lo, A hi, -B, L}: vector `slot` of the task lies at byte A + 16 * slot and
-                                           // starts at read position 16 * slot - B
+    uint4    rd[TASK_READS];               // per read {A, -B, L, L - 5}: vector `slot` of the task lies at byte base + A + 16 * slot
+                                           // (A is relative, modulo 2^32) and starts at read position 16 * slot - B
     uint32_t pend[TASK_READS];             // vectors of reads 0..j inclusive
+    uint32_t base_lo, base_hi;             // byte offset of the task's first vector (0 for a task without vectors)
+    uint32_t last_off;                     // offset of the task's last vector from there
 };
 
 __device__ __forceinline__ uint32_t find_read(const TaskTab& t, uint32_t slot)
 {
-    // number of reads whose vectors end at or before `slot` (pend is non-decreasing)
-    uint32_t j = t.pend[3] <= slot ? 4u : 0u;
+    // number of reads whose vectors end at or before `slot` (pend is non-decreasing), at most TASK_READS - 1
+    uint32_t j = t.pend[7] <= slot ? 8u : 0u;
+    j += t.pend[j + 3] <= slot ? 4u : 0u;
     j += t.pend[j + 1] <= slot ? 2u : 0u;
     j += t.pend[j] <= slot ? 1u : 0u;
     return j;
@@ -150,6 +152,10 @@ __device__ __forceinline__ uint32_t find_read(const TaskTab& t, uint32_t slot)
 
 // 16 bytes of the read stream, non-temporal: every byte is used once
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long b)      // set bits of b in the lanes below this one
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+}
 __device__ __forceinline__ uint4 ld_stream16(const uint8_t* p)
 {
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
@@ -172,7 +178,26 @@ __device__ __forceinline__ uint32_t gather_even(uint32_t x)   // bit 2k -> bit k
     return (x | (x >> 8)) & 0x0000FFFFu;
 }
 
-__global__ __launch_bounds__(256, 4)
+// Hit word of a vector as the probes deliver it ("Z form"): byte i = forward hits of positions 4i..4i+3 in the low nibble,
+// reverse hits of the same positions in the high nibble.
+__device__ __forceinline__ uint32_t z_low_nibbles(uint32_t z)      // low nibbles of the four bytes -> 16 bits
+{
+    uint32_t x = z & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    return (x | (x >> 8)) & 0x0000FFFFu;
+}
+__device__ __forceinline__ uint32_t z_from_mask16(uint32_t m)      // 16 bits -> the same bits in both nibbles of each byte
+{
+    uint32_t x = m & 0xFFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    return x | (x << 4);
+}
+
+constexpr int SCAN_WAVES = 8;              // waves per block (they share the 16 KiB probe table)
+constexpr int SCAN_BLOCKS_PER_CU = 2;      // (LDS)
+
+__global__ __launch_bounds__(64 * SCAN_WAVES, SCAN_BLOCKS_PER_CU)
 void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                   const uint64_t* __restrict__ off, uint32_t n,
                   const uint8_t* __restrict__ kmer7,
@@ -181,21 +206,28 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                   unsigned long long* __restrict__ counters,
                   unsigned long long* __restrict__ keys)
 {
-    // 7-mer code (14 bits, base p in bits 0-1) -> bit0/1: bases p..p+5 / p+1..p+6 are an R1 6-mer, bit2/3: same for
+    // 7-mer code (14 bits, base p in bits 0-1) -> bit0/1: bases p..p+5 / p+1..p+6 are an R1 6-mer, bit4/5: same for
     // the reverse complement of one.  One probe answers two positions.
-    __shared__ __attribute__((aligned(16))) uint8_t s_kmer[16384];
-    __shared__ uint2 s_ent[4][WENT];     // per-wave staging of lane-vectors with hits (see emit)
-    __shared__ uint32_t s_ringr[4][32];  // read index of each ring slot
-    __shared__ TaskTab s_tab[4][2];
-    __shared__ int32_t s_pt[4][32][2];   // polyT of the reads of the wave's last 4 tasks (ring)
-    __shared__ uint2 s_cand[4][192];     // pending T/A-rich candidates: even bits of .x = flags of the lane's 16 bases, of .y = next 16
-    __shared__ uint32_t s_candi[4][192]; // (p0 + 16) << 6 | ring << 1 | type
-    __shared__ uint32_t s_ptmin[4][32][2];  // per ring slot and strand: min of (window start << 5 | offset), 0xFFFFFFFF = none
-    __shared__ int32_t s_ringL[4][32];   // read length of each ring slot
+    // All of the block's LDS is one object with the probe table first, i.e. at LDS address 0: a probe's address is its index.
+    struct Shared {
+        uint8_t  kmer[16384];
+        uint8_t  buf[SCAN_WAVES][2][1024];   // per wave: the vectors of the next two steps (LDS-DMA)
+        uint2    ent[SCAN_WAVES][WENT];      // per-wave staging of lane-vectors with hits (see emit)
+        uint32_t ringr[SCAN_WAVES][32];      // read index of each ring slot
+        TaskTab  tab[SCAN_WAVES][2];
+        int32_t  pt[SCAN_WAVES][32][2];      // polyT of the reads of the wave's last tasks (ring)
+        uint2    cand[SCAN_WAVES][192];      // pending T/A-rich candidates: .x = flags of the lane's 16 bases (T even bits, A odd), .y = of the next 16
+        uint32_t candi[SCAN_WAVES][192];     // (p0 + 16) << 6 | ring << 1 | type
+        uint32_t ptmin[SCAN_WAVES][32][2];   // per ring slot and strand: min of (window start << 5 | offset), 0xFFFFFFFF = none
+        int32_t  ringL[SCAN_WAVES][32];      // read length of each ring slot
+    };
+    __shared__ __attribute__((aligned(16))) Shared sh;
+    auto& s_kmer = sh.kmer; auto& s_buf = sh.buf; auto& s_ent = sh.ent; auto& s_ringr = sh.ringr; auto& s_tab = sh.tab;
+    auto& s_pt = sh.pt; auto& s_cand = sh.cand; auto& s_candi = sh.candi; auto& s_ptmin = sh.ptmin; auto& s_ringL = sh.ringL;
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        reinterpret_cast<uint4*>(s_kmer)[tid + 256 * k] = reinterpret_cast<const uint4*>(kmer7)[tid + 256 * k];
+    for (int k = 0; k < 1024 / (64 * SCAN_WAVES); ++k)
+        reinterpret_cast<uint4*>(s_kmer)[tid + 64 * SCAN_WAVES * k] = reinterpret_cast<const uint4*>(kmer7)[tid + 64 * SCAN_WAVES * k];
     __syncthreads();
 
     const int lane = tid & 63, wv = tid >> 6;
@@ -226,7 +258,10 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const uint64_t o1 = __shfl_down(o, 1);
         int64_t L = (uint32_t)lane < nr ? (int64_t)(o1 - o) : 0;
         bool bad = false;
-        if (L < 0 || L >= (1ll << 26) || o + (uint64_t)L > total_rounded) { bad = (uint32_t)lane < nr; L = 0; }
+        // the vectors of a task are addressed relative to its first one with 32 bits: true for any valid offset array (8 reads
+        // below 2^26 bases each); offsets that jump further are corrupt
+        const uint64_t T0 = __shfl(o, 0) & ~15ull;
+        if (L < 0 || L >= (1ll << 26) || o + (uint64_t)L > total_rounded || o - T0 >= (1ull << 30)) { bad = (uint32_t)lane < nr; L = 0; }
         if (bad) atomicMax(&stat[S_BADREAD], ~(unsigned long long)(r0 + lane));        // corrupt offsets: report, never loop on them
         // every vector of a validated read lies inside [0, total_rounded): no bounds checks on the loads below
         uint32_t nv = L > 0 ? (uint32_t)(((o & 15ull) + (uint64_t)L + 15ull) >> 4) : 0u;
@@ -235,31 +270,48 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         for (int d = 1; d < TASK_READS; d <<= 1) { const uint32_t x = __shfl_up(incl, d); if (lane >= d) incl += x; }
         if (lane < TASK_READS) {
             const uint32_t excl = incl - nv;
-            const uint64_t A = (o & ~15ull) - 16ull * excl;
-            tb.rd[lane] = make_uint4((uint32_t)A, (uint32_t)(A >> 32), (uint32_t)(-(int32_t)(16u * excl + (uint32_t)(o & 15ull))), (uint32_t)L);
+            const uint32_t A = nv ? (uint32_t)((o & ~15ull) - T0) - 16u * excl : 0u;
+            tb.rd[lane] = make_uint4(A, (uint32_t)(-(int32_t)(16u * excl + (uint32_t)(o & 15ull))), (uint32_t)L, (uint32_t)((int32_t)L - (KMER - 1)));
             tb.pend[lane] = incl;
+            if (lane == TASK_READS - 1) { tb.base_lo = incl ? (uint32_t)T0 : 0u; tb.base_hi = incl ? (uint32_t)(T0 >> 32) : 0u; }
         }
+        // offset of the last vector: lanes behind the task's end re-read it (a valid address that costs no select)
+        uint32_t lastv = lane < TASK_READS && nv ? (uint32_t)((o & ~15ull) - T0) + 16u * (nv - 1u) : 0u;
+#pragma unroll
+        for (int d = 1; d < TASK_READS; d <<= 1) { const uint32_t x = __shfl_xor(lastv, d); lastv = x > lastv ? x : lastv; }
+        if (lane == 0) tb.last_off = lastv;
     };
-    auto vec_at = [&](const TaskTab& tb, uint32_t j, uint32_t slot) -> uint4 {
-        const uint2 a = *reinterpret_cast<const uint2*>(&tb.rd[j]);
-        const uint64_t g0 = (((uint64_t)a.y << 32) | a.x) + 16ull * slot;
-        return ld_stream16(bases + g0);
-    };
-    auto slot_vec = [&](const TaskTab& tb, uint32_t slot, uint32_t nslots) -> uint4 {
-        uint4 vv = make_uint4(0, 0, 0, 0);
-        if (nslots) {                                               // (an all-empty task may come with an empty buffer)
-            vv = *reinterpret_cast<const uint4*>(bases);           // idle lanes: valid letters (zeros would force the exact path)
-            if (slot < nslots) vv = vec_at(tb, find_read(tb, slot), slot);
-        }
-        return vv;
+    auto tab_base = [&](const TaskTab& tb) -> uint64_t {           // wave-uniform byte offset of the task's first vector
+        const uint32_t lo = __builtin_amdgcn_readfirstlane(tb.base_lo), hi = __builtin_amdgcn_readfirstlane(tb.base_hi);
+        return ((uint64_t)hi << 32) | lo;
     };
     // Staged item: one lane-vector with hits, {forward hit mask | reverse hit mask << 16, (p0 + 16) << 5 | ring slot}.
     // Items become queue entries 64 at a time once the polyT of their reads is known: per strand one cluster
     // {read, (first hit << 1) | strand, offset mask}; a cluster whose first hit lies left of polyT goes to queue A
     // (relaxed search applies), any other is split into single hits for the filter (queue B).  One packed reservation
     // (A count | B count << 32) per call.  force_a: polyT not known yet (staging overflow), everything to queue A.
+    // An item is staged in Z form and unclipped; to_plain gives {forward hits | reverse hits << 16} of the 6-mer starts whose
+    // six bases lie inside the read (the item's read length comes from the ring).
+    auto to_plain = [&](uint2 it) -> uint32_t {
+        const int32_t p0 = (int32_t)(it.y >> 5) - 16;
+        const int32_t L = s_ringL[wv][it.y & 31u];
+        const int32_t lo = max(-p0, 0), hv = min(max(L - (KMER - 1) - p0, 0), 16);
+        const uint32_t valid = __builtin_amdgcn_ubfe(0xFFFFFFFFu << lo, 0, hv);
+        return (z_low_nibbles(it.x) & valid) | ((z_low_nibbles(it.x >> 4) & valid) << 16);
+    };
     auto emit = [&](bool from_lds, uint2 mine, bool mine_on, uint32_t n_items, bool force_a) {
         struct Cl { QEnt f, r; bool af, ar, bf, br; };
+        if (from_lds) {
+            for (uint32_t h = (uint32_t)lane; h < n_items; h += 64u) {
+                const uint32_t x = to_plain(ent[h]);
+                ent[h].x = x;
+                nhits_stat += __popc(x);
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            mine.x = mine_on ? to_plain(mine) : 0u;
+            nhits_stat += __popc(mine.x);
+        }
         // Two items that are neighbouring vectors of one read and whose hits of a strand span at most 17 positions (one
         // adapter copy cut by the vector boundary) form ONE cluster: its union window still fits the 56 columns of
         // k_sw_clusters and one alignment serves both.  The item holding the cluster's first hit in strand order
@@ -346,8 +398,8 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         if ((uint32_t)lane < count) {
             const uint2 c = s_cand[wv][first + lane];
             const uint32_t info = s_candi[wv][first + lane];
-            const uint32_t m = gather_even(c.x) | (gather_even(c.y) << 16);
             const int32_t p0 = (int32_t)(info >> 6) - 16; const uint32_t ring = (info >> 1) & 31u, typ = info & 1u;
+            const uint32_t m = gather_even(c.x >> typ) | (gather_even(c.y >> typ) << 16);
             const int32_t L = s_ringL[wv][ring];
             uint32_t q = 0;
 #pragma unroll
@@ -376,91 +428,127 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         }
     };
 
+    // The vectors of a step reach the wave through LDS: global_load_lds_dwordx4 writes lane l's 16 bytes to buffer + 16 l
+    // without passing through registers, so the loads of the next TWO steps stay in flight while a step is worked on (a load
+    // into registers would have to be copied when the steps rotate, and a copy waits for its load; one step of work does not
+    // cover the memory latency at four waves per SIMD).  The compiler does not see these loads: the waits are placed here.
+    // Loads complete in order, so "at most one younger load outstanding" means the older one has landed.
+    const uint32_t buf_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&s_buf[wv][0][0];
+    auto dma_issue = [&](uint32_t g, const uint8_t* gptr) {            // step g's vector of this lane -> buffer g & 1
+        const uint32_t base = __builtin_amdgcn_readfirstlane(buf_lds + (g & 1u) * 1024u);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"                       // (the buffer's previous contents have been read)
+                     "s_mov_b32 m0, %0\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off nt" :: "s"(base), "v"(gptr) : "memory", "m0");
+    };
+    auto dma_wait = [&](bool younger_in_flight) {
+        if (younger_in_flight) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    const uint32_t kmer_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&s_kmer[0];
+
     int cur = 0;
-    uint32_t tseq = 0, since_flush = 0;     // ring slot of read j of the current task: (tseq & 3) * 8 + j
+    uint32_t tseq = 0;                      // ring slot of read j of the current task: (tseq & 1) * TASK_READS + j
     uint32_t task = grab();
     if (task != 0xFFFFFFFFu) load_tab(task, s_tab[wv][cur]);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    bool have_v = false;
+    uint32_t g = 0;                         // steps this wave has done
+    bool have_v = false, have_n = false;    // the loads of step g / g + 1 have been issued
+    const uint32_t lane_z = lane < 63 ? 0xFFFFFFFFu : 0u;      // lane 63 only feeds lane 62's look-ahead: it stages no hits
+    const uint32_t pt_thr = lane < 63 ? 12u : 99u;             // ... and parks no polyT candidates
     while (task != 0xFFFFFFFFu) {
         const uint32_t next_task = grab();
         if (next_task != 0xFFFFFFFFu) load_tab(next_task, s_tab[wv][cur ^ 1]);
         __builtin_amdgcn_wave_barrier();
         const TaskTab& tb = s_tab[wv][cur];
+        const TaskTab& nt = s_tab[wv][cur ^ 1];
         const uint64_t r0 = (uint64_t)task * TASK_READS;
         const uint32_t nr = (uint32_t)(n - r0 < TASK_READS ? n - r0 : TASK_READS);
-        uint32_t P[TASK_READS];                 // vectors of reads 0..k inclusive, wave-uniform (scalar registers)
-#pragma unroll
-        for (int k = 0; k < TASK_READS; ++k) P[k] = __builtin_amdgcn_readfirstlane(tb.pend[k]);
-        const uint32_t nslots = P[TASK_READS - 1];
+        const uint32_t nslots = __builtin_amdgcn_readfirstlane(tb.pend[TASK_READS - 1]);
         const uint32_t niter = (nslots + 62u) / 63u;
-        // read of a slot = number of boundaries at or below it (compare + add-with-carry per boundary, P[] in scalar registers)
-        auto map_j = [&](uint32_t slot) -> uint32_t {
-            uint32_t jv = 0;
-#pragma unroll
-            for (int k = 0; k < TASK_READS - 1; ++k) jv += P[k] <= slot ? 1u : 0u;
+        const uint32_t nnslots = next_task != 0xFFFFFFFFu ? __builtin_amdgcn_readfirstlane(nt.pend[TASK_READS - 1]) : 0u;
+        const uint32_t nniter = (nnslots + 62u) / 63u;
+        // Read of a slot = number of boundaries (pend[k], k < TASK_READS - 1) at or below it.  The lanes of a step hold 64
+        // consecutive slots starting at `lo`, and steps are mapped in order: with kb = number of boundaries at or below lo only
+        // the boundaries inside the 64 slots are compared (one per step on average).  Leaves kb = boundaries at or below lo + 63.
+        uint32_t kb = 0;
+        const uint32_t pend_lane = tb.pend[lane & (TASK_READS - 1)];          // boundary k in lane k: read back with v_readlane
+        auto map_step = [&](uint32_t lo, uint32_t slot) -> uint32_t {
+            uint32_t jv = kb;
+            while (kb < TASK_READS - 1) {
+                const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)pend_lane, (int)kb);
+                if (b > lo + 63u) break;
+                jv += b <= slot ? 1u : 0u;
+                kb = __builtin_amdgcn_readfirstlane(kb + 1u);
+            }
             return jv;
         };
-        const uint32_t ring0 = (tseq & 3u) * TASK_READS;
+        // address of this lane's vector in step s of this task (jj = read of the lane's slot) / of the next task; a lane
+        // behind the task's end gets the task's last vector (a valid address that costs no select)
+        const uint32_t last_off = __builtin_amdgcn_readfirstlane(tb.last_off), nlast_off = __builtin_amdgcn_readfirstlane(nt.last_off);
+        const uint64_t tbase = tab_base(tb);
+        const uint64_t nbase = next_task != 0xFFFFFFFFu ? tab_base(nt) : 0ull;
+        auto addr_cur = [&](uint32_t s, uint32_t jj) -> const uint8_t* {
+            const uint32_t sl = s * 63u + (uint32_t)lane;
+            return bases + tbase + min(tb.rd[jj].x + 16u * sl, last_off);
+        };
+        auto addr_next = [&](uint32_t s) -> const uint8_t* {
+            const uint32_t sl = s * 63u + (uint32_t)lane;
+            return bases + nbase + min(nt.rd[find_read(nt, sl)].x + 16u * sl, nlast_off);
+        };
+        const uint32_t ring0 = (tseq & 1u) * TASK_READS;
         if (lane < 2 * TASK_READS) s_ptmin[wv][ring0 + (lane >> 1)][lane & 1] = 0xFFFFFFFFu;
-        if (lane < TASK_READS) { s_ringr[wv][ring0 + lane] = (uint32_t)(r0 + lane); s_ringL[wv][ring0 + lane] = (int32_t)tb.rd[lane].w; }
+        if (lane < TASK_READS) { s_ringr[wv][ring0 + lane] = (uint32_t)(r0 + lane); s_ringL[wv][ring0 + lane] = (int32_t)tb.rd[lane].z; }
         __builtin_amdgcn_wave_barrier();
-        if (!have_v) v = slot_vec(tb, (uint32_t)lane, nslots);
-        have_v = false;
-        uint32_t j = map_j((uint32_t)lane);
+        uint32_t j = map_step(0u, (uint32_t)lane), jn = map_step(63u, 63u + (uint32_t)lane);
+        if (niter) {                            // (start of the batch, or behind a task without vectors: nothing is in flight)
+            if (!have_v) { dma_issue(g, addr_cur(0u, j)); have_v = true; }
+            if (!have_n) {
+                if (niter > 1u) { dma_issue(g + 1u, addr_cur(1u, jn)); have_n = true; }
+                else if (nniter) { dma_issue(g + 1u, addr_next(0u)); have_n = true; }
+            }
+        }
 
-        for (uint32_t it = 0; it < niter; ++it) {
+        for (uint32_t it = 0; it < niter; ++it, ++g) {
             const uint32_t slot_lo = it * 63u;
             const uint32_t slot = slot_lo + (uint32_t)lane;
-            // next step's vector first (or the next task's first vectors).  Exactly one load, issued by every lane on every
-            // path (idle lanes re-read the buffer's first vector), so that it stays in flight across this step's work.
-            uint32_t jn = 0, pj = 0, pslot = slot + 63u;
-            const TaskTab* ptab = &tb;
-            bool pvalid;
-            if (it + 1 < niter) {
-                jn = pj = map_j(pslot);
-                pvalid = pslot < nslots;
-            } else {
-                ptab = &s_tab[wv][cur ^ 1];
-                pslot = (uint32_t)lane;
-                pvalid = next_task != 0xFFFFFFFFu && pslot < ptab->pend[TASK_READS - 1];
-                pj = pvalid ? find_read(*ptab, pslot) : 0u;
-                have_v = next_task != 0xFFFFFFFFu;
-            }
-            const uint2 pa = *reinterpret_cast<const uint2*>(&ptab->rd[pj]);
-            const uint64_t pg = pvalid ? (((uint64_t)pa.y << 32) | pa.x) + 16ull * pslot : 0ull;
-            const uint4 vn = ld_stream16(bases + pg);      // streamed once: keep it out of the caches the gathers of the later kernels live in
-            const bool act = slot < nslots;
-            const uint4 rd = tb.rd[j];
-            const int32_t L = act ? (int32_t)rd.w : 0;
-            const int32_t p0 = (int32_t)(slot << 4) + (int32_t)rd.z;
-            const uint64_t r = r0 + j;
-            const bool same_next = lane < 63 && p0 + 16 < L;      // the next lane holds the next 16 bases of the same read
-            const bool worker = act && lane < 63;                  // lane 63 only feeds lane 62's look-ahead
+            dma_wait(have_n);
+            const uint4 v = *reinterpret_cast<const uint4*>(&s_buf[wv][g & 1u][16 * lane]);
+            // where the step after next comes from
+            uint32_t jnn = 0;
+            const uint8_t* pf = bases;
+            bool have_nn = false;
+            if (it + 2u < niter) { jnn = map_step(slot_lo + 126u, slot + 126u); pf = addr_cur(it + 2u, jnn); have_nn = true; }
+            else if (it + 2u - niter < nniter) { pf = addr_next(it + 2u - niter); have_nn = true; }
 
-            // 2-bit codes.  (byte >> 1) & 7 is a perfect hash of "ACTG" (0..3); v_perm maps it back to the expected letter,
-            // v_dot4 packs four codes into a byte.  A byte that is not its expected letter (N, a bad base, the zero padding
-            // behind the last read) sends the whole wave through the exact per-byte path.
+            // 2-bit codes.  byte & 6 is a perfect hash of "ACTG" (twice the code: 0, 2, 4, 6); v_perm maps it back to the expected
+            // letter, v_dot4 packs four of them into twice a byte of codes.  A byte that is not its expected letter (N, a bad
+            // base, the zero padding behind the last read) sends the whole wave through the exact per-byte path.
             const uint32_t words[4] = { v.x, v.y, v.z, v.w };
             uint32_t sel[4], diff = 0;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                sel[d] = (words[d] >> 1) & 0x07070707u;
-                diff |= __builtin_amdgcn_perm(0u, 0x47544341u, sel[d]) ^ words[d];
+                sel[d] = words[d] & 0x06060606u;
+                diff |= __builtin_amdgcn_perm(0x00470054u, 0x00430041u, sel[d]) ^ words[d];
             }
-            const int32_t lo = max(-p0, 0);                                     // read bases of this vector: [lo, hi)
-            const int32_t hi = min(max(L - p0, 1), 16);           // (inactive lanes: anything, never used)
-            uint32_t rm_s = (0xFFFFFFFFu >> (32 - 2 * hi)) & (0xFFFFFFFFu << (2 * lo)) & 0x55555555u;
-            const int32_t hv = min(max(L - (KMER - 1) - p0, 0), 16);
-            uint32_t valid = ((1u << hv) - 1u) & (0xFFFFFFFFu << lo);          // 6-mer starts whose 6 bases lie in the read
+            asm volatile("" : "+v"(diff));                          // (one compare of the OR, not four compares)
+            if (have_nn) dma_issue(g, pf);                          // the buffer just read takes the step after next
+            // Position of the vector in its read.  Nothing is clipped to the read here: a 6-mer start is checked against the
+            // read when the item becomes a cluster (to_plain); a polyT window start is valid only if its 16 bases lie inside the
+            // read (eval_cands), so flags of bytes outside it never count, and the first 'TTT' behind a valid start lies inside
+            // its window (>= 12 T among 16 leave a run of three).  A lane behind the task's last vector sits at p0 >= L of the
+            // last read: it has neither.
+            const int32_t p0 = (int32_t)(slot << 4) + (int32_t)tb.rd[j].y;
+            uint32_t fm = 0x55555555u;                              // positions whose T / A flag counts
+            uint32_t zm = lane_z;                                   // 6-mer starts that may hit, Z form
             uint32_t codes, bad = 0;
             const bool exact = __ballot(diff != 0) != 0;
             if (!exact) {
                 uint32_t c[4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) c[d] = __builtin_amdgcn_udot4(sel[d], 0x40100401u, 0u, false);
-                codes = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+                for (int d = 0; d < 4; ++d) c[d] = __builtin_amdgcn_udot4(sel[d], 0x40100401u, 0u, false);      // 2 * (four codes)
+                codes = (c[0] >> 1) | (c[1] << 7) | (c[2] << 15) | (c[3] << 23);
             } else {
+                const int32_t L = (int32_t)tb.rd[j].z;
                 uint32_t nN = 0, nbad = 0;
                 codes = 0;
 #pragma unroll
@@ -472,79 +560,90 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                     nbad |= ((isN || ok) ? 0u : 1u) << k;
                     codes |= ((b >> 1) & 3u) << (2 * k);
                 }
-                const uint32_t rm16 = (0xFFFFu >> (16 - hi)) & (0xFFFFu << lo);
-                bad = nbad & rm16;
+                const int32_t lo_t = max(-p0, 0);                                // read bases of this vector: [lo_t, hi)
+                const int32_t hi = min(max(L - p0, 1), 16);
+                const bool same_next = lane < 63 && p0 + 16 < L;                 // the next lane holds the next 16 bases of the same read
+                const uint32_t rm16 = (0xFFFFu >> (16 - hi)) & (0xFFFFu << lo_t);
+                bad = slot < nslots ? nbad & rm16 : 0u;                          // (a lane behind the task's end owns no base)
                 nN = (nN | ~rm16) & 0xFFFFu;                                     // out-of-read behaves like N
-                rm_s &= ~spread16(nN | nbad);                                    // neither T nor A
+                fm &= ~spread16(nN | nbad);                                      // neither T nor A
                 uint32_t N1 = wave_shl1(nN);
                 if (!same_next) N1 = 0xFFFFu;
                 const uint32_t N32 = nN | (N1 << 16);
                 uint32_t nvm = N32 | (N32 >> 1);
                 nvm |= nvm >> 2;
                 nvm |= N32 >> 4; nvm |= N32 >> 5;
-                valid &= ~nvm;                                                   // 6-mers touching an N never match
+                zm &= z_from_mask16(~nvm);                                       // 6-mers touching an N never match
             }
             // T = code 2, A = code 0: flags on the even bits
-            const uint32_t T_s = (codes >> 1) & ~codes & rm_s;
-            const uint32_t A_s = ~((codes >> 1) | codes) & rm_s;
+            const uint32_t T_s = (codes >> 1) & ~codes & fm;
+            const uint32_t A_s = ~((codes >> 1) | codes) & fm;
 
             // look-ahead from the next lane (one DPP move each)
-            uint32_t TA1 = wave_shl1(T_s | (A_s << 1));
+            const uint32_t TA = T_s | (A_s << 1);
+            const uint32_t TA1 = wave_shl1(TA);
             const uint32_t codes1 = wave_shl1(codes);
-            if (!same_next) TA1 = 0;
 
-            // R1 6-mer hits of both strands: 8 probes of the 7-mer table, two positions each
-            uint32_t accA = 0, accB = 0;
+            // R1 6-mer hits of both strands: 8 probes of the 7-mer table, two positions each.  (Issued by hand: the compiler
+            // masks every sub-dword LDS load although ds_read_u8 zero-extends.)
+            uint32_t e[8];
+            {
+                uint32_t ad[8];
+                const uint32_t hi = __builtin_amdgcn_alignbit(codes1, codes, 20);      // codes of positions 10 .. 25
 #pragma unroll
-            for (int k = 0; k < 16; k += 2) {
-                const uint32_t idx = k <= 8 ? __builtin_amdgcn_ubfe(codes, 2 * k, 14)
-                                            : (__builtin_amdgcn_alignbit(codes1, codes, 2 * k) & 0x3FFFu);
-                const uint32_t e = s_kmer[idx];
-                if (k & 2) accB |= e << k; else accA |= e << k;
+                for (int k = 0; k < 16; k += 2)
+                    ad[k >> 1] = kmer_lds + (k <= 8 ? __builtin_amdgcn_ubfe(codes, 2 * k, 14) : __builtin_amdgcn_ubfe(hi, 2 * k - 20, 14));
+                asm volatile("ds_read_u8 %0, %8\n\tds_read_u8 %1, %9\n\tds_read_u8 %2, %10\n\tds_read_u8 %3, %11\n\t"
+                             "ds_read_u8 %4, %12\n\tds_read_u8 %5, %13\n\tds_read_u8 %6, %14\n\tds_read_u8 %7, %15"
+                             : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(e[4]), "=&v"(e[5]), "=&v"(e[6]), "=&v"(e[7])
+                             : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]));
             }
-            // accA: probes 0,4,8,12 -> forward flags on bits = 0,1 (mod 4), reverse flags two bits above; accB: probes 2,6,10,14
-            uint32_t hitF = ((accA & 0x3333u) | (accB & 0xCCCCu)) & valid;
-            uint32_t hitR = (((accA & 0xCCCCu) | (accB & 0x33330u)) >> 2) & valid;
-            if (!worker) { hitF = 0; hitR = 0; }
 
             // polyT windows.  A 16-window with >= 12 T needs >= 12 T among the 31 bases a lane can see, which few lanes
             // have: those lanes park their flags; evaluation happens 64 lanes at a time (eval_cands).
             {
-                const bool cT = worker && __popc(T_s) + __popc(TA1 & 0x15555555u) >= 12;
-                const bool cA = worker && __popc(A_s) + __popc(TA1 & 0x2AAAAAAAu) >= 12;
-                const unsigned long long bT = __ballot(cT), bA = __ballot(cA);
-                const uint32_t nT = (uint32_t)__popcll(bT), nc = nT + (uint32_t)__popcll(bA);
-                if (nc) {
-                    const unsigned long long below = (1ull << lane) - 1ull;
+                // (lane 63 never parks: its vector is lane 0's of the next step.  A lane behind the task's end may: it sits at
+                // p0 >= L, where eval_cands finds no valid window start.)
+                const bool cT = __popc(T_s) + __popc(TA1 & 0x15555555u) >= pt_thr;
+                const bool cA = __popc(A_s) + __popc(TA1 & 0x2AAAAAAAu) >= pt_thr;
+                const unsigned long long bc = __ballot(cT || cA);
+                if (bc) {
+                    // one entry per lane: its flags of both kinds, the kind to evaluate in bit 0 of the info word
                     const uint32_t info = ((uint32_t)(p0 + 16) << 6) | ((ring0 + j) << 1);
-                    if (cT) { const uint32_t at = ncand + (uint32_t)__popcll(bT & below);
-                              s_cand[wv][at] = make_uint2(T_s, TA1); s_candi[wv][at] = info; }
-                    if (cA) { const uint32_t at = ncand + nT + (uint32_t)__popcll(bA & below);
-                              s_cand[wv][at] = make_uint2(A_s, TA1 >> 1); s_candi[wv][at] = info | 1u; }
-                    ncand += nc;
-                }
-            }
-            if (exact && __ballot(bad != 0 && worker)) {
-                if (bad != 0 && worker) atomicMax(&stat[S_BADREAD], ~(unsigned long long)r);
-            }
-            // lanes with hits stage {masks, position, ring slot}; they become queue entries at the next flush
-            {
-                const uint32_t hw = hitF | (hitR << 16);
-                nhits_stat += __popc(hw);
-                const unsigned long long bal = __ballot(hw != 0);
-                if (bal) {
-                    const uint32_t cnt = (uint32_t)__popcll(bal);
-                    const uint2 item = make_uint2(hw, ((uint32_t)(p0 + 16) << 5) | (ring0 + j));
-                    if (nent + cnt <= WENT) {
-                        if (hw) ent[nent + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = item;
-                        nent += cnt;
-                    } else {
-                        emit(false, item, hw != 0, 0u, true);      // staging full (pathological reads): straight to queue A
+                    if (cT || cA) { const uint32_t at = ncand + lanes_below(bc);
+                                    s_cand[wv][at] = make_uint2(TA, TA1); s_candi[wv][at] = info | (cT ? 0u : 1u); }
+                    ncand += (uint32_t)__popcll(bc);
+                    const unsigned long long bb = __ballot(cT && cA);              // rich in both (AT repeats): a second entry
+                    if (bb) {
+                        if (cT && cA) { const uint32_t at = ncand + lanes_below(bb);
+                                        s_cand[wv][at] = make_uint2(TA, TA1); s_candi[wv][at] = info | 1u; }
+                        ncand += (uint32_t)__popcll(bb);
                     }
                 }
             }
-            v = vn;
-            j = jn;
+            if (exact && __ballot(bad != 0)) {
+                if (bad != 0) atomicMax(&stat[S_BADREAD], ~(unsigned long long)(r0 + j));
+            }
+            // Lanes with hits stage {Z, position, ring slot}; they become queue entries at the next flush.  A table entry holds
+            // the forward hits of its two positions in bits 0-1 and the reverse hits in bits 4-5: two probes make a byte of Z.
+            {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]));
+                const uint32_t b0 = e[0] | (e[1] << 2), b1 = e[2] | (e[3] << 2), b2 = e[4] | (e[5] << 2), b3 = e[6] | (e[7] << 2);
+                const uint32_t z = ((b0 | (b1 << 8)) | ((b2 | (b3 << 8)) << 16)) & zm;
+                const unsigned long long bal = __ballot(z != 0);
+                if (bal) {
+                    const uint32_t cnt = (uint32_t)__popcll(bal);
+                    const uint2 item = make_uint2(z, ((uint32_t)(p0 + 16) << 5) | (ring0 + j));
+                    if (nent + cnt <= WENT) {
+                        if (z) ent[nent + lanes_below(bal)] = item;
+                        nent += cnt;
+                    } else {
+                        emit(false, item, z != 0, 0u, true);       // staging full (pathological reads): straight to queue A
+                    }
+                }
+            }
+            j = jn; jn = jnn;
+            have_v = have_n; have_n = have_nn;
             __builtin_amdgcn_wave_barrier();
             while (ncand >= 64u) { ncand -= 64u; eval_cands(ncand, 64u); }
         }
@@ -562,11 +661,12 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             }
         }
         __builtin_amdgcn_wave_barrier();
-        ++tseq; ++since_flush;
-        if (nent >= WFLUSH || since_flush >= 3) { flush(); since_flush = 0; }      // staged clusters never outlive the 4-task ring
+        ++tseq;
+        flush();                                // the task's polyT is known: its staged items become clusters
         task = next_task;
         cur ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (no load of a step is left in flight: every issued step was done)
     flush();
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) nhits_stat += __shfl_xor(nhits_stat, d);
@@ -1216,7 +1316,7 @@ void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
 
 // host-side table -------------------------------------------------------------
 // 7-mer probe table of k_scan_reads: index = 2-bit codes of 7 consecutive bases (base p in bits 0-1), entry bit 0 / 1:
-// bases p..p+5 / p+1..p+6 spell a 6-mer of R1, bit 2 / 3: the same for the reverse complement of a 6-mer of R1
+// bases p..p+5 / p+1..p+6 spell a 6-mer of R1, bit 4 / 5: the same for the reverse complement of a 6-mer of R1
 // (KmerIndexer over [R1] with k = 6, kmer_indexer.py:20-27, applied to the read and to its reverse complement).
 void build_kmer7_table(uint8_t* k7 /* [16384] */)
 {
@@ -1234,7 +1334,7 @@ void build_kmer7_table(uint8_t* k7 /* [16384] */)
     }
     for (uint32_t idx = 0; idx < 16384u; ++idx) {
         const uint32_t e0 = six[idx & 4095u], e1 = six[idx >> 2];
-        k7[idx] = (uint8_t)((e0 & 1u) | ((e1 & 1u) << 1) | (((e0 >> 1) & 1u) << 2) | (((e1 >> 1) & 1u) << 3));
+        k7[idx] = (uint8_t)((e0 & 1u) | ((e1 & 1u) << 1) | (((e0 >> 1) & 1u) << 4) | (((e1 >> 1) & 1u) << 5));
     }
 }
 
@@ -1281,10 +1381,10 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     {
         ScopedKernelTimer tm(ctx, "k_scan_reads");
         const uint32_t ntasks = (n + TASK_READS - 1) / TASK_READS;
-        uint32_t grid = (ntasks + 3) / 4;
-        if (grid > 256u * 4u) grid = 256u * 4u;                                  // persistent: 4 blocks per CU (LDS)
+        uint32_t grid = (ntasks + SCAN_WAVES - 1) / SCAN_WAVES;
+        if (grid > 256u * SCAN_BLOCKS_PER_CU) grid = 256u * SCAN_BLOCKS_PER_CU;   // persistent: as many blocks per CU as the LDS takes
         grid = (grid + TASK_SHARDS - 1) / TASK_SHARDS * TASK_SHARDS;            // every shard has a block
-        hipLaunchKernelGGL(k_scan_reads, dim3(grid), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
+        hipLaunchKernelGGL(k_scan_reads, dim3(grid), dim3(64 * SCAN_WAVES), 0, st, d_bases, total_rounded, d_off, n,
                            static_cast<const uint8_t*>(ctx->x_lut.p), static_cast<int32_t*>(ctx->x_polyt.p),
                            qa, qb, qcap, counters, keys);
     }
