@@ -245,7 +245,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     auto grab = [&]() -> uint32_t {
         uint32_t k = 0;
         if (lane == 0) k = atomicAdd(task_ctr, 1u);
-        k = __shfl(k, 0);
+        k = __builtin_amdgcn_readfirstlane(k);          // (wave-uniform for the compiler too: the task loop branches on scalars)
         const unsigned long long t = (unsigned long long)k * TASK_SHARDS + shard;
         return t < ntasks ? (uint32_t)t : 0xFFFFFFFFu;
     };
@@ -299,19 +299,8 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const uint32_t valid = __builtin_amdgcn_ubfe(0xFFFFFFFFu << lo, 0, hv);
         return (z_low_nibbles(it.x) & valid) | ((z_low_nibbles(it.x >> 4) & valid) << 16);
     };
-    auto emit = [&](bool from_lds, uint2 mine, bool mine_on, uint32_t n_items, bool force_a) {
-        struct Cl { QEnt f, r; bool af, ar, bf, br; };
-        if (from_lds) {
-            for (uint32_t h = (uint32_t)lane; h < n_items; h += 64u) {
-                const uint32_t x = to_plain(ent[h]);
-                ent[h].x = x;
-                nhits_stat += __popc(x);
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            mine.x = mine_on ? to_plain(mine) : 0u;
-            nhits_stat += __popc(mine.x);
-        }
+    auto emit = [&](bool from_lds, uint2 mine, bool mine_on, uint32_t n_items, bool force_a) __attribute__((always_inline)) {
+        constexpr int MAXC = (int)(WENT / 64u);
         // Two items that are neighbouring vectors of one read and whose hits of a strand span at most 17 positions (one
         // adapter copy cut by the vector boundary) form ONE cluster: its union window still fits the 56 columns of
         // k_sw_clusters and one alignment serves both.  The item holding the cluster's first hit in strand order
@@ -322,71 +311,94 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             const uint32_t M = ha | (hb << 16);
             return ha != 0 && hb != 0 && b.y - a.y == (16u << 5) && (31 - __builtin_clz(M)) - __builtin_ctz(M) <= 17;
         };
-        auto clusters = [&](uint32_t c) -> Cl {
-            uint2 it = mine; bool on = mine_on;
-            if (from_lds) { const uint32_t h = c * 64u + (uint32_t)lane; on = h < n_items; it = on ? ent[h] : make_uint2(0u, 0u); }
-            uint32_t hF = on ? it.x & 0xFFFFu : 0u, hR = on ? it.x >> 16 : 0u;
-            const uint32_t ring = it.y & 31u;
-            const int32_t p0 = (int32_t)(it.y >> 5) - 16;
-            int32_t p0r = p0;
-            if (from_lds) {
-                // neighbours inside the 64-item chunk by DPP (a pair cut by the chunk boundary is simply not merged)
-                const uint2 nx = make_uint2(wave_shl1(it.x), wave_shl1(it.y));
-                const uint32_t cF = span_ok(it, nx, 0) ? 1u : 0u, cR = span_ok(it, nx, 16) ? 1u : 0u;     // cond(h, h+1)
-                const uint32_t cFp = wave_shr1(cF), cFp2 = wave_shr1(cFp), cRp = wave_shr1(cR), cRn = wave_shl1(cR);
-                const uint32_t xp = wave_shr1(it.x);
-                // forward strand: the earlier item leads
-                if (cFp && !cFp2) hF = 0;                                                // absorbed by h-1
-                else if (cF && !cFp) hF |= (nx.x & 0xFFFFu) << 16;                      // absorbs h+1
-                // reverse strand: the later item leads
-                if (cR && !cRn) hR = 0;                                                  // absorbed by h+1
-                else if (cRp && !cR) { hR = (xp >> 16) | (hR << 16); p0r = p0 - 16; }   // absorbs h-1
-            }
-            const uint32_t r = s_ringr[wv][ring];
-            const int32_t L = s_ringL[wv][ring];
-            const int32_t ptF = s_pt[wv][ring][0], ptR = s_pt[wv][ring][1];
-            Cl cl;
-            const int k0 = hF ? __builtin_ctz(hF) : 0;
-            const int32_t posF = p0 + k0;
-            cl.f = make_uint4(r, (uint32_t)posF << 1, hF >> k0, 0u);
-            cl.af = hF != 0 && (force_a || (ptF >= 0 && posF + KMER <= ptF + 1));
-            cl.bf = hF != 0 && !cl.af;
-            const int k1 = hR ? 31 - __builtin_clz(hR) : 0;
-            const int32_t posR = L - KMER - (p0r + k1);
-            cl.r = make_uint4(r, ((uint32_t)posR << 1) | 1u, __brev(hR) >> (31 - k1), 0u);
-            cl.ar = hR != 0 && (force_a || (ptR >= 0 && posR + KMER <= ptR + 1));
-            cl.br = hR != 0 && !cl.ar;
-            return cl;
-        };
+        // Pass 1, 64 items at a time: the lane's (up to) two clusters, kept in registers across the reservation:
+        // {read, forward (position << 1, offset mask), reverse (position << 1 | 1, offset mask), af | ar << 1 | bf << 2 | br << 3}
+        uint32_t c_r[MAXC], c_fy[MAXC], c_fz[MAXC], c_ry[MAXC], c_rz[MAXC], c_fl[MAXC];
         const uint32_t nchunk = from_lds ? (n_items + 63u) / 64u : 1u;
         uint32_t acc = 0;
-        for (uint32_t c = 0; c < nchunk; ++c) {
-            const Cl cl = clusters(c);
-            acc += (cl.af ? 1u : 0u) + (cl.ar ? 1u : 0u) + (((cl.bf ? 1u : 0u) + (cl.br ? 1u : 0u)) << 16);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            c_r[c] = c_fy[c] = c_fz[c] = c_ry[c] = c_rz[c] = c_fl[c] = 0u;
+            if ((uint32_t)c < nchunk) {
+                uint2 it = mine; bool on = mine_on;
+                if (from_lds) { const uint32_t h = (uint32_t)c * 64u + (uint32_t)lane; on = h < n_items; it = on ? ent[h] : make_uint2(0u, 0u); }
+                it.x = on ? to_plain(it) : 0u;
+                nhits_stat += __popc(it.x);
+                uint32_t hF = it.x & 0xFFFFu, hR = it.x >> 16;
+                const uint32_t ring = it.y & 31u;
+                const int32_t p0 = (int32_t)(it.y >> 5) - 16;
+                int32_t p0r = p0;
+                if (from_lds) {
+                    // neighbours inside the 64-item chunk by DPP (a pair cut by the chunk boundary is simply not merged)
+                    const uint2 nx = make_uint2(wave_shl1(it.x), wave_shl1(it.y));
+                    const uint32_t cF = span_ok(it, nx, 0) ? 1u : 0u, cR = span_ok(it, nx, 16) ? 1u : 0u;     // cond(h, h+1)
+                    const uint32_t cFp = wave_shr1(cF), cFp2 = wave_shr1(cFp), cRp = wave_shr1(cR), cRn = wave_shl1(cR);
+                    const uint32_t xp = wave_shr1(it.x);
+                    // forward strand: the earlier item leads
+                    if (cFp && !cFp2) hF = 0;                                                // absorbed by h-1
+                    else if (cF && !cFp) hF |= (nx.x & 0xFFFFu) << 16;                      // absorbs h+1
+                    // reverse strand: the later item leads
+                    if (cR && !cRn) hR = 0;                                                  // absorbed by h+1
+                    else if (cRp && !cR) { hR = (xp >> 16) | (hR << 16); p0r = p0 - 16; }   // absorbs h-1
+                }
+                const int32_t L = s_ringL[wv][ring];
+                const int32_t ptF = s_pt[wv][ring][0], ptR = s_pt[wv][ring][1];
+                const int k0 = hF ? __builtin_ctz(hF) : 0;
+                const int32_t posF = p0 + k0;
+                const bool af = hF != 0 && (force_a || (ptF >= 0 && posF + KMER <= ptF + 1));
+                const bool bf = hF != 0 && !af;
+                const int k1 = hR ? 31 - __builtin_clz(hR) : 0;
+                const int32_t posR = L - KMER - (p0r + k1);
+                const bool ar = hR != 0 && (force_a || (ptR >= 0 && posR + KMER <= ptR + 1));
+                const bool br = hR != 0 && !ar;
+                c_r[c] = s_ringr[wv][ring];
+                c_fy[c] = (uint32_t)posF << 1; c_fz[c] = hF >> k0;
+                c_ry[c] = ((uint32_t)posR << 1) | 1u; c_rz[c] = __brev(hR) >> (31 - k1);
+                c_fl[c] = (af ? 1u : 0u) | (ar ? 2u : 0u) | (bf ? 4u : 0u) | (br ? 8u : 0u);
+                acc += (af ? 1u : 0u) + (ar ? 1u : 0u) + (((bf ? 1u : 0u) + (br ? 1u : 0u)) << 16);
+            }
         }
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(acc), 63);
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(nab, (unsigned long long)(tot & 0xFFFFu) | ((unsigned long long)(tot >> 16) << 32));
-        base = __shfl(base, 0);
-        unsigned long long gA = base & 0xFFFFFFFFull, gB = base >> 32;
-        for (uint32_t c = 0; c < nchunk; ++c) {
-            const Cl cl = clusters(c);
-            const uint32_t mine_cnt = (cl.af ? 1u : 0u) + (cl.ar ? 1u : 0u) + (((cl.bf ? 1u : 0u) + (cl.br ? 1u : 0u)) << 16);
-            const uint32_t incl = wave_incl_scan(mine_cnt);
-            const uint32_t excl = incl - mine_cnt;
-            unsigned long long ga = gA + (excl & 0xFFFFu), gb = gB + (excl >> 16);
-            if (cl.af) { if (ga < qcap) qa[ga] = cl.f; ++ga; }
-            if (cl.ar) { if (ga < qcap) qa[ga] = cl.r; }
-            if (cl.bf) { if (gb < qcap) qb[gb] = cl.f; ++gb; }
-            if (cl.br) { if (gb < qcap) qb[gb] = cl.r; }
-            const uint32_t ctot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            gA += ctot & 0xFFFFu; gB += ctot >> 16;
+        unsigned long long gA = __builtin_amdgcn_readfirstlane((uint32_t)base), gB = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        // Pass 2: positions inside the reservation, entries written
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if ((uint32_t)c < nchunk) {
+                const uint32_t fl = c_fl[c];
+                const uint32_t mine_cnt = (fl & 1u) + ((fl >> 1) & 1u) + ((((fl >> 2) & 1u) + ((fl >> 3) & 1u)) << 16);
+                const uint32_t incl = wave_incl_scan(mine_cnt);
+                const uint32_t excl = incl - mine_cnt;
+                unsigned long long ga = gA + (excl & 0xFFFFu), gb = gB + (excl >> 16);
+                const QEnt ef = make_uint4(c_r[c], c_fy[c], c_fz[c], 0u), er = make_uint4(c_r[c], c_ry[c], c_rz[c], 0u);
+                if (fl & 1u) { if (ga < qcap) qa[ga] = ef; ++ga; }
+                if (fl & 2u) { if (ga < qcap) qa[ga] = er; }
+                if (fl & 4u) { if (gb < qcap) qb[gb] = ef; ++gb; }
+                if (fl & 8u) { if (gb < qcap) qb[gb] = er; }
+                const uint32_t ctot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                gA += ctot & 0xFFFFu; gB += ctot >> 16;
+            }
         }
     };
-    auto flush = [&]() {
-        if (nent == 0) return;
-        emit(true, make_uint2(0u, 0u), false, nent, false);
-        nent = 0;
+    // Only whole groups of 64 staged items are turned into clusters (every lane busy); the rest waits for the next task's
+    // items - but never longer: the ring keeps a read's polyT for one more task only.
+    uint32_t carried = 0;                   // staged items that belong to the previous task
+    auto flush = [&](bool all) {
+        uint32_t nf = all ? nent : (nent & ~63u);
+        if (nf < carried) nf = nent;
+        if (nf) {
+            emit(true, make_uint2(0u, 0u), false, nf, false);
+            const uint32_t rem = nent - nf;                       // < 64 (or 0)
+            if (rem) {
+                const uint2 t = (uint32_t)lane < rem ? ent[nf + lane] : make_uint2(0u, 0u);
+                __builtin_amdgcn_wave_barrier();
+                if ((uint32_t)lane < rem) ent[lane] = t;
+                __builtin_amdgcn_wave_barrier();
+            }
+            nent = rem;
+        }
+        carried = nent;
     };
 
     // polyT: the forward strand wants the FIRST 16-window with >= 12 T, the reverse strand the LAST with >= 12 A
@@ -662,12 +674,12 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         }
         __builtin_amdgcn_wave_barrier();
         ++tseq;
-        flush();                                // the task's polyT is known: its staged items become clusters
+        flush(false);                           // the task's polyT is known: its staged items become clusters
         task = next_task;
         cur ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (no load of a step is left in flight: every issued step was done)
-    flush();
+    flush(true);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) nhits_stat += __shfl_xor(nhits_stat, d);
     if (lane == 0 && nhits_stat) atomicAdd(&stat[S_NHITS], (unsigned long long)nhits_stat);
