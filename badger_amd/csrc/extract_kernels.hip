@@ -499,9 +499,11 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const uint32_t last_off = __builtin_amdgcn_readfirstlane(tb.last_off), nlast_off = __builtin_amdgcn_readfirstlane(nt.last_off);
         const uint64_t tbase = tab_base(tb);
         const uint64_t nbase = next_task != 0xFFFFFFFFu ? tab_base(nt) : 0ull;
-        auto addr_cur = [&](uint32_t s, uint32_t jj) -> const uint8_t* {
+        auto addr_cur = [&](uint32_t s, uint32_t jj, uint32_t& negB) -> const uint8_t* {      // (also: -B of the lane's read)
             const uint32_t sl = s * 63u + (uint32_t)lane;
-            return bases + tbase + min(tb.rd[jj].x + 16u * sl, last_off);
+            const uint2 ab = *reinterpret_cast<const uint2*>(&tb.rd[jj]);
+            negB = ab.y;
+            return bases + tbase + min(ab.x + 16u * sl, last_off);
         };
         auto addr_next = [&](uint32_t s) -> const uint8_t* {
             const uint32_t sl = s * 63u + (uint32_t)lane;
@@ -512,11 +514,16 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         if (lane < TASK_READS) { s_ringr[wv][ring0 + lane] = (uint32_t)(r0 + lane); s_ringL[wv][ring0 + lane] = (int32_t)tb.rd[lane].z; }
         __builtin_amdgcn_wave_barrier();
         uint32_t j = map_step(0u, (uint32_t)lane), jn = map_step(63u, 63u + (uint32_t)lane);
-        if (niter) {                            // (start of the batch, or behind a task without vectors: nothing is in flight)
-            if (!have_v) { dma_issue(g, addr_cur(0u, j)); have_v = true; }
-            if (!have_n) {
-                if (niter > 1u) { dma_issue(g + 1u, addr_cur(1u, jn)); have_n = true; }
-                else if (nniter) { dma_issue(g + 1u, addr_next(0u)); have_n = true; }
+        uint32_t nb = 0, nbn = 0;               // -B of read j / jn (the vector's position in its read is 16 * slot - B)
+        {
+            const uint8_t* const a0 = addr_cur(0u, j, nb);
+            const uint8_t* const a1 = addr_cur(1u, jn, nbn);
+            if (niter) {                        // (start of the batch, or behind a task without vectors: nothing is in flight)
+                if (!have_v) { dma_issue(g, a0); have_v = true; }
+                if (!have_n) {
+                    if (niter > 1u) { dma_issue(g + 1u, a1); have_n = true; }
+                    else if (nniter) { dma_issue(g + 1u, addr_next(0u)); have_n = true; }
+                }
             }
         }
 
@@ -526,10 +533,10 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             dma_wait(have_n);
             const uint4 v = *reinterpret_cast<const uint4*>(&s_buf[wv][g & 1u][16 * lane]);
             // where the step after next comes from
-            uint32_t jnn = 0;
+            uint32_t jnn = 0, nbnn = 0;
             const uint8_t* pf = bases;
             bool have_nn = false;
-            if (it + 2u < niter) { jnn = map_step(slot_lo + 126u, slot + 126u); pf = addr_cur(it + 2u, jnn); have_nn = true; }
+            if (it + 2u < niter) { jnn = map_step(slot_lo + 126u, slot + 126u); pf = addr_cur(it + 2u, jnn, nbnn); have_nn = true; }
             else if (it + 2u - niter < nniter) { pf = addr_next(it + 2u - niter); have_nn = true; }
 
             // 2-bit codes.  byte & 6 is a perfect hash of "ACTG" (twice the code: 0, 2, 4, 6); v_perm maps it back to the expected
@@ -549,7 +556,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             // read (eval_cands), so flags of bytes outside it never count, and the first 'TTT' behind a valid start lies inside
             // its window (>= 12 T among 16 leave a run of three).  A lane behind the task's last vector sits at p0 >= L of the
             // last read: it has neither.
-            const int32_t p0 = (int32_t)(slot << 4) + (int32_t)tb.rd[j].y;
+            const int32_t p0 = (int32_t)(slot << 4) + (int32_t)nb;
             uint32_t fm = 0x55555555u;                              // positions whose T / A flag counts
             uint32_t zm = lane_z;                                   // 6-mer starts that may hit, Z form
             uint32_t codes, bad = 0;
@@ -618,14 +625,14 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 // p0 >= L, where eval_cands finds no valid window start.)
                 const bool cT = __popc(T_s) + __popc(TA1 & 0x15555555u) >= pt_thr;
                 const bool cA = __popc(A_s) + __popc(TA1 & 0x2AAAAAAAu) >= pt_thr;
-                const unsigned long long bc = __ballot(cT || cA);
+                const unsigned long long bT = __builtin_amdgcn_ballot_w64(cT), bA = __builtin_amdgcn_ballot_w64(cA), bc = bT | bA;
                 if (bc) {
                     // one entry per lane: its flags of both kinds, the kind to evaluate in bit 0 of the info word
                     const uint32_t info = ((uint32_t)(p0 + 16) << 6) | ((ring0 + j) << 1);
                     if (cT || cA) { const uint32_t at = ncand + lanes_below(bc);
                                     s_cand[wv][at] = make_uint2(TA, TA1); s_candi[wv][at] = info | (cT ? 0u : 1u); }
                     ncand += (uint32_t)__popcll(bc);
-                    const unsigned long long bb = __ballot(cT && cA);              // rich in both (AT repeats): a second entry
+                    const unsigned long long bb = bT & bA;                         // rich in both (AT repeats): a second entry
                     if (bb) {
                         if (cT && cA) { const uint32_t at = ncand + lanes_below(bb);
                                         s_cand[wv][at] = make_uint2(TA, TA1); s_candi[wv][at] = info | 1u; }
@@ -654,7 +661,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                     }
                 }
             }
-            j = jn; jn = jnn;
+            j = jn; jn = jnn; nb = nbn; nbn = nbnn;
             have_v = have_n; have_n = have_nn;
             __builtin_amdgcn_wave_barrier();
             while (ncand >= 64u) { ncand -= 64u; eval_cands(ncand, 64u); }
