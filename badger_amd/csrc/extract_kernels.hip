@@ -532,12 +532,6 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             const uint32_t slot = slot_lo + (uint32_t)lane;
             dma_wait(have_n);
             const uint4 v = *reinterpret_cast<const uint4*>(&s_buf[wv][g & 1u][16 * lane]);
-            // where the step after next comes from
-            uint32_t jnn = 0, nbnn = 0;
-            const uint8_t* pf = bases;
-            bool have_nn = false;
-            if (it + 2u < niter) { jnn = map_step(slot_lo + 126u, slot + 126u); pf = addr_cur(it + 2u, jnn, nbnn); have_nn = true; }
-            else if (it + 2u - niter < nniter) { pf = addr_next(it + 2u - niter); have_nn = true; }
 
             // 2-bit codes.  byte & 6 is a perfect hash of "ACTG" (twice the code: 0, 2, 4, 6); v_perm maps it back to the expected
             // letter, v_dot4 packs four of them into twice a byte of codes.  A byte that is not its expected letter (N, a bad
@@ -550,7 +544,13 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 diff |= __builtin_amdgcn_perm(0x00470054u, 0x00430041u, sel[d]) ^ words[d];
             }
             asm volatile("" : "+v"(diff));                          // (one compare of the OR, not four compares)
-            if (have_nn) dma_issue(g, pf);                          // the buffer just read takes the step after next
+            // where the step after next comes from
+            uint32_t jnn = 0, nbnn = 0;
+            const uint8_t* pf = bases;
+            bool have_nn = false;
+            if (it + 2u < niter) { jnn = map_step(slot_lo + 126u, slot + 126u); pf = addr_cur(it + 2u, jnn, nbnn); have_nn = true; }
+            else if (it + 2u - niter < nniter) { pf = addr_next(it + 2u - niter); have_nn = true; }
+            if (have_nn) dma_issue(g, pf);                          // the buffer just read takes it
             // Position of the vector in its read.  Nothing is clipped to the read here: a 6-mer start is checked against the
             // read when the item becomes a cluster (to_plain); a polyT window start is valid only if its 16 bases lie inside the
             // read (eval_cands), so flags of bytes outside it never count, and the first 'TTT' behind a valid start lies inside
@@ -565,7 +565,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 uint32_t c[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) c[d] = __builtin_amdgcn_udot4(sel[d], 0x40100401u, 0u, false);      // 2 * (four codes)
-                codes = (c[0] >> 1) | (c[1] << 7) | (c[2] << 15) | (c[3] << 23);
+                codes = ((((c[3] << 8) + c[2]) << 8) + c[1]) << 7 | (c[0] >> 1);      // (the doubled bytes do not overlap: bit 0 of each is 0)
             } else {
                 const int32_t L = (int32_t)tb.rd[j].z;
                 uint32_t nN = 0, nbad = 0;

@@ -34,10 +34,19 @@ for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
 for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
     if not os.path.isdir(d):
         continue
+    files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    if len(files) != 1:          # (one process per pass; more means leftovers of an earlier run in the same directory)
+        sys.exit("%s holds %d counter files, expected 1" % (d, len(files)))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in files:
         for r in csv.DictReader(open(f)):
             agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # the pass as committed: per kernel and counter, launches and mean per launch
+    with open(os.path.join(ROOT, "profiles", "%s_%s.csv" % (tag, os.path.basename(d))), "w") as out:
+        out.write("kernel,counter,launches,mean_per_launch\n")
+        for k in sorted(agg):
+            for c in sorted(agg[k]):
+                out.write("%s,%s,%d,%.1f\n" % (k, c, len(agg[k][c]), sum(agg[k][c]) / len(agg[k][c])))
     for k, cs in agg.items():
         for c, v in cs.items():
             summary[k][c] = sum(v) / len(v)
