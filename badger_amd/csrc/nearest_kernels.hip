@@ -246,6 +246,17 @@ __device__ __forceinline__ uint32_t low_mask(int bases) { return bases >= 16 ? 0
 constexpr int DV_DIR_SHIFT = 8;                          // directory over the top 22 of the 30 variant bits
 constexpr uint32_t DV_DIR_N = 1u << (30 - DV_DIR_SHIFT);
 
+// The membership map exists four times, each copy addressed by a different permutation of the variant's bits.  The deletion
+// variants i = 4g .. 4g+3 of one 16-mer differ from each other only in the bases 4g .. 4g+2 (deleting base i or base i' > i
+// changes the bases in between), i.e. in the six bits [8g, 8g+6): copy g has those six bits as the bit number inside a 64-bit
+// word, so the four probes of a group of lanes read ONE 8-byte word (one memory sector per group instead of one per lane).
+__device__ __forceinline__ uint32_t delmap_index(uint32_t d, int g)
+{
+    const uint32_t lowm = (1u << (8 * g)) - 1u;
+    return ((d >> (8 * g)) & 63u) | ((d & lowm) << 6) | (d & ~((lowm << 6) | 63u));
+}
+constexpr uint32_t DELMAP_WORDS = 1u << 25;              // 2^30 bits per copy
+
 __global__ __launch_bounds__(256)
 void k_build_delmap(const uint32_t* __restrict__ wl, uint32_t nw, uint32_t* __restrict__ delmap,
                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ dir)
@@ -260,15 +271,27 @@ void k_build_delmap(const uint32_t* __restrict__ wl, uint32_t nw, uint32_t* __re
     keys[g] = dup ? 0xFFFFFFFFu : d;
     vals[g] = w;                                          // position in the sorted whitelist
     if (!dup) {
-        atomicOr(&delmap[d >> 5], 1u << (d & 31u));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const uint32_t x = delmap_index(d, c); atomicOr(&delmap[c * DELMAP_WORDS + (x >> 5)], 1u << (x & 31u)); }
         atomicAdd(&dir[(d >> DV_DIR_SHIFT) + 1], 1u);     // histogram; an inclusive scan turns it into bucket starts
     }
 }
 
+// (variant, entry) pairs after the sort, with what a hit needs from the entry beside them: {variant, rank, caller index, 0}
+__global__ __launch_bounds__(256)
+void k_pack_variants(const uint32_t* __restrict__ dv_var, const uint32_t* __restrict__ dv_pos, uint32_t n,
+                     const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ orig, uint4* __restrict__ out)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t v = dv_var[k], p = dv_pos[k];
+    out[k] = v == 0xFFFFFFFFu ? make_uint4(v, 0u, 0u, 0u) : make_uint4(v, sorted[p], orig[p], 0u);
+}
+
 __global__ __launch_bounds__(256)
 void k_nearest_delins(const uint2* __restrict__ list2,
-                      uint32_t nq, const uint32_t* counters, WlIndex ix, const uint32_t* __restrict__ delmap,
-                      const uint32_t* __restrict__ dv_var, const uint32_t* __restrict__ dv_pos, const uint32_t* __restrict__ dv_dir,
+                      uint32_t nq, const uint32_t* counters, const uint32_t* __restrict__ delmap,
+                      const uint4* __restrict__ dv_ent, const uint32_t* __restrict__ dv_dir,
                       uint32_t* __restrict__ best_idx, uint8_t* __restrict__ best_ed, uint16_t* __restrict__ n_ties,
                       uint32_t* __restrict__ list3, uint32_t* counters_out)
 {
@@ -291,18 +314,20 @@ void k_nearest_delins(const uint2* __restrict__ list2,
         return (s < n2 && s / LSH < seg_cnt) ? seg_list[s / LSH] : make_uint2(NONE_IDX, 0u);
     };
     auto variant = [&](uint32_t qq) -> uint32_t { return ((qq & lm) | ((qq >> 2) & ~lm)) & 0x3FFFFFFFu; };   // lane i: deletion variant i
+    const uint32_t* const my_map = delmap + (size_t)(sub >> 2) * DELMAP_WORDS;   // lanes 4g .. 4g+3 of a query share a word of copy g
+    auto map_word = [&](uint32_t qq) -> uint32_t { return my_map[delmap_index(variant(qq), sub >> 2) >> 5]; };
     uint2 e1 = fetch(wave_slot0), e2 = fetch(wave_slot0 + ngroups);
-    uint32_t w1 = e1.x != NONE_IDX ? delmap[variant(e1.y) >> 5] : 0u;
+    uint32_t w1 = e1.x != NONE_IDX ? map_word(e1.y) : 0u;
     for (uint32_t s0 = wave_slot0; s0 < n2; s0 += ngroups) {                      // wave-uniform loop bound
         const uint32_t qi = e1.x, qq = e1.y, dword = w1;
         const bool on = qi != NONE_IDX;
         e1 = e2;
-        w1 = e1.x != NONE_IDX ? delmap[variant(e1.y) >> 5] : 0u;
+        w1 = e1.x != NONE_IDX ? map_word(e1.y) : 0u;
         e2 = fetch(s0 + 2u * ngroups);
         const uint32_t d = variant(qq);
         // equal neighbours give equal variants: keep the first of a run
         const bool dup_del = sub > 0 && (((qq >> (2 * sub)) ^ (qq >> (2 * sub - 2))) & 3u) == 0u;
-        const bool hit = on && !dup_del && ((dword >> (d & 31u)) & 1u);
+        const bool hit = on && !dup_del && ((dword >> (delmap_index(d, sub >> 2) & 31u)) & 1u);
         // A lane whose variant occurs in the whitelist looks up WHICH entries own it (they are the re-insertions of one base
         // into the variant): directory -> the few sorted (variant, entry) pairs of its bucket -> rank and caller index.
         // All lanes do this at once.  Entries within Hamming distance 2 were pass 1's.
@@ -310,10 +335,10 @@ void k_nearest_delins(const uint2* __restrict__ list2,
         if (hit) {
             const uint32_t lo = dv_dir[d >> DV_DIR_SHIFT], hi = dv_dir[(d >> DV_DIR_SHIFT) + 1];
             for (uint32_t k = lo; k < hi; ++k) {
-                if (dv_var[k] != d) continue;
-                const uint32_t p = dv_pos[k];
-                if (hamming16(ix.sorted[p] ^ qq) <= 2u) continue;
-                const uint32_t oo = ix.orig[p];
+                const uint4 en = dv_ent[k];
+                if (en.x != d) continue;
+                if (hamming16(en.y ^ qq) <= 2u) continue;
+                const uint32_t oo = en.z;
                 const bool dup = (nf > 0 && found[0] == oo) || (nf > 1 && found[1] == oo) ||
                                  (nf > 2 && found[2] == oo) || (nf > 3 && found[3] == oo);
                 if (!dup) {
@@ -446,25 +471,26 @@ static int build_probe_index(bdg_ctx* ctx)
         }
     }
     if ((rc = bdg_reserve(ctx, ctx->w_pent, sizeof(uint32_t) * (prank.size() + pidx.size())))) return rc;
-    if ((rc = bdg_reserve(ctx, ctx->w_delmap, size_t(1) << 27))) return rc;          // 2^30 bits
+    if ((rc = bdg_reserve(ctx, ctx->w_delmap, size_t(4) << 27))) return rc;          // four copies of 2^30 bits
     ctx->w_pwords = prank.size();
     BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_pent.p, prank.data(), sizeof(uint32_t) * prank.size(), hipMemcpyHostToDevice));
     BDG_HIP_TRY(ctx, hipMemcpy(static_cast<uint32_t*>(ctx->w_pent.p) + prank.size(), pidx.data(), sizeof(uint32_t) * pidx.size(), hipMemcpyHostToDevice));
-    BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->w_delmap.p, 0, size_t(1) << 27, ctx->stream));
+    BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->w_delmap.p, 0, size_t(4) << 27, ctx->stream));
     {
         // deletion variants: map bits + (variant, entry) pairs sorted by variant on the device + directory
         const size_t npairs = 16ull * nw;
         if (npairs >= (size_t(1) << 31)) return bdg_fail(ctx, BDG_E_ARG, "whitelist too large");
-        if ((rc = bdg_reserve(ctx, ctx->w_dv, sizeof(uint32_t) * (2 * npairs + DV_DIR_N + 2)))) return rc;
-        auto* dv_var = static_cast<uint32_t*>(ctx->w_dv.p);
-        auto* dv_pos = dv_var + npairs;
-        auto* dv_dir = dv_pos + npairs;
-        uint32_t *k_in = nullptr, *v_in = nullptr; void* temp = nullptr;
+        if ((rc = bdg_reserve(ctx, ctx->w_dv, sizeof(uint32_t) * (4 * npairs + DV_DIR_N + 2)))) return rc;
+        auto* dv_ent = static_cast<uint4*>(ctx->w_dv.p);
+        auto* dv_dir = static_cast<uint32_t*>(ctx->w_dv.p) + 4 * npairs;
+        uint32_t *k_in = nullptr, *v_in = nullptr, *dv_var = nullptr, *dv_pos = nullptr; void* temp = nullptr;
         size_t t_sort = 0, t_scan = 0;
         BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, k_in, dv_var, v_in, dv_pos, (int)npairs, 0, 32, ctx->stream));
         BDG_HIP_TRY(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, t_scan, dv_dir, dv_dir, (int)(DV_DIR_N + 1), ctx->stream));
         BDG_HIP_TRY(ctx, hipMalloc(&k_in, sizeof(uint32_t) * npairs));
         hipError_t e = hipMalloc(&v_in, sizeof(uint32_t) * npairs);
+        if (e == hipSuccess) e = hipMalloc(&dv_var, sizeof(uint32_t) * npairs);
+        if (e == hipSuccess) e = hipMalloc(&dv_pos, sizeof(uint32_t) * npairs);
         if (e == hipSuccess) e = hipMalloc(&temp, std::max(t_sort, t_scan));
         if (e == hipSuccess) e = hipMemsetAsync(dv_dir, 0, sizeof(uint32_t) * (DV_DIR_N + 2), ctx->stream);
         if (e == hipSuccess) {
@@ -472,10 +498,13 @@ static int build_probe_index(bdg_ctx* ctx)
                                static_cast<const uint32_t*>(ctx->w_sorted.p), nw, static_cast<uint32_t*>(ctx->w_delmap.p),
                                k_in, v_in, dv_dir);
             e = hipcub::DeviceRadixSort::SortPairs(temp, t_sort, k_in, dv_var, v_in, dv_pos, (int)npairs, 0, 32, ctx->stream);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(k_pack_variants, dim3((uint32_t)((npairs + 255) / 256)), dim3(256), 0, ctx->stream, dv_var, dv_pos,
+                                   (uint32_t)npairs, static_cast<const uint32_t*>(ctx->w_sorted.p), static_cast<const uint32_t*>(ctx->w_orig.p), dv_ent);
         }
         if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(temp, t_scan, dv_dir, dv_dir, (int)(DV_DIR_N + 1), ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(k_in); (void)hipFree(v_in); (void)hipFree(temp);
+        (void)hipFree(k_in); (void)hipFree(v_in); (void)hipFree(dv_var); (void)hipFree(dv_pos); (void)hipFree(temp);
         BDG_HIP_TRY(ctx, e);
     }
     BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -508,8 +537,6 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t qstride, in
     auto* list3 = reinterpret_cast<uint32_t*>(list2 + (size_t)LSH * nq);       // overflow list, nq indices
     auto* counters = static_cast<uint32_t*>(ctx->n_counters.p);
     BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, NCTR_BYTES, st));
-    WlIndex ix{ srt, org, static_cast<const uint32_t*>(ctx->w_prefix.p), static_cast<const uint32_t*>(ctx->w_bitmap.p),
-                ctx->w_n, 32 - ctx->w_pbits, 32 - ctx->w_bbits };
     PairTables pt{ static_cast<const uint32_t*>(ctx->w_pent.p), static_cast<const uint32_t*>(ctx->w_pent.p) + ctx->w_pwords,
                    static_cast<const uint32_t*>(ctx->w_delmap.p), ctx->w_n };
     {
@@ -521,10 +548,9 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t qstride, in
         {
             ScopedKernelTimer tm(ctx, "k_nearest_delins");
             const uint32_t grid = std::min<uint32_t>((nq + 15) / 16, 256u * 8u);
-            const auto* dv_var = static_cast<const uint32_t*>(ctx->w_dv.p);
             const size_t npairs = 16ull * ctx->w_n;
-            hipLaunchKernelGGL(k_nearest_delins, dim3(grid), dim3(256), 0, st, list2, nq, counters, ix, pt.delmap,
-                               dv_var, dv_var + npairs, dv_var + 2 * npairs,
+            hipLaunchKernelGGL(k_nearest_delins, dim3(grid), dim3(256), 0, st, list2, nq, counters, pt.delmap,
+                               static_cast<const uint4*>(ctx->w_dv.p), static_cast<const uint32_t*>(ctx->w_dv.p) + 4 * npairs,
                                d_best_idx, d_best_ed, d_n_ties, list3, counters);
         }
         // queries whose hit list overflowed (one lane found more than 4 distinct entries): exhaustive
