@@ -124,10 +124,11 @@ void k_nearest_scan(const uint32_t* __restrict__ q, uint32_t qstride, int recs,
 // completely (equal-length strings at Levenshtein distance 1 differ by one substitution) and
 // finds every distance-2 entry that is two substitutions away.  An entry is counted in the
 // first pair of agreeing blocks only, so ties are exact.
-// Pass 2 (k_nearest_delins), 16 lanes per query that still has no hit below distance 2: the
+// Pass 2 (k_nearest_delins), 4 lanes per query that still has no hit below distance 2: the
 // remaining distance-2 entries are one deletion + one insertion away, i.e. share a 15-mer
-// deletion variant with the query.  Lane i probes del(q,i) in a 2^30-bit map of all deletion
-// variants of the whitelist; only on a hit are the 64 re-insertions looked up.
+// deletion variant with the query.  Lane g probes del(q, 4g .. 4g+3) in a 2^30-bit map of all
+// deletion variants of the whitelist (one 64-bit word, see delmap_index); only on a hit are the
+// owners of the variant looked up.
 struct PairTables {
     // Blocks of 16 words (64 bytes, one memory sector): word 0 = entries in the block (<= 15) | next block of the bucket << 8
     // (0 = none), words 1..15 = ranks.  Block p * 65536 + key is the head of bucket `key` of table p; longer buckets
@@ -299,56 +300,63 @@ void k_nearest_delins(const uint2* __restrict__ list2,
 #pragma unroll
     for (int k = 0; k < LSH; ++k) { const uint32_t c = counters[k * 32]; n2 = c > n2 ? c : n2; }
     n2 *= LSH;
-    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
-    const uint32_t wave_slot0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u;     // first query slot of this wave
-    const uint32_t ngroups = gridDim.x * 16u;                                     // a multiple of LSH: a group stays in its segment
-    const unsigned long long gmask = 0xFFFFull << (16 * grp);
+    // Four lanes per query: lane g of a query owns its deletion variants 4g .. 4g+3, whose map bits lie in one 64-bit word.
+    const int lane = threadIdx.x & 63, sub = lane & 3, grp = lane >> 2;
+    const uint32_t wave_slot0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;    // first query slot of this wave
+    const uint32_t ngroups = gridDim.x * 64u;                                     // a multiple of LSH: a group stays in its segment
+    const unsigned long long gmask = 0xFull << (4 * grp);
     const uint32_t seg = (wave_slot0 + (uint32_t)grp) % LSH;
     const uint32_t seg_cnt = counters[seg * 32];
     const uint2* seg_list = list2 + (size_t)seg * nq;
-    const uint32_t lm = low_mask(sub);
     // Two loads lead to a group's answer before any look-up: its list entry {index, query} and the deletion-map word of
-    // its variant.  They are issued two and one iterations ahead, so an iteration starts with both in registers.
+    // its variants.  They are issued two and one iterations ahead, so an iteration starts with both in registers.
     auto fetch = [&](uint32_t s0) -> uint2 {                                      // entry s / LSH of segment s % LSH
         const uint32_t s = s0 + (uint32_t)grp;
         return (s < n2 && s / LSH < seg_cnt) ? seg_list[s / LSH] : make_uint2(NONE_IDX, 0u);
     };
-    auto variant = [&](uint32_t qq) -> uint32_t { return ((qq & lm) | ((qq >> 2) & ~lm)) & 0x3FFFFFFFu; };   // lane i: deletion variant i
-    const uint32_t* const my_map = delmap + (size_t)(sub >> 2) * DELMAP_WORDS;   // lanes 4g .. 4g+3 of a query share a word of copy g
-    auto map_word = [&](uint32_t qq) -> uint32_t { return my_map[delmap_index(variant(qq), sub >> 2) >> 5]; };
+    auto variant = [&](uint32_t qq, int t) -> uint32_t {                          // deletion variant 4 * sub + t
+        const uint32_t lm = low_mask(4 * sub + t);
+        return ((qq & lm) | ((qq >> 2) & ~lm)) & 0x3FFFFFFFu;
+    };
+    const uint2* const my_map = reinterpret_cast<const uint2*>(delmap + (size_t)sub * DELMAP_WORDS);
+    auto map_word = [&](uint32_t qq) -> uint2 { return my_map[delmap_index(variant(qq, 0), sub) >> 6]; };
     uint2 e1 = fetch(wave_slot0), e2 = fetch(wave_slot0 + ngroups);
-    uint32_t w1 = e1.x != NONE_IDX ? map_word(e1.y) : 0u;
+    uint2 w1 = e1.x != NONE_IDX ? map_word(e1.y) : make_uint2(0u, 0u);
     for (uint32_t s0 = wave_slot0; s0 < n2; s0 += ngroups) {                      // wave-uniform loop bound
-        const uint32_t qi = e1.x, qq = e1.y, dword = w1;
+        const uint32_t qi = e1.x, qq = e1.y;
+        const unsigned long long word = ((unsigned long long)w1.y << 32) | w1.x;
         const bool on = qi != NONE_IDX;
         e1 = e2;
-        w1 = e1.x != NONE_IDX ? map_word(e1.y) : 0u;
+        w1 = e1.x != NONE_IDX ? map_word(e1.y) : make_uint2(0u, 0u);
         e2 = fetch(s0 + 2u * ngroups);
-        const uint32_t d = variant(qq);
-        // equal neighbours give equal variants: keep the first of a run
-        const bool dup_del = sub > 0 && (((qq >> (2 * sub)) ^ (qq >> (2 * sub - 2))) & 3u) == 0u;
-        const bool hit = on && !dup_del && ((dword >> (delmap_index(d, sub >> 2) & 31u)) & 1u);
-        // A lane whose variant occurs in the whitelist looks up WHICH entries own it (they are the re-insertions of one base
-        // into the variant): directory -> the few sorted (variant, entry) pairs of its bucket -> rank and caller index.
-        // All lanes do this at once.  Entries within Hamming distance 2 were pass 1's.
+        // A variant that occurs in the whitelist: WHICH entries own it (they are the re-insertions of one base into the
+        // variant)?  directory -> the few sorted {variant, rank, caller index} entries of its bucket.  Entries within Hamming
+        // distance 2 were pass 1's.  Equal neighbours give equal variants: the first of a run stands for all.
         uint32_t found[4] = { 0, 0, 0, 0 }; int nf = 0; bool overflow = false;
-        if (hit) {
-            const uint32_t lo = dv_dir[d >> DV_DIR_SHIFT], hi = dv_dir[(d >> DV_DIR_SHIFT) + 1];
-            for (uint32_t k = lo; k < hi; ++k) {
-                const uint4 en = dv_ent[k];
-                if (en.x != d) continue;
-                if (hamming16(en.y ^ qq) <= 2u) continue;
-                const uint32_t oo = en.z;
-                const bool dup = (nf > 0 && found[0] == oo) || (nf > 1 && found[1] == oo) ||
-                                 (nf > 2 && found[2] == oo) || (nf > 3 && found[3] == oo);
-                if (!dup) {
-                    if (nf < 4) { found[0] = nf == 0 ? oo : found[0]; found[1] = nf == 1 ? oo : found[1];
-                                  found[2] = nf == 2 ? oo : found[2]; found[3] = nf == 3 ? oo : found[3]; ++nf; }
-                    else overflow = true;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * sub + t;
+            const uint32_t d = variant(qq, t);
+            const bool dup_del = i > 0 && (((qq >> (2 * i)) ^ (qq >> (2 * i - 2))) & 3u) == 0u;
+            const bool hit = on && !dup_del && ((word >> (delmap_index(d, sub) & 63u)) & 1ull);
+            if (hit) {
+                const uint32_t lo = dv_dir[d >> DV_DIR_SHIFT], hi = dv_dir[(d >> DV_DIR_SHIFT) + 1];
+                for (uint32_t k = lo; k < hi; ++k) {
+                    const uint4 en = dv_ent[k];
+                    if (en.x != d) continue;
+                    if (hamming16(en.y ^ qq) <= 2u) continue;
+                    const uint32_t oo = en.z;
+                    const bool dup = (nf > 0 && found[0] == oo) || (nf > 1 && found[1] == oo) ||
+                                     (nf > 2 && found[2] == oo) || (nf > 3 && found[3] == oo);
+                    if (!dup) {
+                        if (nf < 4) { found[0] = nf == 0 ? oo : found[0]; found[1] = nf == 1 ? oo : found[1];
+                                      found[2] = nf == 2 ? oo : found[2]; found[3] = nf == 3 ? oo : found[3]; ++nf; }
+                        else overflow = true;
+                    }
                 }
             }
         }
-        // merge inside the 16-lane group: distinct hits, lowest caller index
+        // merge inside the query's four lanes: distinct hits, lowest caller index
         const bool any_over = (__ballot(overflow) & gmask) != 0;
         uint32_t add = 0, midx = NONE_IDX;
         int pending = nf;
@@ -547,7 +555,7 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t qstride, in
     if (max_ed >= 2) {
         {
             ScopedKernelTimer tm(ctx, "k_nearest_delins");
-            const uint32_t grid = std::min<uint32_t>((nq + 15) / 16, 256u * 8u);
+            const uint32_t grid = std::min<uint32_t>((nq + 63) / 64, 256u * 8u);
             const size_t npairs = 16ull * ctx->w_n;
             hipLaunchKernelGGL(k_nearest_delins, dim3(grid), dim3(256), 0, st, list2, nq, counters, pt.delmap,
                                static_cast<const uint4*>(ctx->w_dv.p), static_cast<const uint32_t*>(ctx->w_dv.p) + 4 * npairs,
