@@ -563,6 +563,51 @@ def test_extract_long_reads_and_r1_repeats(ctx, orc):
     assert (got == want).all(), _diff(got, want)
 
 
+def test_extract_task_and_step_boundaries(ctx, orc):
+    """The scan kernel takes reads in tasks of 16 and a task's vectors 63 per step, with the loads of the next two steps in
+    flight across step and task ends: tasks without vectors (runs of empty reads), tasks of exactly one or two steps in a row,
+    vector totals at every residue around a multiple of 63, batch sizes around a multiple of 16, reads that end exactly on a
+    16-byte boundary, N and adapter copies in the first / last vector of a task."""
+    rng = np.random.default_rng(4242)
+    R1 = "CTACACGACGCTCTTCCGATCT"
+    rnd = lambda k: "".join("ACGT"[i] for i in rng.integers(0, 4, k))
+    cdna = lambda k: rnd(int(rng.integers(0, 30))) + R1 + rnd(28) + "T" * 30 + rnd(k)
+
+    def check(seqs, lead=0):
+        bases, off = synth.list_to_reads(seqs)
+        if lead:                                   # the first read does not start on a 16-byte boundary
+            bases = np.concatenate([np.frombuffer(rnd(lead).encode(), dtype=np.uint8), bases])
+            off = off + np.uint64(lead)
+        got = ctx.extract_batch(bases, off, 12)
+        want = orc.extract_batch(bases, off, 12, threads=8)
+        assert (got == want).all(), _diff(got, want)
+
+    for n in (1, 2, 15, 16, 17, 31, 32, 33, 48):                         # batch sizes around the task size
+        check([cdna(int(rng.integers(0, 900))) for _ in range(n)], lead=int(rng.integers(0, 16)))
+    # whole tasks without a single vector between ordinary ones
+    seqs = [cdna(500) for _ in range(16)] + [""] * 16 + [cdna(300) for _ in range(5)] + [""] * 40 + [cdna(700) for _ in range(20)] + [""] * 16
+    check(seqs)
+    check([""] * 100)
+    # tasks of one step (16 reads in <= 63 vectors) in a row, then long ones, then one-step tasks again
+    short = lambda: rnd(int(rng.integers(20, 60)))
+    check([short() for _ in range(64)] + [cdna(4000) for _ in range(16)] + [short() for _ in range(48)] + [R1 + rnd(16) + rnd(12) + "T" * 30])
+    # a task's vector total at every residue around multiples of 63: 15 fixed reads + one that sets the total
+    for total in (62, 63, 64, 65, 125, 126, 127, 189, 190):
+        fixed = [rnd(16 * 3) for _ in range(15)]                      # 45 vectors (reads start on 16-byte boundaries here)
+        last = 16 * (total - 45)
+        check(fixed + [cdna(0)[:last] if last <= 110 else cdna(last - 110)[:last]] + [cdna(200) for _ in range(16)])
+    # reads of every length around the 16-byte grid, with N at the ends and adapter copies cut by task boundaries
+    seqs = []
+    for L in list(range(0, 70)) + [95, 96, 97, 1007, 1008, 1009]:
+        s = cdna(L)[:max(L, 0)] if L < 120 else cdna(L - 110)
+        seqs.append(s)
+        if len(s) > 2:
+            seqs.append("N" + s[1:-1] + "N")
+    rng.shuffle(seqs)
+    check(seqs, lead=7)
+    check([R1 * 3 + "T" * 40] * 40 + [rnd(1008)] * 8 + [(rnd(10) + R1)[-16 * k:] for k in range(1, 3)] * 8)
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_nearest16_and_graph_fuzz_clustered(ctx, orc, seed):
     """Dense barcode neighbourhoods: many ties, multi-hit deletion variants, homopolymer-rich strings."""
