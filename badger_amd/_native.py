@@ -29,7 +29,7 @@ SLOTS = 4
 
 EXPORTS = [
     "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_set_stream", "bdg_synchronize", "bdg_set_overlap",
-    "bdg_profile_enable", "bdg_profile_reset", "bdg_profile_read",
+    "bdg_profile_enable", "bdg_profile_only", "bdg_profile_reset", "bdg_profile_read",
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
@@ -82,6 +82,7 @@ def load():
     L.bdg_synchronize.argtypes = [vp]
     L.bdg_set_overlap.argtypes = [vp, C.c_int]
     L.bdg_profile_enable.argtypes = [vp, C.c_int]
+    L.bdg_profile_only.argtypes = [vp, C.c_char_p]
     L.bdg_profile_reset.argtypes = [vp]
     L.bdg_profile_read.argtypes = [vp, C.POINTER(KernelTime), C.c_int]
     L.bdg_extract_batch.argtypes = [vp, vp, vp, u32, u32, vp]
@@ -164,6 +165,10 @@ class Context:
 
     def profile(self, on=True):
         self._check(self.lib.bdg_profile_enable(self.h, 1 if on else 0))
+
+    def profile_only(self, kernel=None):
+        """time only this kernel (None: every kernel again)"""
+        self._check(self.lib.bdg_profile_only(self.h, kernel.encode() if kernel else None))
 
     def profile_reset(self):
         self._check(self.lib.bdg_profile_reset(self.h))

@@ -181,6 +181,13 @@ int bdg_set_overlap(bdg_ctx* ctx, int on)
 
 int bdg_profile_enable(bdg_ctx* ctx, int on) { if (!ctx) return BDG_E_ARG; ctx->profiling = on != 0; return BDG_OK; }
 
+int bdg_profile_only(bdg_ctx* ctx, const char* kernel)
+{
+    if (!ctx) return BDG_E_ARG;
+    ctx->profile_only = kernel ? kernel : "";
+    return BDG_OK;
+}
+
 int bdg_profile_reset(bdg_ctx* ctx)
 {
     if (!ctx) return BDG_E_ARG;

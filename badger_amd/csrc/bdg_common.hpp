@@ -38,6 +38,7 @@ struct bdg_ctx {
     hipStream_t launch_stream = nullptr;    // where kernels (and their timing events) currently go: stream, or aux_stream
     std::string err;
     bool profiling = false;
+    std::string profile_only;               // non-empty: only this kernel is timed (bdg_profile_only)
     std::vector<KTimer> timers;
     std::vector<hipEvent_t> event_pool;
 
@@ -113,7 +114,7 @@ void bdg_timer_end(bdg_ctx* ctx, int id);
 struct ScopedKernelTimer {
     bdg_ctx* ctx; int id;
     ScopedKernelTimer(bdg_ctx* c, const char* name) : ctx(c), id(-1) {
-        if (c->profiling) { id = bdg_timer_id(c, name); bdg_timer_begin(c, id); }
+        if (c->profiling && (c->profile_only.empty() || c->profile_only == name)) { id = bdg_timer_id(c, name); bdg_timer_begin(c, id); }
     }
     ~ScopedKernelTimer() { if (id >= 0) bdg_timer_end(ctx, id); }
 };

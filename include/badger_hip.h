@@ -105,6 +105,11 @@ int  bdg_synchronize(bdg_ctx* ctx);            /* waits for everything the conte
  * bdg_synchronize() (or a device-wide synchronisation), not merely in main-stream order. */
 int  bdg_set_overlap(bdg_ctx* ctx, int on);
 int  bdg_profile_enable(bdg_ctx* ctx, int on);
+/* Time only the kernel of this name (NULL or "": every kernel again).  A pair of events around a kernel costs a few
+ * microseconds and keeps the next launch from being queued behind it early; timing all eight kernels of a step adds ~6 % to
+ * the step, timing one adds nothing measurable (bench.py times the dominant kernel in its timed region, all of them in a
+ * separate pass). */
+int  bdg_profile_only(bdg_ctx* ctx, const char* kernel);
 int  bdg_profile_reset(bdg_ctx* ctx);
 /* Synchronises, then writes up to cap entries; returns the number of kernels known. */
 int  bdg_profile_read(bdg_ctx* ctx, bdg_kernel_time* out, int cap);
