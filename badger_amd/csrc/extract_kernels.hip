@@ -541,7 +541,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 sel[d] = words[d] & 0x06060606u;
-                diff |= __builtin_amdgcn_perm(0x00470054u, 0x00430041u, sel[d]) ^ words[d];
+                diff = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_perm(0x00470054u, 0x00430041u, sel[d]), words[d], diff, 0xBE);   // (a ^ b) | c
             }
             asm volatile("" : "+v"(diff));                          // (one compare of the OR, not four compares)
             // where the step after next comes from
@@ -557,16 +557,20 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             // its window (>= 12 T among 16 leave a run of three).  A lane behind the task's last vector sits at p0 >= L of the
             // last read: it has neither.
             const int32_t p0 = (int32_t)(slot << 4) + (int32_t)nb;
-            uint32_t fm = 0x55555555u;                              // positions whose T / A flag counts
+            const uint32_t where = ((uint32_t)(p0 + 16) << 5) | (ring0 + j);     // position and ring slot, as staged and parked
             uint32_t zm = lane_z;                                   // 6-mer starts that may hit, Z form
             uint32_t codes, bad = 0;
+            uint32_t T_s, A_s;                                      // T = code 2, A = code 0: flags on the even bits
             const bool exact = __ballot(diff != 0) != 0;
             if (!exact) {
                 uint32_t c[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) c[d] = __builtin_amdgcn_udot4(sel[d], 0x40100401u, 0u, false);      // 2 * (four codes)
                 codes = ((((c[3] << 8) + c[2]) << 8) + c[1]) << 7 | (c[0] >> 1);      // (the doubled bytes do not overlap: bit 0 of each is 0)
+                T_s = (codes >> 1) & ~codes & 0x55555555u;
+                A_s = ~((codes >> 1) | codes) & 0x55555555u;
             } else {
+                uint32_t fm = 0x55555555u;                                       // positions whose T / A flag counts
                 const int32_t L = (int32_t)tb.rd[j].z;
                 uint32_t nN = 0, nbad = 0;
                 codes = 0;
@@ -593,10 +597,9 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 nvm |= nvm >> 2;
                 nvm |= N32 >> 4; nvm |= N32 >> 5;
                 zm &= z_from_mask16(~nvm);                                       // 6-mers touching an N never match
+                T_s = (codes >> 1) & ~codes & fm;
+                A_s = ~((codes >> 1) | codes) & fm;
             }
-            // T = code 2, A = code 0: flags on the even bits
-            const uint32_t T_s = (codes >> 1) & ~codes & fm;
-            const uint32_t A_s = ~((codes >> 1) | codes) & fm;
 
             // look-ahead from the next lane (one DPP move each)
             const uint32_t TA = T_s | (A_s << 1);
@@ -628,7 +631,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 const unsigned long long bT = __builtin_amdgcn_ballot_w64(cT), bA = __builtin_amdgcn_ballot_w64(cA), bc = bT | bA;
                 if (bc) {
                     // one entry per lane: its flags of both kinds, the kind to evaluate in bit 0 of the info word
-                    const uint32_t info = ((uint32_t)(p0 + 16) << 6) | ((ring0 + j) << 1);
+                    const uint32_t info = where << 1;
                     if (cT || cA) { const uint32_t at = ncand + lanes_below(bc);
                                     s_cand[wv][at] = make_uint2(TA, TA1); s_candi[wv][at] = info | (cT ? 0u : 1u); }
                     ncand += (uint32_t)__popcll(bc);
@@ -652,7 +655,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                 const unsigned long long bal = __ballot(z != 0);
                 if (bal) {
                     const uint32_t cnt = (uint32_t)__popcll(bal);
-                    const uint2 item = make_uint2(z, ((uint32_t)(p0 + 16) << 5) | (ring0 + j));
+                    const uint2 item = make_uint2(z, where);
                     if (nent + cnt <= WENT) {
                         if (z) ent[nent + lanes_below(bal)] = item;
                         nent += cnt;
