@@ -1,0 +1,50 @@
+"""Properties of the generated gfx950 code that the scan kernel's hand-placed instructions rely on (CPU tier: hipcc
+cross-compiles without a GPU).  k_scan_reads loads its vectors with global_load_lds_dwordx4 from inline assembly: the
+assembly sets M0 (a register the compiler reserves) and waits for the loads by hand, so nothing else in the kernel may
+touch M0, and the kernel must keep the register / LDS budget its launch shape assumes (2 blocks of 8 waves per CU)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def scan_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path_factory.mktemp("isa") / "extract.s")
+    src = os.path.join(ROOT, "badger_amd", "csrc", "extract_kernels.hip")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-Wno-unused-function",
+                    "-Wno-inline-asm", "-Wno-unused-command-line-argument", "-o", out, src], check=True, timeout=600)
+    text = open(out).read()
+    m = re.search(r"^(_ZN\S*k_scan_reads\S*):[^\n]*\n(.*?)\n\s*\.amdhsa_kernel \1\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
+    assert m, "k_scan_reads not found in the generated code"
+    meta = dict(re.findall(r"\.set \S*k_scan_reads\S*\.(num_vgpr|private_seg_size|numbered_sgpr), (\d+)", text))
+    return m.group(2).split("\n"), m.group(3), meta
+
+
+def test_m0_is_written_only_for_the_lds_dma(scan_isa):
+    body, _, _ = scan_isa
+    code = [l.strip() for l in body if l.strip() and not l.strip().startswith(";")]
+    uses = [i for i, l in enumerate(code) if re.search(r"\bm0\b", l)]
+    dmas = [i for i, l in enumerate(code) if l.startswith("global_load_lds_dwordx4")]
+    assert dmas, "the LDS-DMA loads are gone"
+    for i in uses:
+        assert code[i].startswith("s_mov_b32 m0,"), "M0 touched outside the DMA sequence: " + code[i]
+        assert any(0 < d - i <= 3 for d in dmas), "an M0 write that is not followed by its load"
+    assert len(uses) == len(dmas)
+    # every wait on the vector-memory counter inside the step loop is one of the hand-placed ones or a full drain
+    assert any("s_waitcnt vmcnt(1)" in l for l in code)
+
+
+def test_scan_kernel_budget(scan_isa):
+    _, desc, meta = scan_isa
+    assert int(meta["private_seg_size"]) == 0, "k_scan_reads spills"
+    assert int(meta["num_vgpr"]) <= 128, "more than 128 registers: fewer than 4 waves per SIMD"
+    lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", desc).group(1))
+    assert 2 * lds <= 160 * 1024, "two blocks no longer fit a CU's LDS"
