@@ -7,8 +7,8 @@
 // alignment behind align_pattern_ssw (:42-51).
 //
 // Launches per batch, no host round trip in between:
-//   k_scan_reads     persistent waves take tasks of 8 reads and stream them as 16-byte vectors, 63 per step, straight from
-//                    the ASCII buffer: polyT start of both strands (T-windows of the reverse complement are A-windows of
+//   k_scan_reads     persistent waves take tasks of 16 reads and stream them as 16-byte vectors, 63 per step, straight from
+//                    the ASCII buffer (through LDS-DMA, two steps ahead): polyT start of both strands (T-windows of the reverse complement are A-windows of
 //                    the read) and every R1 6-mer hit of both strands (7-mer probe table in LDS).  The hits of a vector -
 //                    or of two neighbouring vectors cut through one adapter copy - form one CLUSTER
 //                    {read, (first hit << 1) | strand, offset mask}; queue A takes clusters whose first hit lies left of
@@ -119,14 +119,15 @@ __device__ __forceinline__ uint32_t range_mask16(int32_t lo, int32_t hi)
 
 // ---------------------------------------------------------------------------
 // k_scan_reads
-// Autonomous waves, no block barrier after the tables are in LDS.  A wave repeatedly takes a TASK
-// of 8 consecutive reads from an XCD-sharded counter (the next task is taken, and its offsets are
+// Autonomous waves, no block barrier after the probe table is in LDS.  A wave repeatedly takes a TASK
+// of 16 consecutive reads from a sharded counter (the next task is taken, and its offsets are
 // loaded, while the current one is processed).  The task's reads are laid end to end as a stream of
 // 16-byte vectors; each step the wave's lanes take 63 consecutive vectors of that stream (lane 63
 // repeats as lane 0 of the next step: it only feeds lane 62's look-ahead), so short tails of one
-// read and the head of the next share a step.  polyT is reduced per read segment with ballots.
-// Clusters are staged in a per-wave LDS region and flushed to the global queues with ONE packed
-// 64-bit reservation (A count | B count << 32) every few tasks.
+// read and the head of the next share a step.  The vectors reach the wave through LDS
+// (global_load_lds_dwordx4, two steps ahead).  polyT candidates are parked and evaluated 64 at a time.
+// Lane-vectors with hits are staged in a per-wave LDS region and become clusters at the end of the
+// task, written to the global queues with ONE packed 64-bit reservation (A count | B count << 32).
 // ---------------------------------------------------------------------------
 constexpr int TASK_READS = 16;
 constexpr uint32_t WENT = 256;             // per-wave staging (2 KiB)
@@ -411,31 +412,34 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
             const uint2 c = s_cand[wv][first + lane];
             const uint32_t info = s_candi[wv][first + lane];
             const int32_t p0 = (int32_t)(info >> 6) - 16; const uint32_t ring = (info >> 1) & 31u, typ = info & 1u;
-            const uint32_t m = gather_even(c.x >> typ) | (gather_even(c.y >> typ) << 16);
+            uint32_t m = gather_even(c.x >> typ) | (gather_even(c.y >> typ) << 16);     // flags of the 32 bases from p0 on
             const int32_t L = s_ringL[wv][ring];
-            uint32_t q = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                // bit 5 of popcount + 20 is set iff the count is >= 12 (int(16 * 0.75), common.py:11)
-                const uint32_t cnt = __popc(__builtin_amdgcn_ubfe(m, k, 16)) + 20u;
-                q |= (k >= 5 ? (cnt << (k - 5)) : (cnt >> (5 - k))) & (1u << k);
-            }
-            const uint32_t m3 = m & (m >> 1) & (m >> 2);
-            if (typ == 0) {
-                q &= range_mask16(-p0, L - 16 - p0);                    // window starts 0 <= p < L-16 (common.py:17,28)
-                if (q) {
-                    const int k = __builtin_ctz(q);
-                    const uint32_t tt = m3 >> k;                            // 'TTT' starts, common.py:31
-                    atomicMin(&s_ptmin[wv][ring][0], ((uint32_t)(p0 + k) << 5) | (tt ? (uint32_t)__builtin_ctz(tt) : 0u));
-                }
-            } else {
-                q &= range_mask16(1 - p0, L - 16 - p0 + 1);             // reverse strand: 0 <= L-16-p < L-16
-                if (q) {
-                    const int k = 31 - __builtin_clz(q);
-                    const uint32_t mm = m3 & ((1u << (k + 14)) - 1u);
-                    const int j = mm ? 31 - __builtin_clz(mm) : k + 13;
-                    atomicMin(&s_ptmin[wv][ring][1], ((uint32_t)(L - 16 - (p0 + k)) << 5) | (uint32_t)(k + 13 - j));
-                }
+            // The reverse strand wants the LAST A-window, which is the first window of the same 31 bases read backwards
+            // (base p0 + 30 - x at position x): window start k becomes 15 - k, the position of the window on the reverse
+            // strand, L - 16 - (p0 + k), becomes (L - 31 - p0) + (15 - k), and the first 'TTT' behind the start is the same
+            // search.  One code path serves both kinds.
+            if (typ) m = __brev(m) >> 1;
+            const int32_t P = typ ? L - 31 - p0 : p0;                   // strand position of the window with start 0
+            // The 16 window counts at once, bit-sliced: after the level of width w, bit k of (s_i) holds bit i of the number
+            // of flags among m[k .. k + w); a level adds the counts of two half windows (a ripple adder of bitwise operations:
+            // sum = a ^ b ^ carry, carry = majority).  31 instructions for all 16 starts.
+            auto xor3 = [](uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); };
+            auto maj = [](uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); };
+            const uint32_t a0 = m ^ (m >> 1), a1 = m & (m >> 1);                                         // width 2
+            const uint32_t b0 = a0 >> 2, b1 = a1 >> 2, c0 = a0 & b0;
+            const uint32_t s0 = a0 ^ b0, s1 = xor3(a1, b1, c0), s2 = maj(a1, b1, c0);                    // width 4: 0..4
+            const uint32_t d0 = s0 >> 4, d1 = s1 >> 4, d2 = s2 >> 4, e0 = s0 & d0, e1 = maj(s1, d1, e0);
+            const uint32_t t0 = s0 ^ d0, t1 = xor3(s1, d1, e0), t2 = xor3(s2, d2, e1), t3 = maj(s2, d2, e1);   // width 8: 0..8
+            const uint32_t f0 = t0 >> 8, f1 = t1 >> 8, f2 = t2 >> 8, f3 = t3 >> 8;
+            const uint32_t g0 = t0 & f0, g1 = maj(t1, f1, g0), g2 = maj(t2, f2, g1);
+            const uint32_t u2 = xor3(t2, f2, g1), u3 = xor3(t3, f3, g2), u4 = maj(t3, f3, g2);           // width 16: 0..16 (bits 0, 1 not needed)
+            // >= 12 (int(16 * 0.75), common.py:11) = 16, or 8 + 4 + ...
+            uint32_t q = __builtin_amdgcn_bitop3_b32(u4, u3, u2, 0xF8) &                                 // u4 | (u3 & u2)
+                         range_mask16(-P, L - 16 - P);                  // window starts 0 <= p < L-16 (common.py:17,28)
+            if (q) {
+                const int k = __builtin_ctz(q);
+                const uint32_t tt = (m & (m >> 1) & (m >> 2)) >> k;     // 'TTT' starts, common.py:31
+                atomicMin(&s_ptmin[wv][ring][typ], ((uint32_t)(P + k) << 5) | (tt ? (uint32_t)__builtin_ctz(tt) : 0u));
             }
         }
     };
