@@ -256,19 +256,21 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const uint32_t nr = (uint32_t)(n - r0 < TASK_READS ? n - r0 : TASK_READS);
         uint64_t o = 0;
         if ((uint32_t)lane <= nr) o = off[r0 + lane];
-        const uint64_t o1 = __shfl_down(o, 1);
+        // (lanes 0 .. 16 hold the task's offsets: neighbours, prefix sums and maxima over them go through DPP, not LDS)
+        const uint64_t o1 = ((uint64_t)wave_shl1((uint32_t)(o >> 32)) << 32) | wave_shl1((uint32_t)o);
         int64_t L = (uint32_t)lane < nr ? (int64_t)(o1 - o) : 0;
         bool bad = false;
         // the vectors of a task are addressed relative to its first one with 32 bits: true for any valid offset array (8 reads
         // below 2^26 bases each); offsets that jump further are corrupt
-        const uint64_t T0 = __shfl(o, 0) & ~15ull;
+        const uint64_t T0 = (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(o >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)o)) & ~15ull;
         if (L < 0 || L >= (1ll << 26) || o + (uint64_t)L > total_rounded || o - T0 >= (1ull << 30)) { bad = (uint32_t)lane < nr; L = 0; }
         if (bad) atomicMax(&stat[S_BADREAD], ~(unsigned long long)(r0 + lane));        // corrupt offsets: report, never loop on them
         // every vector of a validated read lies inside [0, total_rounded): no bounds checks on the loads below
         uint32_t nv = L > 0 ? (uint32_t)(((o & 15ull) + (uint64_t)L + 15ull) >> 4) : 0u;
         uint32_t incl = nv;
-#pragma unroll
-        for (int d = 1; d < TASK_READS; d <<= 1) { const uint32_t x = __shfl_up(incl, d); if (lane >= d) incl += x; }
+        static_assert(TASK_READS == 16, "the sixteen reads of a task are one DPP row");
+#define BDG_ROW_SHR(x, d) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x110 + (d) /* row_shr:d */, 0xF, 0xF, true))
+        incl += BDG_ROW_SHR(incl, 1); incl += BDG_ROW_SHR(incl, 2); incl += BDG_ROW_SHR(incl, 4); incl += BDG_ROW_SHR(incl, 8);
         if (lane < TASK_READS) {
             const uint32_t excl = incl - nv;
             const uint32_t A = nv ? (uint32_t)((o & ~15ull) - T0) - 16u * excl : 0u;
@@ -278,9 +280,10 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         }
         // offset of the last vector: lanes behind the task's end re-read it (a valid address that costs no select)
         uint32_t lastv = lane < TASK_READS && nv ? (uint32_t)((o & ~15ull) - T0) + 16u * (nv - 1u) : 0u;
-#pragma unroll
-        for (int d = 1; d < TASK_READS; d <<= 1) { const uint32_t x = __shfl_xor(lastv, d); lastv = x > lastv ? x : lastv; }
-        if (lane == 0) tb.last_off = lastv;
+        lastv = max(lastv, BDG_ROW_SHR(lastv, 1)); lastv = max(lastv, BDG_ROW_SHR(lastv, 2));
+        lastv = max(lastv, BDG_ROW_SHR(lastv, 4)); lastv = max(lastv, BDG_ROW_SHR(lastv, 8));
+#undef BDG_ROW_SHR
+        if (lane == TASK_READS - 1) tb.last_off = lastv;             // (maximum over lanes 0 .. 15)
     };
     auto tab_base = [&](const TaskTab& tb) -> uint64_t {           // wave-uniform byte offset of the task's first vector
         const uint32_t lo = __builtin_amdgcn_readfirstlane(tb.base_lo), hi = __builtin_amdgcn_readfirstlane(tb.base_hi);
