@@ -250,7 +250,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const unsigned long long t = (unsigned long long)k * TASK_SHARDS + shard;
         return t < ntasks ? (uint32_t)t : 0xFFFFFFFFu;
     };
-    // offsets of a task -> table (lanes 0..8 load, everybody computes through shuffles)
+    // offsets of a task -> table (lanes 0..16 load them; neighbours, prefix sums and maxima go through DPP)
     auto load_tab = [&](uint32_t task, TaskTab& tb) {
         const uint64_t r0 = (uint64_t)task * TASK_READS;
         const uint32_t nr = (uint32_t)(n - r0 < TASK_READS ? n - r0 : TASK_READS);
@@ -260,7 +260,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const uint64_t o1 = ((uint64_t)wave_shl1((uint32_t)(o >> 32)) << 32) | wave_shl1((uint32_t)o);
         int64_t L = (uint32_t)lane < nr ? (int64_t)(o1 - o) : 0;
         bool bad = false;
-        // the vectors of a task are addressed relative to its first one with 32 bits: true for any valid offset array (8 reads
+        // the vectors of a task are addressed relative to its first one with 32 bits: true for any valid offset array (16 reads
         // below 2^26 bases each); offsets that jump further are corrupt
         const uint64_t T0 = (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(o >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)o)) & ~15ull;
         if (L < 0 || L >= (1ll << 26) || o + (uint64_t)L > total_rounded || o - T0 >= (1ull << 30)) { bad = (uint32_t)lane < nr; L = 0; }

@@ -344,13 +344,13 @@ void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
 //   k_qj_split   for every bucket the first entry at or past each multiple of W rows (so that a row can take its
 //                candidates in slices of W rows without searching),
 //   k_graph_qjoin one block per row i: for each slice of later rows, every entry of the 11 bucket tails is one unit
-//                of S(i, j); the block accumulates them in an LDS hash table {j: count} - the count IS the reference's
-//                statistic - then sweeps the table: entries with count >= T are verified with one Myers pass (dmin3)
-//                64 at a time.  Nothing is computed for the ~99 % of candidate pairs that share a single six-mer
-//                by chance, except one LDS atomic.
-// A slice with more entries than the table takes is cut by a hash of j into parts that are counted first, so a
-// pass can never overflow the table; a slice that cannot be cut (P_MAX parts are not enough - only contrived inputs)
-// is verified entry by entry in closed form (qgram_S + "is this the first matching position pair").
+//                of S(i, j); the block keeps S(i, j) in one byte of LDS per row j of the slice (direct addressing, no keys)
+//                - the count IS the reference's statistic - and the add that lifts a byte to T lists j; listed rows are
+//                verified with one Myers pass (dmin3) 64 at a time.  Nothing is computed for the ~99 % of candidate
+//                pairs that share a single six-mer by chance, except one LDS atomic.
+// A slice takes any number of entries.  If a row's list of candidates overflows (dense single-cell inputs), the slice's rows
+// are read back from the counters instead.  bdg_graph_set_algo(ctx, 4) verifies every entry by itself in closed form
+// (qgram_S + "is this the first matching position pair"): the cross-check of the tests.
 // ---------------------------------------------------------------------------
 constexpr int QJ_NQ = 11;                        // six-mers per 16-mer
 constexpr uint32_t QJ_W = 32768;                 // rows per slice = bytes of LDS counters per block
