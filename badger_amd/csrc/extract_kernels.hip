@@ -262,7 +262,8 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         bool bad = false;
         // the vectors of a task are addressed relative to its first one with 32 bits: true for any valid offset array (16 reads
         // below 2^26 bases each); offsets that jump further are corrupt
-        const uint64_t T0 = (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(o >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)o)) & ~15ull;
+        const uint32_t o0_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)o), o0_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(o >> 32));
+        const uint64_t T0 = (((uint64_t)o0_hi << 32) | o0_lo) & ~15ull;          // (the builtin returns int: unsigned before it is widened)
         if (L < 0 || L >= (1ll << 26) || o + (uint64_t)L > total_rounded || o - T0 >= (1ull << 30)) { bad = (uint32_t)lane < nr; L = 0; }
         if (bad) atomicMax(&stat[S_BADREAD], ~(unsigned long long)(r0 + lane));        // corrupt offsets: report, never loop on them
         // every vector of a validated read lies inside [0, total_rounded): no bounds checks on the loads below
@@ -365,7 +366,7 @@ void k_scan_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(acc), 63);
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(nab, (unsigned long long)(tot & 0xFFFFu) | ((unsigned long long)(tot >> 16) << 32));
-        unsigned long long gA = __builtin_amdgcn_readfirstlane((uint32_t)base), gB = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        unsigned long long gA = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base), gB = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
         // Pass 2: positions inside the reservation, entries written
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {

@@ -288,6 +288,30 @@ def test_config5_visium_scale_whitelist_and_thr2_graph(world):
     assert len(got) == len(want) and (got == want).all()
 
 
+def test_offsets_across_the_32_bit_boundaries():
+    """The scan kernel addresses a task's vectors relative to its first one and rebuilds 64-bit offsets from 32-bit halves
+    (readfirstlane, DPP): the same reads placed so that their offsets straddle 2^31, 2^32 and 2^33 give the same records."""
+    dev = torch.device("cuda", 0)
+    wl = synth.make_whitelist(1000)
+    b, o = synth.make_reads(3000, wl, seed=3)
+    b, o = b.to(dev), o.to(dev)
+    n, tot = len(o) - 1, int(o[-1])
+    ctx = _native.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    want = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    ctx.extract_batch_dev(b, o, n, tot, 12, want)
+    assert ctx.extract_status()[0] == 0
+    for shift in ((1 << 31) - 1000003, (1 << 31) + 17, (1 << 32) - 999, (1 << 32) + 5000, (1 << 33) - 1000000):
+        big = torch.full((shift + tot + 64,), 65, dtype=torch.uint8, device=dev)
+        big[shift:shift + tot] = b[:tot]
+        got = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+        ctx.extract_batch_dev(big, (o.to(torch.int64) + shift).contiguous(), n, shift + tot, 12, got)
+        rc, bad, _ = ctx.extract_status()
+        assert rc == 0, (shift, rc, bad)
+        assert bool((got == want).all()), shift
+        del big
+
+
 def test_config4_one_gpu_share_of_100m_reads():
     """BASELINE config 4: 100M reads over 8 GPUs = 12.5M reads (12.6 GB of bases) per GPU in ONE batch.  Records of
     sampled ranges must equal what the same reads give when extracted alone (no dependence on batch size, queue
