@@ -26,11 +26,13 @@ NONE_IDX = 0xFFFFFFFF
 
 E_ARG, E_HIP, E_NOMEM, E_CAPACITY, E_BADBASE, E_FORMAT = -1, -2, -3, -4, -5, -6
 SLOTS = 4
+STRAND_RULE_DEFAULT, STRAND_RULE_NO_POLYA = 0, 1
 
 EXPORTS = [
     "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_set_stream", "bdg_synchronize", "bdg_set_overlap",
     "bdg_profile_enable", "bdg_profile_only", "bdg_profile_reset", "bdg_profile_read",
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
+    "bdg_extract_set_strand_rule",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
     "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host",
@@ -90,6 +92,7 @@ def load():
     L.bdg_extract_status.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.bdg_extract_counters.argtypes = [vp, C.POINTER(u64)]
     L.bdg_extract_set_queue_capacity.argtypes = [vp, u64]
+    L.bdg_extract_set_strand_rule.argtypes = [vp, C.c_int]
     L.bdg_nearest16.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp, vp]
     L.bdg_whitelist_load.argtypes = [vp, vp, u32]
     L.bdg_nearest16_dev.argtypes = [vp, vp, u32, u32, vp, vp, vp]
@@ -229,6 +232,10 @@ class Context:
     def extract_set_queue_capacity(self, entries_per_segment):
         """entries per segment of the internal candidate queues (0 = automatic); an overflow grows it again"""
         self._check(self.lib.bdg_extract_set_queue_capacity(self.h, entries_per_segment))
+
+    def extract_set_strand_rule(self, rule):
+        """STRAND_RULE_DEFAULT (find_barcode_umi) or STRAND_RULE_NO_POLYA (find_barcode_umi_no_polya) for the launches that follow"""
+        self._check(self.lib.bdg_extract_set_strand_rule(self.h, rule))
 
     def extract_counters(self):
         out = (C.c_uint64 * 8)()

@@ -176,7 +176,7 @@ class TenXBarcodeExtractor:
     def _ctx(self):
         return _native.default_context(self.device, self.instance)
 
-    def extract_records(self, sequences):
+    def extract_records(self, sequences, strand_rule=_native.STRAND_RULE_DEFAULT):
         """list[str] -> structured array of bdg_extract_rec (one device call)."""
         n = len(sequences)
         off = np.zeros(n + 1, dtype=np.uint64)
@@ -186,12 +186,16 @@ class TenXBarcodeExtractor:
             bases = np.frombuffer("".join(sequences).encode("ascii"), dtype=np.uint8)
         except UnicodeEncodeError as e:
             raise KeyError(str(e))
+        ctx = self._ctx()
         try:
-            return self._ctx().extract_batch(bases, off, self.UMI_LEN_10X)
+            ctx.extract_set_strand_rule(strand_rule)
+            return ctx.extract_batch(bases, off, self.UMI_LEN_10X)
         except _native.BadgerHipError as e:
             if e.code == _native.E_BADBASE:
                 raise KeyError(str(e))      # the reference raises KeyError in reverese_complement
             raise
+        finally:
+            ctx.extract_set_strand_rule(_native.STRAND_RULE_DEFAULT)     # the context is shared: leave it as found
 
     def find_barcode_umi_batch(self, read_chunk):
         """read_chunk: list[(read_id, seq)] -> list[TenXBarcodeDetectionResult], input order."""
@@ -200,6 +204,15 @@ class TenXBarcodeExtractor:
 
     def find_barcode_umi(self, read_id, sequence):
         return self.find_barcode_umi_batch([(read_id, sequence)])[0]
+
+    def find_barcode_umi_no_polya_batch(self, read_chunk):
+        """The reference's second strand rule (barcode_callers.py:231-248) over a chunk: the forward result if it is
+        valid, else the reverse one if valid, else the more informative of the two."""
+        recs = self.extract_records([s for _, s in read_chunk], _native.STRAND_RULE_NO_POLYA)
+        return [record_to_result(rid, s, r) for (rid, s), r in zip(read_chunk, recs)]
+
+    def find_barcode_umi_no_polya(self, read_id, sequence):
+        return self.find_barcode_umi_no_polya_batch([(read_id, sequence)])[0]
 
     @staticmethod
     def result_type():

@@ -240,6 +240,14 @@ int bdg_extract_set_queue_capacity(bdg_ctx* ctx, uint64_t entries_per_segment)
     return BDG_OK;
 }
 
+int bdg_extract_set_strand_rule(bdg_ctx* ctx, int rule)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (rule != BDG_STRAND_RULE_DEFAULT && rule != BDG_STRAND_RULE_NO_POLYA) return bdg_fail(ctx, BDG_E_ARG, "unknown strand rule");
+    ctx->x_strand_rule = rule;
+    return BDG_OK;
+}
+
 int bdg_extract_counters(bdg_ctx* ctx, uint64_t out[8])
 {
     if (!ctx || !out) return BDG_E_ARG;

@@ -50,6 +50,7 @@ struct bdg_ctx {
     DevBuf x_counters;   // uint64 [8]
     uint64_t x_hits_cap = 0;
     uint64_t x_hits_cap_fixed = 0;     // bdg_extract_set_queue_capacity (0 = automatic)
+    int x_strand_rule = 0;             // bdg_extract_set_strand_rule
     uint64_t x_hits_cap_launched = 0;  // capacity the last launch ran with
     void* x_counters_host = nullptr;   // pinned mirror
     // host-buffer staging

@@ -1279,7 +1279,7 @@ void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                       const int32_t* __restrict__ polyt,
                       const unsigned long long* __restrict__ keys,
                       const unsigned long long* __restrict__ counters, uint64_t qcap,
-                      uint32_t umi_len, bdg_extract_rec* __restrict__ out)
+                      uint32_t umi_len, int strand_rule, bdg_extract_rec* __restrict__ out)
 {
     const uint64_t r = (uint64_t)blockIdx.x * 256ull + threadIdx.x;
     const bool active = r < n;
@@ -1317,7 +1317,9 @@ void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     const StrandRes v = finalize_strand(bases, total_rounded, rs, L, 1, ptR, krR, ksR, (int)umi_len, active);
     if (!active) return;
     bool use_rev;
-    if (v.valid && f.valid) use_rev = !(f.score > v.score);          // barcode_callers.py:175-176
+    if (strand_rule == BDG_STRAND_RULE_NO_POLYA) use_rev = !f.valid; // find_barcode_umi_no_polya, :234-247: forward if valid, else
+                                                                     // reverse (valid, or neither is: both scores are 0 then, :247)
+    else if (v.valid && f.valid) use_rev = !(f.score > v.score);     // barcode_callers.py:175-176
     else use_rev = v.valid != 0;                                     // :177-179
     const StrandRes c = use_rev ? v : f;
     bdg_extract_rec rec;
@@ -1443,7 +1445,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
         ScopedKernelTimer tm(ctx, "k_finalize_reads");
         hipLaunchKernelGGL(k_finalize_reads, dim3((n + 255) / 256), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
                            static_cast<const int32_t*>(ctx->x_polyt.p),
-                           static_cast<const unsigned long long*>(ctx->x_keys.p), counters, qcap, umi_len, d_out);
+                           static_cast<const unsigned long long*>(ctx->x_keys.p), counters, qcap, umi_len, ctx->x_strand_rule, d_out);
     }
     BDG_HIP_TRY(ctx, hipGetLastError());
     return BDG_OK;

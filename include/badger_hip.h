@@ -137,6 +137,18 @@ int  bdg_extract_status(bdg_ctx* ctx, uint64_t* bad_read, uint64_t* n_windows);
  * 0 = automatic (total_bytes / 48 per queue).  An overflow still grows it.  For callers that must bound the
  * workspace, and for tests of the overflow path. */
 int  bdg_extract_set_queue_capacity(bdg_ctx* ctx, uint64_t entries_per_segment);
+/* Which of the reference's two strand rules picks a read's result from its forward and reverse-complement results:
+ * BDG_STRAND_RULE_DEFAULT    TenXBarcodeExtractor.find_barcode_umi (barcode_callers.py:165-179): both valid -> the higher
+ *                            r1_score, ties to the reverse strand; one valid -> that one; none -> the forward result;
+ * BDG_STRAND_RULE_NO_POLYA   TenXBarcodeExtractor.find_barcode_umi_no_polya (barcode_callers.py:231-248): the forward
+ *                            result if valid, else the reverse one if valid, else the more informative of the two (neither
+ *                            carries a score then, which leaves the reverse result).
+ * Holds for the launches that follow.  The reference's second rule forms the reverse complement only when the forward
+ * result is invalid, so a byte outside 'ACGTN' raises there only then; this library reports BDG_E_BADBASE for every
+ * read holding one, under either rule. */
+#define BDG_STRAND_RULE_DEFAULT  0
+#define BDG_STRAND_RULE_NO_POLYA 1
+int  bdg_extract_set_strand_rule(bdg_ctx* ctx, int rule);
 /* Pipeline statistics of the last extraction (synchronises): out[0] 6-mer hits, [1] clusters aligned
  * (queue A), [2] hits sent to the strict filter (queue B), [3] of those skipped because the
  * relaxed search had already succeeded, [4] filter survivors, [5] hits re-queued from clusters,

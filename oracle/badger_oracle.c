@@ -247,8 +247,8 @@ static int code_of(char c)
     return -1;
 }
 
-/* barcode_callers.py:165-179 find_barcode_umi */
-int orc_extract_read(const char* seq, int len, int umi_len, orc_extract_rec* rec)
+/* barcode_callers.py:165-179 find_barcode_umi (rule 0) and :231-248 find_barcode_umi_no_polya (rule 1) */
+int orc_extract_read_rule(const char* seq, int len, int umi_len, int rule, orc_extract_rec* rec)
 {
     char* rc = (char*)malloc((size_t)len + 1);
     int32_t* hits = (int32_t*)malloc(sizeof(int32_t) * ((size_t)len + 2));
@@ -258,7 +258,11 @@ int orc_extract_read(const char* seq, int len, int umi_len, orc_extract_rec* rec
     extract_strand(seq, len, umi_len, hits, &f);                        /* :166 */
     extract_strand(rc, len, umi_len, hits, &v);                         /* :170-171 */
     int use_rev;
-    if (v.valid && f.valid) use_rev = !(f.r1_score > v.r1_score);       /* :175-176 */
+    if (rule == ORC_RULE_NO_POLYA) {
+        /* :234-237 forward result if valid; :244-245 else reverse if valid; :247 neither is valid: both carry
+         * r1_score 0 (:204-209 build the result without a score), so "forward if more informative" never holds */
+        use_rev = f.valid ? 0 : v.valid ? 1 : !(f.r1_score > v.r1_score);
+    } else if (v.valid && f.valid) use_rev = !(f.r1_score > v.r1_score);   /* :175-176 */
     else if (v.valid) use_rev = 1;                                      /* :177-178 */
     else use_rev = 0;                                                   /* :179 */
     const strand_res* c = use_rev ? &v : &f;
@@ -287,15 +291,26 @@ int orc_extract_read(const char* seq, int len, int umi_len, orc_extract_rec* rec
     return 0;
 }
 
+int orc_extract_read(const char* seq, int len, int umi_len, orc_extract_rec* rec)
+{
+    return orc_extract_read_rule(seq, len, umi_len, ORC_RULE_DEFAULT, rec);
+}
+
 int64_t orc_extract_batch(const uint8_t* bases, const uint64_t* off, uint32_t n,
                           uint32_t umi_len, orc_extract_rec* out, int threads)
+{
+    return orc_extract_batch_rule(bases, off, n, umi_len, ORC_RULE_DEFAULT, out, threads);
+}
+
+int64_t orc_extract_batch_rule(const uint8_t* bases, const uint64_t* off, uint32_t n,
+                               uint32_t umi_len, int rule, orc_extract_rec* out, int threads)
 {
     int64_t bad = 0;
     if (threads < 1) threads = 1;
 #pragma omp parallel for schedule(dynamic, 64) num_threads(threads)
     for (int64_t i = 0; i < (int64_t)n; ++i) {
-        int rcode = orc_extract_read((const char*)bases + off[i], (int)(off[i + 1] - off[i]),
-                                     (int)umi_len, &out[i]);
+        int rcode = orc_extract_read_rule((const char*)bases + off[i], (int)(off[i + 1] - off[i]),
+                                          (int)umi_len, rule, &out[i]);
         if (rcode != 0) {
 #pragma omp critical
             { if (bad == 0 || -(i + 1) > bad) bad = -(i + 1); }

@@ -72,6 +72,15 @@ int  orc_detect_exact_positions(const char* seq, int start, int end,
                                 int32_t out[3]);
 /* barcode_callers.py:165-229 (find_barcode_umi on one read). Returns 0 or -1 (bad base). */
 int  orc_extract_read(const char* seq, int len, int umi_len, orc_extract_rec* rec);
+/* The same with the strand rule chosen: ORC_RULE_DEFAULT = find_barcode_umi (:165-179), ORC_RULE_NO_POLYA =
+ * find_barcode_umi_no_polya (:231-248: forward result if valid, else reverse if valid, else the more informative).
+ * The reference forms the reverse complement only when the forward result is invalid, so there a bad base raises
+ * only then; here it is reported for every read (stricter on invalid input, identical on valid input). */
+#define ORC_RULE_DEFAULT  0
+#define ORC_RULE_NO_POLYA 1
+int  orc_extract_read_rule(const char* seq, int len, int umi_len, int rule, orc_extract_rec* rec);
+int64_t orc_extract_batch_rule(const uint8_t* bases, const uint64_t* off, uint32_t n,
+                               uint32_t umi_len, int rule, orc_extract_rec* out, int threads);
 /* extract_raw_barcodes.py:126-128 over a concatenated batch; OpenMP over reads.
  * Returns 0, or -(index+1) of the first read holding a bad base. */
 int64_t orc_extract_batch(const uint8_t* bases, const uint64_t* off, uint32_t n,

@@ -56,6 +56,10 @@ def lib():
     L.orc_extract_read.restype = C.c_int
     L.orc_extract_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
     L.orc_extract_batch.restype = C.c_int64
+    L.orc_extract_read_rule.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_extract_read_rule.restype = C.c_int
+    L.orc_extract_batch_rule.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_int]
+    L.orc_extract_batch_rule.restype = C.c_int64
     L.orc_rank16.argtypes = [C.c_char_p]
     L.orc_rank16.restype = C.c_uint32
     L.orc_unrank16.argtypes = [C.c_uint32, C.c_char_p]
@@ -125,21 +129,24 @@ def detect_exact_positions(seq, start, end, hits, min_score=0, start_delta=-1, e
     return out[0], out[1], out[2]
 
 
-def extract_read(seq, umi_len=12):
+RULE_DEFAULT, RULE_NO_POLYA = 0, 1          # find_barcode_umi / find_barcode_umi_no_polya
+
+
+def extract_read(seq, umi_len=12, rule=RULE_DEFAULT):
     s = _b(seq)
     rec = np.zeros(1, dtype=REC_DTYPE)
-    if lib().orc_extract_read(s, len(s), umi_len, rec.ctypes.data) != 0:
+    if lib().orc_extract_read_rule(s, len(s), umi_len, rule, rec.ctypes.data) != 0:
         raise KeyError("base outside 'ACGTN '")
     return rec[0]
 
 
-def extract_batch(bases, off, umi_len=12, threads=1):
+def extract_batch(bases, off, umi_len=12, threads=1, rule=RULE_DEFAULT):
     """bases: uint8 array of concatenated ASCII reads; off: uint64[n+1]."""
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     off = np.ascontiguousarray(off, dtype=np.uint64)
     n = len(off) - 1
     out = np.zeros(n, dtype=REC_DTYPE)
-    rc = lib().orc_extract_batch(bases.ctypes.data, off.ctypes.data, n, umi_len, out.ctypes.data, threads)
+    rc = lib().orc_extract_batch_rule(bases.ctypes.data, off.ctypes.data, n, umi_len, rule, out.ctypes.data, threads)
     if rc != 0:
         raise KeyError("read %d holds a base outside 'ACGTN '" % (-rc - 1))
     return out

@@ -54,6 +54,39 @@ def test_extract_golden_rows(ctx, orc, golden_dir):
         assert (recs == want).all(), _diff(recs, want)
 
 
+def test_extract_no_polya_rule(ctx, orc, golden_dir):
+    """bdg_extract_set_strand_rule(NO_POLYA) against the rows the reference's find_barcode_umi_no_polya produced
+    (barcode_callers.py:231-248), against the oracle on a synthetic batch, and through the host mirror's method."""
+    from badger_amd import _native
+    from badger_amd.barcode_extraction.barcode_callers import TenXBarcodeExtractorV3
+    ext = json.load(open(os.path.join(golden_dir, "extract_rows.json")))
+    alt = json.load(open(os.path.join(golden_dir, "extract_rows_no_polya.json")))
+    seqs = [r["seq"] for r in ext["reads"]]
+    bases, off = synth.list_to_reads(seqs)
+    ctx.extract_set_strand_rule(_native.STRAND_RULE_NO_POLYA)
+    try:
+        for umi_len, key, skey in ((12, "row_v3", "r1_score_v3"), (10, "row_v2", "r1_score_v2")):
+            recs = ctx.extract_batch(bases, off, umi_len)
+            for r, a, rec in zip(ext["reads"], alt["reads"], recs):
+                assert _row(r["id"], r["seq"], rec, orc) == a[key], r["id"]
+                assert int(rec["r1_score"]) == a[skey], r["id"]
+        wl = synth.make_whitelist(1000)
+        b, o = synth.make_reads(4000, wl, seed=11, p_sub=0.08, p_ins=0.04, p_del=0.04)
+        b, o = b.numpy(), o.numpy().astype(np.uint64)
+        got = ctx.extract_batch(b, o, 12)
+        want = orc.extract_batch(b, o, 12, threads=8, rule=orc.RULE_NO_POLYA)
+        assert (got == want).all(), _diff(got, want)
+        assert (got != orc.extract_batch(b, o, 12, threads=8)).any()          # the rules do differ on this batch
+    finally:
+        ctx.extract_set_strand_rule(_native.STRAND_RULE_DEFAULT)
+    det = TenXBarcodeExtractorV3()
+    chunk = [(r["id"], r["seq"]) for r in ext["reads"][:60]]
+    for res, a in zip(det.find_barcode_umi_no_polya_batch(chunk), alt["reads"]):
+        assert str(res) == a["row_v3"]
+    assert str(det.find_barcode_umi_no_polya(*chunk[3])) == alt["reads"][3]["row_v3"]
+    assert str(det.find_barcode_umi(*chunk[3])) == ext["reads"][3]["row_v3"]      # the shared context went back to the default rule
+
+
 def test_extract_config1_tsv(ctx, orc, golden_dir):
     seqs, ids = [], []
     with gzip.open(os.path.join(golden_dir, "c1_reads.fa.gz"), "rt") as f:

@@ -109,6 +109,22 @@ def test_extract_rows(golden_dir):
             assert int(rec["r1_score"]) == r[skey], r["id"]
 
 
+def test_extract_rows_no_polya_rule(golden_dir):
+    """find_barcode_umi_no_polya (barcode_callers.py:231-248) on the same reads: rows produced by the reference."""
+    ext = json.load(open(os.path.join(golden_dir, "extract_rows.json")))
+    alt = json.load(open(os.path.join(golden_dir, "extract_rows_no_polya.json")))
+    assert len(alt["reads"]) == len(ext["reads"])
+    differ = 0
+    for umi_len, key, skey in ((12, "row_v3", "r1_score_v3"), (10, "row_v2", "r1_score_v2")):
+        for r, a in zip(ext["reads"], alt["reads"]):
+            assert a["id"] == r["id"] and a[key] != "KeyError"
+            rec = orc.extract_read(r["seq"], umi_len, rule=orc.RULE_NO_POLYA)
+            assert _row(r["id"], r["seq"], rec) == a[key], r["id"]
+            assert int(rec["r1_score"]) == a[skey], r["id"]
+            differ += a[key] != r[key]
+    assert differ >= 10          # the fixture does exercise the difference between the two rules
+
+
 def test_config1_tsv_and_stats(golden_dir):
     seqs, ids = [], []
     with gzip.open(os.path.join(golden_dir, "c1_reads.fa.gz"), "rt") as f:

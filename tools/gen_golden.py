@@ -167,7 +167,34 @@ def edge_case_reads(rng):
     return reads
 
 
+def gen_no_polya():
+    """The reference's second strand rule (TenXBarcodeExtractor.find_barcode_umi_no_polya, barcode_callers.py:231-248:
+    forward result if valid, else reverse if valid, else the more informative one) on the reads of extract_rows.json.
+    Reads whose reverse complement cannot be formed raise KeyError there only when the forward result is invalid; the
+    fixture records the row or the exception's class name."""
+    install_shims()
+    from barcode_extraction import barcode_callers
+    ext = json.load(open(os.path.join(OUT, "extract_rows.json")))
+    d3, d2 = barcode_callers.TenXBarcodeExtractorV3(), barcode_callers.TenXBarcodeExtractorV2()
+    rows = []
+    for r in ext["reads"]:
+        row = {"id": r["id"]}
+        for tag, d in (("v3", d3), ("v2", d2)):
+            try:
+                res = d.find_barcode_umi_no_polya(r["id"], r["seq"])
+                row["row_" + tag] = str(res)
+                row["r1_score_" + tag] = res.r1_score
+            except KeyError:
+                row["row_" + tag] = "KeyError"
+        rows.append(row)
+    json.dump({"of": "extract_rows.json", "reads": rows}, open(os.path.join(OUT, "extract_rows_no_polya.json"), "w"))
+    print("extract_rows_no_polya.json:", len(rows), "reads,",
+          sum(1 for a, b in zip(rows, ext["reads"]) if a["row_v3"] != b["row_v3"]), "rows differ from find_barcode_umi")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--no-polya-only":
+        return gen_no_polya()
     install_shims()
     os.makedirs(OUT, exist_ok=True)
     from badger_amd import synth
@@ -321,6 +348,7 @@ def main():
         with contextlib.redirect_stdout(buf):
             ref_badger.main(argv)
         open(prefix + "_stdout_tail.txt", "w").write(buf.getvalue().strip().split("\n")[-1] + "\n")
+    gen_no_polya()
     print("golden fixtures written to", OUT)
 
 
