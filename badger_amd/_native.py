@@ -29,14 +29,14 @@ SLOTS = 4
 STRAND_RULE_DEFAULT, STRAND_RULE_NO_POLYA = 0, 1
 
 EXPORTS = [
-    "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_set_stream", "bdg_synchronize", "bdg_set_overlap",
+    "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_device_count", "bdg_set_stream", "bdg_synchronize", "bdg_set_overlap",
     "bdg_profile_enable", "bdg_profile_only", "bdg_profile_reset", "bdg_profile_read",
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_extract_set_strand_rule",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
     "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host",
-    "bdg_ingest_open", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error", "bdg_ingest_close", "bdg_format_rows",
+    "bdg_ingest_open", "bdg_ingest_open_mt", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error", "bdg_ingest_close", "bdg_format_rows",
 ]
 
 
@@ -57,6 +57,7 @@ class BadgerHipError(RuntimeError):
 
 
 _LIB = None
+PRELOAD_TORCH = os.environ.get("BADGER_AMD_PRELOAD_TORCH", "1") != "0"
 
 
 def load():
@@ -70,7 +71,9 @@ def load():
     # PyTorch-ROCm bundles its own HIP runtime and two HIP runtimes cannot both open the device: whichever
     # initialises second sees no GPU.  If torch can end up in this process, load it first so that the library's HIP
     # symbols bind to the runtime torch uses (stand-alone C/C++ hosts just link /opt/rocm's).
-    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+    # A process that will never import torch (the stage-1 command line) sets PRELOAD_TORCH = False before the first call
+    # and starts more than a second sooner.
+    if PRELOAD_TORCH and "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
         import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
@@ -80,6 +83,7 @@ def load():
     L.bdg_last_error.argtypes = [vp]
     L.bdg_last_error.restype = C.c_char_p
     L.bdg_version.restype = C.c_char_p
+    L.bdg_device_count.restype = C.c_int
     L.bdg_set_stream.argtypes = [vp, vp]
     L.bdg_synchronize.argtypes = [vp]
     L.bdg_set_overlap.argtypes = [vp, C.c_int]
@@ -109,6 +113,7 @@ def load():
     L.bdg_kept_records.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.bdg_kept_records_to_host.argtypes = [vp, vp, u64]
     L.bdg_ingest_open.argtypes = [C.c_char_p, u32, u32, C.c_int, C.POINTER(vp)]
+    L.bdg_ingest_open_mt.argtypes = [C.c_char_p, u32, u32, C.c_int, u32, C.POINTER(vp)]
     L.bdg_ingest_next.argtypes = [vp, C.POINTER(IngestChunk)]
     L.bdg_ingest_release.argtypes = [vp, u32]
     L.bdg_ingest_error.argtypes = [vp]
@@ -308,10 +313,11 @@ class Ingest:
     """[gzipped] FASTA / FASTQ -> chunks of reads in pinned host memory, parsed by a native background thread
     (bdg_ingest_*).  Iterating yields IngestChunk structures; release(chunk) hands the memory back to the parser."""
 
-    def __init__(self, path, chunk_reads=100000, ring_chunks=4, pinned=True):
+    def __init__(self, path, chunk_reads=100000, ring_chunks=4, pinned=True, inflate_threads=0):
+        """inflate_threads: threads that inflate a BGZF (bgzip) input; 0 = min(8, cores), 1 = zlib's sequential reader"""
         self.lib = load()
         h = C.c_void_p()
-        rc = self.lib.bdg_ingest_open(os.fsencode(path), chunk_reads, ring_chunks, 1 if pinned else 0, C.byref(h))
+        rc = self.lib.bdg_ingest_open_mt(os.fsencode(path), chunk_reads, ring_chunks, 1 if pinned else 0, inflate_threads, C.byref(h))
         if rc != 0:
             raise BadgerHipError(rc, "cannot read %s (unknown extension or unreadable file)" % path)
         self.h = h
@@ -356,6 +362,11 @@ def format_rows(ch, recs):
 
 
 _DEFAULT = {}
+
+
+def device_count():
+    """devices this process may open (no context needed)"""
+    return int(load().bdg_device_count())
 
 
 def default_context(device=0, instance=0):

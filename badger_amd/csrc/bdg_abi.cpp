@@ -101,6 +101,12 @@ extern "C" {
 #endif
 const char* bdg_version(void) { return "badger_hip 0.2 (gfx950) src " BDG_SRC_HASH; }
 
+int bdg_device_count(void)
+{
+    int ndev = 0;
+    return hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 ? ndev : 0;
+}
+
 int bdg_init(int device_id, bdg_ctx** out)
 {
     if (!out) return BDG_E_ARG;

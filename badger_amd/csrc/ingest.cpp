@@ -61,10 +61,193 @@ bool grow(T*& p, size_t& cap, size_t used, size_t want, bool pinned)
     return true;
 }
 
+// ---- BGZF: gzip members of <= 64 KiB that state their own compressed size (the 'BC' extra field, SAM specification
+// section 4.1; what bgzip / htslib write).  gzip.open() in the reference (extract_raw_barcodes.py:86-87) reads them as the
+// multi-member gzip files they are, one core; here a dispatcher thread cuts the file into blocks, a pool inflates them and
+// the parser takes the results in file order.  A member without the field (bgzip output with a plain gzip file appended)
+// is inflated by the dispatcher itself, in sequence, to the end of the file.
+struct BgzfBlock {
+    std::vector<uint8_t> in, out;
+    size_t out_len = 0;
+    int state = 0;                 // 0 free, 1 waiting for a worker, 2 inflated, 3 failed
+};
+
+struct BgzfReader {
+    FILE* f = nullptr;
+    std::vector<BgzfBlock> q;      // ring indexed by block number % size
+    uint64_t issued = 0, claimed = 0, taken = 0;   // blocks queued by the dispatcher / claimed by workers / consumed
+    size_t pos = 0;                // consumer's position inside block `taken`
+    bool eof = false, failed = false, stop = false;
+    std::string err;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread dispatcher;
+    std::vector<std::thread> workers;
+
+    static bool is_bgzf_header(const uint8_t* h, size_t n)
+    {
+        return n >= 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 &&
+               h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+    }
+    void fail(const std::string& m)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) { failed = true; err = m; }
+        eof = true;
+        cv.notify_all();
+    }
+    // slot for the next block, once the consumer has drained it; nullptr when asked to stop
+    BgzfBlock* next_slot()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || issued - taken < q.size(); });
+        return stop ? nullptr : &q[issued % q.size()];
+    }
+    void publish(BgzfBlock* b, int state)
+    {
+        { std::lock_guard<std::mutex> lk(mu); b->state = state; ++issued; }
+        cv.notify_all();
+    }
+    // the rest of the file as ordinary (multi-member) gzip, starting with the `have` bytes already read
+    void sequential_tail(const uint8_t* head, size_t have)
+    {
+        z_stream z; memset(&z, 0, sizeof(z));
+        if (inflateInit2(&z, 15 + 16) != Z_OK) return fail("zlib: inflateInit2 failed");
+        std::vector<uint8_t> in(1u << 18);
+        memcpy(in.data(), head, have);
+        z.next_in = in.data(); z.avail_in = (uInt)have;
+        bool member_open = true;
+        for (;;) {
+            if (z.avail_in == 0) {
+                const size_t got = fread(in.data(), 1, in.size(), f);
+                if (got == 0) {
+                    if (member_open) { inflateEnd(&z); return fail("gzip: unexpected end of file"); }
+                    break;
+                }
+                z.next_in = in.data(); z.avail_in = (uInt)got;
+            }
+            if (!member_open) {                                   // between members: another one, or trailing bytes (ignored, like gzread)
+                if (z.avail_in < 2) {                             // the magic may straddle two reads
+                    uint8_t keep = z.next_in[0];
+                    in[0] = keep;
+                    const size_t got = fread(in.data() + 1, 1, in.size() - 1, f);
+                    z.next_in = in.data(); z.avail_in = (uInt)(got + 1);
+                    if (got == 0) break;
+                }
+                if (z.next_in[0] != 0x1f || z.next_in[1] != 0x8b) break;
+                inflateReset(&z); member_open = true;
+            }
+            BgzfBlock* b = next_slot();
+            if (!b) { inflateEnd(&z); return; }
+            b->out.resize(1u << 16);
+            z.next_out = b->out.data(); z.avail_out = (uInt)b->out.size();
+            const int rc = inflate(&z, Z_NO_FLUSH);
+            if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) { inflateEnd(&z); return fail(std::string("gzip: ") + (z.msg ? z.msg : "corrupt data")); }
+            if (rc == Z_STREAM_END) member_open = false;
+            b->out_len = b->out.size() - z.avail_out;
+            publish(b, 2);
+        }
+        inflateEnd(&z);
+    }
+    void dispatch_loop()
+    {
+        uint8_t h[18];
+        for (;;) {
+            const size_t got = fread(h, 1, sizeof(h), f);
+            if (got == 0) break;                                                   // clean end of file
+            if (got < 2 || h[0] != 0x1f || h[1] != 0x8b) break;                   // trailing bytes behind the last member: ignored
+            if (!is_bgzf_header(h, got)) { sequential_tail(h, got); break; }
+            const size_t total = ((size_t)h[16] | ((size_t)h[17] << 8)) + 1;       // whole member, header and trailer included
+            if (total < 18 + 8) return fail("BGZF: impossible block size");
+            BgzfBlock* b = next_slot();
+            if (!b) return;
+            b->in.resize(total - 18);
+            if (fread(b->in.data(), 1, b->in.size(), f) != b->in.size()) return fail("BGZF: unexpected end of file");
+            publish(b, 1);
+        }
+        { std::lock_guard<std::mutex> lk(mu); eof = true; }
+        cv.notify_all();
+    }
+    void work_loop()
+    {
+        z_stream z; memset(&z, 0, sizeof(z));
+        if (inflateInit2(&z, -15) != Z_OK) return fail("zlib: inflateInit2 failed");
+        for (;;) {
+            BgzfBlock* b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || claimed < issued || (eof && claimed == issued); });
+                if (stop || claimed == issued) break;
+                b = &q[claimed % q.size()];
+                ++claimed;
+                if (b->state != 1) continue;                                       // inflated by the dispatcher already
+            }
+            const size_t n = b->in.size();
+            const uint8_t* t = b->in.data() + n - 8;                               // CRC32, ISIZE
+            const uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+            const uint32_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
+            int state = 2;
+            if (isize > (1u << 16)) state = 3;
+            else {
+                b->out.resize(isize ? isize : 1);
+                inflateReset(&z);
+                z.next_in = b->in.data(); z.avail_in = (uInt)(n - 8);
+                z.next_out = b->out.data(); z.avail_out = isize;
+                const int rc = inflate(&z, Z_FINISH);
+                if (rc != Z_STREAM_END || z.avail_out != 0 || z.avail_in != 0 ||
+                    (uint32_t)crc32(crc32(0L, Z_NULL, 0), b->out.data(), isize) != crc) state = 3;
+                b->out_len = isize;
+            }
+            { std::lock_guard<std::mutex> lk(mu); b->state = state; }
+            cv.notify_all();
+        }
+        inflateEnd(&z);
+    }
+    // like gzread: up to cap bytes, 0 at the end, -1 on a corrupt file
+    int read(char* dst, size_t cap)
+    {
+        size_t done = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        while (done < cap) {
+            cv.wait(lk, [&] { return (taken < issued && q[taken % q.size()].state >= 2) || (eof && taken == issued); });
+            if (taken == issued) break;
+            BgzfBlock& b = q[taken % q.size()];
+            if (b.state == 3) { if (!failed) { failed = true; err = "BGZF: corrupt block (size or checksum)"; } break; }
+            const size_t k = std::min(cap - done, b.out_len - pos);
+            if (k) {
+                lk.unlock();                                   // the block is ours until `taken` moves
+                memcpy(dst + done, b.out.data() + pos, k);
+                lk.lock();
+            }
+            done += k; pos += k;
+            if (pos == b.out_len) { b.state = 0; pos = 0; ++taken; cv.notify_all(); }
+        }
+        if (done == 0 && failed) return -1;
+        return (int)done;
+    }
+    void start(FILE* file, unsigned threads)
+    {
+        f = file;
+        if (threads < 1) threads = 1;
+        q.resize(64 * (size_t)threads);
+        dispatcher = std::thread(&BgzfReader::dispatch_loop, this);
+        for (unsigned i = 0; i < threads; ++i) workers.emplace_back(&BgzfReader::work_loop, this);
+    }
+    ~BgzfReader()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        if (dispatcher.joinable()) dispatcher.join();
+        for (auto& w : workers) if (w.joinable()) w.join();
+        if (f) fclose(f);
+    }
+};
+
 }  // namespace
 
 struct bdg_ingest {
     gzFile gz = nullptr;
+    BgzfReader* bgzf = nullptr;
     int format = 0;             // 0 FASTA, 1 FASTQ
     uint32_t chunk_reads = 100000;
     bool pinned = true;
@@ -82,8 +265,14 @@ struct bdg_ingest {
 
     bool fill()
     {
-        const int got = gzread(gz, buf.data(), (unsigned)buf.size());
-        if (got < 0) { int e = 0; err = std::string("read error: ") + gzerror(gz, &e); failed = true; return false; }
+        int got;
+        if (bgzf) {
+            got = bgzf->read(buf.data(), buf.size());
+            if (got < 0) { err = "read error: " + bgzf->err; failed = true; return false; }
+        } else {
+            got = gzread(gz, buf.data(), (unsigned)buf.size());
+            if (got < 0) { int e = 0; err = std::string("read error: ") + gzerror(gz, &e); failed = true; return false; }
+        }
         bpos = 0; blen = (size_t)got;
         return got > 0;
     }
@@ -199,11 +388,13 @@ void parse_loop(bdg_ingest* g)
                 ok = chunk_begin_read(g, *c, p + 1, len - 1);
                 if (!ok) break;
                 const uint64_t b0 = c->bases_bytes;
-                if (!g->next_line(p, len)) { g->err = "truncated FASTQ record at line " + std::to_string(g->line_no); g->failed = true; break; }
+                // (a read error inside a record keeps its own message: next_line has set `failed` then)
+                auto malformed = [&](const char* what) { if (!g->failed) { g->err = std::string(what) + " at line " + std::to_string(g->line_no); g->failed = true; } };
+                if (!g->next_line(p, len)) { malformed("truncated FASTQ record"); break; }
                 ok = chunk_append_bases(g, *c, p, len);
                 const uint64_t slen = c->bases_bytes - b0;
-                if (!g->next_line(p, len) || len == 0 || p[0] != '+') { g->err = "malformed FASTQ record (no '+' line) at line " + std::to_string(g->line_no); g->failed = true; break; }
-                if (!g->next_line(p, len) || len != slen) { g->err = "malformed FASTQ record (quality length) at line " + std::to_string(g->line_no); g->failed = true; break; }
+                if (!g->next_line(p, len) || len == 0 || p[0] != '+') { malformed("malformed FASTQ record (no '+' line)"); break; }
+                if (!g->next_line(p, len) || len != slen) { malformed("malformed FASTQ record (quality length)"); break; }
                 chunk_end_read(*c);
             }
         }
@@ -233,6 +424,12 @@ extern "C" {
 
 int bdg_ingest_open(const char* path, uint32_t chunk_reads, uint32_t ring_chunks, int pinned, bdg_ingest** out)
 {
+    return bdg_ingest_open_mt(path, chunk_reads, ring_chunks, pinned, 0, out);
+}
+
+int bdg_ingest_open_mt(const char* path, uint32_t chunk_reads, uint32_t ring_chunks, int pinned, uint32_t inflate_threads,
+                       bdg_ingest** out)
+{
     if (!out) return BDG_E_ARG;
     *out = nullptr;
     if (!path || chunk_reads == 0) return BDG_E_ARG;
@@ -243,11 +440,28 @@ int bdg_ingest_open(const char* path, uint32_t chunk_reads, uint32_t ring_chunks
     if (ends_with_ci(name, ".fq") || ends_with_ci(name, ".fastq")) format = 1;
     else if (ends_with_ci(name, ".fa") || ends_with_ci(name, ".fasta")) format = 0;
     else return BDG_E_ARG;                                   // unknown extension (BAM / SAM are the caller's business)
-    gzFile gz = gzopen(path, "rb");                          // plain files are read through unchanged
-    if (!gz) return BDG_E_ARG;
-    gzbuffer(gz, 1u << 20);
+    // BGZF (blocked gzip) is inflated by a pool of threads; anything else goes through zlib's reader, one thread
+    BgzfReader* bgzf = nullptr;
+    gzFile gz = nullptr;
+    if (inflate_threads != 1) {
+        FILE* f = fopen(path, "rb");
+        if (!f) return BDG_E_ARG;
+        uint8_t h[18];
+        const size_t got = fread(h, 1, sizeof(h), f);
+        if (BgzfReader::is_bgzf_header(h, got)) {
+            rewind(f);
+            unsigned t = inflate_threads ? inflate_threads : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+            bgzf = new BgzfReader();
+            bgzf->start(f, t);
+        } else fclose(f);
+    }
+    if (!bgzf) {
+        gz = gzopen(path, "rb");                             // plain files are read through unchanged
+        if (!gz) return BDG_E_ARG;
+        gzbuffer(gz, 1u << 20);
+    }
     bdg_ingest* g = new bdg_ingest();
-    g->gz = gz; g->format = format; g->chunk_reads = chunk_reads; g->pinned = pinned != 0;
+    g->gz = gz; g->bgzf = bgzf; g->format = format; g->chunk_reads = chunk_reads; g->pinned = pinned != 0;
     g->ring.resize(ring_chunks < 2 ? 2 : ring_chunks);
     g->buf.resize(4u << 20);
     g->worker = std::thread(parse_loop, g);
@@ -299,6 +513,7 @@ void bdg_ingest_close(bdg_ingest* g)
         free(c.ids); free(c.id_off);
     }
     if (g->gz) gzclose(g->gz);
+    delete g->bgzf;
     delete g;
 }
 

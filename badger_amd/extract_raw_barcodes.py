@@ -119,15 +119,16 @@ def is_fastx(input_file):
     return ext.lower() in (".fq", ".fastq", ".fa", ".fasta")
 
 
-def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None):
+def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None, inflate_threads=0):
     """file -> native parser thread -> pinned chunks -> GPU(s) -> native row formatter -> on_chunk(rows, recs), in
     chunk order.  Two chunks per device are in flight (bdg_extract_submit / bdg_extract_collect), chunk k on device
     k mod N, so parsing, H2D + kernels and formatting / writing overlap and N devices run concurrently from this one
     thread.  Like the reference's chunk generator (:131-150) a trailing empty chunk is reported when the input ends on
-    a chunk boundary (on_chunk(b"", empty records))."""
+    a chunk boundary (on_chunk(b"", empty records)).  A BGZF (bgzip) input is inflated by inflate_threads threads
+    (0 = min(8, cores)); plain gzip is one sequential stream and stays on one."""
     chunk_size = chunk_size or READ_CHUNK_SIZE
     ng = len(detectors)
-    ing = _native.Ingest(input_file, chunk_size, ring_chunks=2 * ng + 2)
+    ing = _native.Ingest(input_file, chunk_size, ring_chunks=2 * ng + 2, inflate_threads=inflate_threads)
     inflight = deque()
     empty = _native.np.zeros(0, dtype=_native.REC_DTYPE)
 
@@ -263,8 +264,7 @@ class BarcodeCaller:
 def _detectors(mode, gpus):
     gpus = max(1, gpus)
     if gpus > 1:
-        import torch                         # (already loaded by _native; device_count does not initialise the GPU)
-        have = torch.cuda.device_count()
+        have = _native.device_count()
         if gpus > have:
             raise SystemExit("--gpus %d: this node shows %d device(s)" % (gpus, have))
     return [BARCODE_CALLING_MODES[mode](device=g) for g in range(gpus)]
@@ -314,7 +314,7 @@ def process_in_parallel(args):
                     outf.write(rows.decode("ascii"))
                     stats.add_records(recs)
                 merge_stats(stats)
-            run_fastx_pipeline(args.input, detectors, on_chunk)
+            run_fastx_pipeline(args.input, detectors, on_chunk, inflate_threads=args.threads if args.threads > 1 else 0)
         else:
             for k, chunk in enumerate(read_chunks(records)):
                 det = detectors[k % len(detectors)]
@@ -415,6 +415,7 @@ def main(sys_argv):
 
 
 if __name__ == "__main__":
+    _native.PRELOAD_TORCH = False            # nothing on this command line's path imports torch: skip its start-up cost
     try:
         main(sys.argv[1:])
     except SystemExit:

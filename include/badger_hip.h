@@ -91,6 +91,9 @@ int  bdg_init(int device_id, bdg_ctx** out);
 void bdg_free(bdg_ctx* ctx);
 const char* bdg_last_error(bdg_ctx* ctx);     /* ctx-local, valid until the next call; ctx may be NULL */
 const char* bdg_version(void);
+/* Number of devices this process may open (hipGetDeviceCount; 0 when there is none or the runtime fails).  What the
+ * reference's "-t threads" sizing becomes for "--gpus N" (extract_raw_barcodes.py:366, :208-214). */
+int  bdg_device_count(void);
 /* Use `hip_stream` (a hipStream_t) for all later work of this context.  NULL is the device's
  * default (null) stream -- which is what torch.cuda.current_stream().cuda_stream is unless the
  * caller made its own.  Until this is called the context works on a private non-blocking stream.
@@ -193,6 +196,13 @@ typedef struct bdg_ingest_chunk {
     const uint64_t* id_off;       /* n + 1 offsets into ids */
 } bdg_ingest_chunk;
 int  bdg_ingest_open(const char* path, uint32_t chunk_reads, uint32_t ring_chunks, int pinned, bdg_ingest** out);
+/* The same with the number of inflate threads stated.  A BGZF file (blocked gzip as bgzip / htslib write it: members of
+ * <= 64 KiB that carry their compressed size) is cut into its blocks and inflated by that many threads, results taken
+ * in file order; 0 = min(8, cores), 1 = zlib's sequential reader for every input (what gzip.open does in the reference,
+ * extract_raw_barcodes.py:86-87).  Plain gzip and uncompressed files are read by one thread whatever the number.  This
+ * is what the reference's "-t threads" can still buy on the input side. */
+int  bdg_ingest_open_mt(const char* path, uint32_t chunk_reads, uint32_t ring_chunks, int pinned, uint32_t inflate_threads,
+                        bdg_ingest** out);
 /* Blocks until the next chunk is parsed.  The chunk's memory stays untouched until bdg_ingest_release(id); at most
  * ring_chunks - 1 chunks can be held.  BDG_E_FORMAT: malformed record (bdg_ingest_error says where). */
 int  bdg_ingest_next(bdg_ingest* g, bdg_ingest_chunk* out);

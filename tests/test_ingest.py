@@ -103,6 +103,95 @@ def test_fastq_records_and_errors(tmp_path, name):
     ing.close()
 
 
+def _bgzf(data, block=65280, eof_marker=True, level=6):
+    """data as a BGZF file (SAM specification 4.1): gzip members of at most 64 KiB, each with the 'BC' extra field that
+    states the member's size; what bgzip writes."""
+    import struct
+    import zlib
+    out = bytearray()
+    pieces = [data[a:a + block] for a in range(0, len(data), block)] + ([b""] if eof_marker else [])
+    for piece in pieces:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(piece) + co.flush()
+        total = 18 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, total - 1)
+        out += body + struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece))
+    return bytes(out)
+
+
+def _flat(chunks):
+    return [r for c in chunks for r in c]
+
+
+@pytest.mark.parametrize("threads", [0, 1, 2, 5])
+def test_bgzf_input_is_inflated_in_parallel_and_in_order(tmp_path, threads):
+    rng = np.random.default_rng(3)
+    rnd = lambda k: "".join("ACGTN"[i] for i in rng.integers(0, 5, k))
+    text = "".join("@r%d w\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in ((i, rnd(int(rng.integers(0, 4000)))) for i in range(1500)))
+    raw = text.encode()
+    plain = tmp_path / "plain.fastq"
+    plain.write_bytes(raw)
+    want = _flat(_chunks(str(plain), 256))
+    assert len(want) == 1500
+
+    def chunks_of(path, size=256):
+        ing = _native.Ingest(str(path), size, 3, pinned=False, inflate_threads=threads)
+        out = []
+        try:
+            while True:
+                ch = ing.next()
+                if ch.n == 0:
+                    return out
+                off = np.ctypeslib.as_array(C.cast(ch.off, C.POINTER(C.c_uint64)), shape=(ch.n + 1,))
+                idoff = np.ctypeslib.as_array(C.cast(ch.id_off, C.POINTER(C.c_uint64)), shape=(ch.n + 1,))
+                bases = C.string_at(ch.bases, int(ch.total_bytes))
+                ids = C.string_at(ch.ids, int(idoff[-1]))
+                out += [(ids[int(idoff[i]):int(idoff[i + 1])].decode(), bases[int(off[i]):int(off[i + 1])].decode()) for i in range(ch.n)]
+                ing.release(ch)
+        finally:
+            ing.close()
+
+    p = tmp_path / "r.fastq.gz"
+    for block, marker in ((65280, True), (1000, True), (65280, False)):
+        p.write_bytes(_bgzf(raw, block, marker))
+        assert chunks_of(p) == want
+    p.write_bytes(_bgzf(raw[:raw.index(b"@r100 ")], 17))                    # 12,000 tiny blocks
+    assert chunks_of(p) == want[:100]
+    assert list(erb.open_reads(str(p)))[:20] == want[:20]                 # Python's gzip reads the same file as multi-member gzip
+    # a plain gzip member behind BGZF blocks, BGZF behind plain gzip, and trailing bytes that are no gzip member
+    half = raw.index(b"@r700 ")
+    p.write_bytes(_bgzf(raw[:half], eof_marker=False) + gzip.compress(raw[half:]))
+    assert chunks_of(p) == want
+    p.write_bytes(_bgzf(raw[:half], eof_marker=False) + gzip.compress(raw[half:half + 100000]) + gzip.compress(raw[half + 100000:]))
+    assert chunks_of(p) == want
+    p.write_bytes(gzip.compress(raw[:half]) + _bgzf(raw[half:]))
+    assert chunks_of(p) == want
+    p.write_bytes(_bgzf(raw) + b"\0" * 37)
+    assert chunks_of(p) == want
+    # an empty BGZF file (the end marker alone) and the same name without the extension's help
+    p.write_bytes(_bgzf(b""))
+    assert chunks_of(p) == []
+    q = tmp_path / "looks_plain.fastq"
+    q.write_bytes(_bgzf(raw))
+    assert chunks_of(q) == want
+    # damage: a flipped payload byte (checksum), a truncated last block, a block that claims an impossible size
+    good = bytearray(_bgzf(raw))
+    bad = bytearray(good); bad[len(bad) // 2] ^= 0x55
+    p.write_bytes(bytes(bad))
+    with pytest.raises((ValueError, _native.BadgerHipError)):
+        chunks_of(p)
+    p.write_bytes(bytes(good[:len(good) - 40]))
+    with pytest.raises((ValueError, _native.BadgerHipError)):
+        chunks_of(p)
+    bad = bytearray(good); bad[16:18] = b"\x05\x00"
+    p.write_bytes(bytes(bad))
+    if threads == 1:
+        assert chunks_of(p) == want              # zlib's sequential reader never looks at the size field
+    else:
+        with pytest.raises((ValueError, _native.BadgerHipError)):
+            chunks_of(p)
+
+
 def test_unknown_extension_is_refused(tmp_path):
     p = tmp_path / "reads.bam"
     p.write_bytes(b"BAM\1")

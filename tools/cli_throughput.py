@@ -31,13 +31,26 @@ def main():
         for a in range(0, n, 50000):
             f.write("".join("@read_%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in zip(range(a, a + 50000), seqs[a:a + 50000])))
     subprocess.check_call("gzip -1 -k -f %s" % fq, shell=True)
-    sizes = {"fastq": os.path.getsize(fq), "fastq.gz": os.path.getsize(fq + ".gz")}
+    # the same reads as BGZF (what bgzip writes: 64 KiB gzip members that state their size), written here with zlib
+    import struct
+    import zlib
+    bgz = os.path.join(tmp, "cli_reads_bgzf.fastq.gz")
+    with open(fq, "rb") as src, open(bgz, "wb") as dst:
+        while True:
+            piece = src.read(65280)
+            co = zlib.compressobj(1, zlib.DEFLATED, -15)
+            body = co.compress(piece) + co.flush()
+            dst.write(b"\x1f\x8b\x08\x04\0\0\0\0\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(body) + 8 - 1))
+            dst.write(body + struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece)))
+            if not piece:
+                break
+    sizes = {"fastq": os.path.getsize(fq), "fastq.gz": os.path.getsize(fq + ".gz"), "bgzf.fastq.gz": os.path.getsize(bgz)}
     cores = len(os.sched_getaffinity(0))
     recs = orc.extract_batch(bases.numpy(), off.numpy().astype(np.uint64), 12, threads=cores)
     want = "#read_id\tbarcode\tUMI\tBC_score\tvalid_UMI\tstrand\tpolyT_start\tR1_end\n" + \
            "".join(record_to_row("read_%d" % i, s, r) + "\n" for i, (s, r) in enumerate(zip(seqs, recs)))
     print(json.dumps({"prepared_s": round(time.perf_counter() - t0, 1), "reads": n, "bytes": sizes}), flush=True)
-    for path in (fq, fq + ".gz"):
+    for path in (fq, fq + ".gz", bgz):
         # parser alone
         t0 = time.perf_counter()
         ing = _native.Ingest(path, 100000, 4)

@@ -1,0 +1,36 @@
+#!/bin/bash
+# CPU-only: the read ingest (parser thread + BGZF dispatcher / inflate pool, badger_amd/csrc/ingest.cpp) under
+# ThreadSanitizer and under AddressSanitizer + UBSan, on a BGZF file, on a BGZF file with a plain gzip member appended
+# and on a BGZF file with a damaged block, each read to the end twice and closed in mid-file once.
+# GPU sanitizers are not available on the pool; this covers the host threads of the path.
+set -eu
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+T=${TMPDIR:-/tmp}/bdg_sanitize; mkdir -p $T
+python3 - "$ROOT" "$T" <<'PY'
+import gzip, sys
+import numpy as np
+root, t = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root + "/tests"); sys.path.insert(0, root)
+from test_ingest import _bgzf
+rng = np.random.default_rng(3)
+rnd = lambda k: "".join("ACGTN"[i] for i in rng.integers(0, 5, k))
+raw = "".join("@r%d w\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in ((i, rnd(int(rng.integers(0, 4000)))) for i in range(3000))).encode()
+open(t + "/a.fastq.gz", "wb").write(_bgzf(raw, 4000))
+half = raw.index(b"@r1500 ")
+open(t + "/b.fastq.gz", "wb").write(_bgzf(raw[:half], eof_marker=False) + gzip.compress(raw[half:]))
+bad = bytearray(_bgzf(raw)); bad[len(bad) // 2] ^= 0x55
+open(t + "/c.fastq.gz", "wb").write(bytes(bad))
+PY
+FLAGS="-O1 -g -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$ROOT/include -I$ROOT/badger_amd/csrc"
+LIBS="-L/opt/rocm/lib -lamdhip64 -lz -lpthread -Wl,-rpath,/opt/rocm/lib"
+g++ $FLAGS -fsanitize=thread $ROOT/tools/sanitize/ingest_driver.cpp $ROOT/badger_amd/csrc/ingest.cpp -o $T/drv_tsan $LIBS 2>/dev/null
+g++ $FLAGS -fsanitize=address,undefined $ROOT/tools/sanitize/ingest_driver.cpp $ROOT/badger_amd/csrc/ingest.cpp -o $T/drv_asan $LIBS 2>/dev/null
+rc=0
+for f in a b c; do for t in 0 1 3; do
+    for drv in drv_tsan drv_asan; do
+        out=$($T/$drv $T/$f.fastq.gz $t 2>&1) || true
+        if echo "$out" | grep -q "Sanitizer\|runtime error"; then echo "FAIL $drv $f threads=$t"; echo "$out" | head -20; rc=1; fi
+    done
+done; done
+[ $rc = 0 ] && echo "ingest sanitizers: clean (tsan, asan+ubsan; 3 files x 3 thread counts)"
+exit $rc
