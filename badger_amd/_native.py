@@ -29,7 +29,8 @@ SLOTS = 4
 STRAND_RULE_DEFAULT, STRAND_RULE_NO_POLYA = 0, 1
 
 EXPORTS = [
-    "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_device_count", "bdg_set_stream", "bdg_synchronize", "bdg_set_overlap",
+    "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_device_count",
+    "bdg_mem_alloc", "bdg_mem_free", "bdg_mem_to_host", "bdg_set_stream", "bdg_synchronize", "bdg_set_overlap",
     "bdg_profile_enable", "bdg_profile_only", "bdg_profile_reset", "bdg_profile_read",
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_extract_set_strand_rule",
@@ -84,6 +85,9 @@ def load():
     L.bdg_last_error.restype = C.c_char_p
     L.bdg_version.restype = C.c_char_p
     L.bdg_device_count.restype = C.c_int
+    L.bdg_mem_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+    L.bdg_mem_free.argtypes = [vp, vp]
+    L.bdg_mem_to_host.argtypes = [vp, vp, vp, u64]
     L.bdg_set_stream.argtypes = [vp, vp]
     L.bdg_synchronize.argtypes = [vp]
     L.bdg_set_overlap.argtypes = [vp, C.c_int]
@@ -307,6 +311,41 @@ class Context:
         p = d_recs if isinstance(d_recs, int) else d_recs.data_ptr()
         self._check(self.lib.bdg_distinct_dev(self.h, p, n, d_uniq.data_ptr(), d_count.data_ptr(),
                                               d_first.data_ptr(), d_n.data_ptr()))
+
+
+class DeviceArray:
+    """A zero-filled array in the context's device memory (bdg_mem_alloc): what the package's own command lines pass to
+    the *_dev entry points in place of a torch tensor, so that they start without importing torch."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        ctx._check(ctx.lib.bdg_mem_alloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value or 0
+
+    def data_ptr(self):
+        return self.ptr
+
+    def to_host(self, rows=None):
+        """the first `rows` rows (all by default) as a numpy array; waits for the context's stream"""
+        rows = self.shape[0] if rows is None else int(rows)
+        out = np.zeros((rows,) + self.shape[1:], dtype=self.dtype)
+        self.ctx._check(self.ctx.lib.bdg_mem_to_host(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr and self.ctx.h:
+            self.ctx.lib.bdg_mem_free(self.ctx.h, self.ptr)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Ingest:

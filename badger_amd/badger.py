@@ -148,6 +148,7 @@ def main(args):
 
 
 if __name__ == "__main__":
+    _native.PRELOAD_TORCH = False            # this command line allocates through the library (bdg_mem_alloc): no torch start-up
     try:
         main(sys.argv[1:])
     except (SystemExit, KeyboardInterrupt):

@@ -9,6 +9,14 @@ for _c, _v in RANK.items():
     _LUT[ord(_c)] = _v
 
 
+def _pack(codes, length):
+    """rows of 2-bit codes -> ranks (uint64); an OR-reduction of shifted columns (numpy's row sums of many short rows
+    are an order of magnitude slower)"""
+    dt = np.uint32 if length <= 16 else np.uint64
+    sh = (2 * np.arange(length)).astype(dt)
+    return np.bitwise_or.reduce(codes.astype(dt) << sh, axis=1).astype(np.uint64)
+
+
 def rank(seq, length):
     rk = 0
     for i in range(length):
@@ -29,5 +37,20 @@ def rank_many(seqs, length=16):
     if (codes == 255).any():
         bad = seqs[int(np.nonzero((codes == 255).any(axis=1))[0][0])]
         raise KeyError("barcode %r holds a base outside ACGT" % bad)
-    w = (np.uint64(1) << (2 * np.arange(length, dtype=np.uint64)))
-    return (codes.astype(np.uint64) * w).sum(axis=1, dtype=np.uint64)
+    return _pack(codes, length)
+
+
+def rank_valid_many(seqs, length=16):
+    """Ranks of those strings of an iterable that are `length` bases of ACGT (the only ones an unrank() output can equal,
+    reference barcode_graph.py:264 `unrank(...) in barcode_list`); uint64 array, order of the input."""
+    seqs = [s for s in seqs if len(s) == length]
+    if not seqs:
+        return np.zeros(0, dtype=np.uint64)
+    try:
+        raw = np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8)
+    except UnicodeEncodeError:
+        seqs = [s for s in seqs if s.isascii()]
+        raw = np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8)
+    codes = _LUT[raw.reshape(-1, length)]
+    codes = codes[(codes != 255).all(axis=1)]
+    return _pack(codes, length)

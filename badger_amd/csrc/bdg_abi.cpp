@@ -126,6 +126,38 @@ int bdg_init(int device_id, bdg_ctx** out)
     return BDG_OK;
 }
 
+int bdg_mem_alloc(bdg_ctx* ctx, uint64_t bytes, void** d_out)
+{
+    if (!ctx || !d_out) return BDG_E_ARG;
+    *d_out = nullptr;
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return bdg_fail(ctx, BDG_E_NOMEM, "device allocation failed"); }
+    hipError_t e = hipMemsetAsync(p, 0, bytes ? bytes : 1, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(p); return bdg_fail(ctx, BDG_E_HIP, hipGetErrorString(e)); }
+    *d_out = p;
+    return BDG_OK;
+}
+
+int bdg_mem_free(bdg_ctx* ctx, void* d_ptr)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (!d_ptr) return BDG_OK;
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));         // work that still uses the buffer
+    BDG_HIP_TRY(ctx, hipFree(d_ptr));
+    return BDG_OK;
+}
+
+int bdg_mem_to_host(bdg_ctx* ctx, void* dst, const void* d_src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !d_src))) return BDG_E_ARG;
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (bytes) BDG_HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDG_OK;
+}
+
 void bdg_free(bdg_ctx* ctx)
 {
     if (!ctx) return;

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _native
 from .barcode_graph import qgram_threshold
-from .common import RANK, rank, rank_many
+from .common import RANK, rank, rank_many, rank_valid_many
 
 logger = logging.getLogger("BarcodeGraph")
 NONE = np.uint32(0xFFFFFFFF)
@@ -83,23 +83,21 @@ class Stage2:
 
     def count_device(self, ctx):
         """the same from the extraction records the context kept on the device (bdg_distinct_dev)"""
-        import torch
         ptr, n = ctx.kept_records()
-        dev = torch.device("cuda", ctx.device)
         m = max(n, 1)
-        uniq = torch.zeros(m, dtype=torch.int32, device=dev)
-        cnt = torch.zeros(m, dtype=torch.int32, device=dev)
-        first = torch.zeros(m, dtype=torch.int32, device=dev)
-        dn = torch.zeros(2, dtype=torch.int32, device=dev)
+        # device arrays through the library's own allocator (bdg_mem_alloc): the command line runs without torch
+        uniq = _native.DeviceArray(ctx, m, np.uint32)
+        cnt = _native.DeviceArray(ctx, m, np.uint32)
+        first = _native.DeviceArray(ctx, m, np.uint32)
+        dn = _native.DeviceArray(ctx, 2, np.uint32)
         if n:
             ctx.distinct_dev(ptr, n, uniq, cnt, first, dn)
-            ctx.synchronize()
-        nu, nbad = int(dn[0]), int(dn[1])
+        nu, nbad = (int(x) for x in dn.to_host())
         if nbad:
             raise KeyError("%d extracted barcodes hold a base outside ACGT" % nbad)      # reference: rank() raises KeyError
-        self.uniq = uniq[:nu].cpu().numpy().view(np.uint32).copy()
-        self.count = cnt[:nu].cpu().numpy().astype(np.int64)
-        self.first = first[:nu].cpu().numpy().view(np.uint32).astype(np.int64)
+        self.uniq = uniq.to_host(nu)
+        self.count = cnt.to_host(nu).astype(np.int64)
+        self.first = first.to_host(nu).astype(np.int64)
         self._d_uniq = uniq                                    # stays on the device for the edge build
         return nu
 
@@ -111,19 +109,18 @@ class Stage2:
             self.ea = self.eb = np.zeros(0, np.intp)
             return
         if on_device:
-            import torch
-            dev = torch.device("cuda", ctx.device)
             cap = max(1024, 8 * nu)
             while True:
-                d_edges = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
-                d_tot = torch.zeros(1, dtype=torch.int64, device=dev)
+                d_edges = _native.DeviceArray(ctx, (cap, 3), np.uint32)
+                d_tot = _native.DeviceArray(ctx, 1, np.uint64)
                 ctx.graph_edges_dev(self._d_uniq, nu, self.threshold, T, d_edges, cap, d_tot)
-                ctx.synchronize()
-                tot = int(d_tot[0])
+                tot = int(d_tot.to_host()[0])
                 if tot <= cap:
                     break
                 cap = tot
-            e = d_edges[:tot].cpu().numpy().view(np.uint32)
+                d_edges.free()
+            e = d_edges.to_host(tot)
+            d_edges.free()
             a, b = e[:, 0], e[:, 1]
         else:
             e = self._ctx().graph_edges(self.uniq, self.threshold, T)
@@ -144,8 +141,7 @@ class Stage2:
         if true_barcodes:
             tbcs = [rank(bc, bc_len) for bc in true_barcodes]
         elif barcode_list:
-            ok = [s for s in barcode_list if len(s) == bc_len and all(ch in RANK for ch in s)]
-            listed = np.isin(self.uniq, rank_many(ok, bc_len).astype(np.uint32)) if ok else np.zeros(len(self.uniq), bool)
+            listed = np.isin(self.uniq, rank_valid_many(barcode_list, bc_len).astype(np.uint32))
             while i < len(by_count) and cnt[by_count[i]] > cutoff and n <= hi:
                 if listed[by_count[i]]:
                     tbcs.append(int(self.uniq[by_count[i]]))

@@ -94,6 +94,13 @@ const char* bdg_version(void);
 /* Number of devices this process may open (hipGetDeviceCount; 0 when there is none or the runtime fails).  What the
  * reference's "-t threads" sizing becomes for "--gpus N" (extract_raw_barcodes.py:366, :208-214). */
 int  bdg_device_count(void);
+/* Plain device buffers on the context's device, for hosts that bring no allocator of their own (the command lines of
+ * this package run without torch): zero-filled allocation, release, and a copy to host memory that waits for the
+ * context's stream first.  Callers that do have one (torch tensors, hipMalloc of their own) pass those pointers to the
+ * *_dev entry points just the same. */
+int  bdg_mem_alloc(bdg_ctx* ctx, uint64_t bytes, void** d_out);
+int  bdg_mem_free(bdg_ctx* ctx, void* d_ptr);
+int  bdg_mem_to_host(bdg_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
 /* Use `hip_stream` (a hipStream_t) for all later work of this context.  NULL is the device's
  * default (null) stream -- which is what torch.cuda.current_stream().cuda_stream is unless the
  * caller made its own.  Until this is called the context works on a private non-blocking stream.

@@ -238,3 +238,24 @@ def test_stage2_from_fastx_input(tmp_path, golden_dir):
         badger.main(["-r", os.path.join(golden_dir, "c1_reads.fa.gz"), "-d", "tenX_v3",
                      "-l", os.path.join(golden_dir, "c1_whitelist.txt"), "-c", "50", "-o", prefix])
     assert open(prefix + "_output_file.tsv").read() == open(os.path.join(golden_dir, "c1_stage2_output_file.tsv")).read()
+
+
+def test_command_lines_run_without_torch(tmp_path, golden_dir):
+    """Both command lines as a user starts them (python -m ...): same files as the in-process runs above, and torch is
+    never imported on the way (device buffers come from bdg_mem_alloc, the device count from bdg_device_count)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    reads = os.path.join(golden_dir, "c1_reads.fa.gz")
+    tsv = str(tmp_path / "s1.tsv")
+    r = subprocess.run([sys.executable, "-X", "importtime", "-m", "badger_amd.extract_raw_barcodes", "--mode", "tenX_v3", "-i", reads,
+                        "-o", tsv, "-t", "1"], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "| torch" not in r.stderr and "badger_amd._native" in r.stderr
+    assert open(tsv).read() == open(os.path.join(golden_dir, "c1_expected.tsv")).read()
+    prefix = str(tmp_path / "s2")
+    r = subprocess.run([sys.executable, "-X", "importtime", "-m", "badger_amd.badger", "-r", reads, "-d", "tenX_v3",
+                        "-l", os.path.join(golden_dir, "c1_whitelist.txt"), "-c", "50", "-o", prefix], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "| torch" not in r.stderr and "badger_amd.stage2" in r.stderr
+    assert open(prefix + "_output_file.tsv").read() == open(os.path.join(golden_dir, "c1_stage2_output_file.tsv")).read()

@@ -31,6 +31,13 @@ def main():
     subprocess.check_call([sys.executable, "-m", "badger_amd.extract_raw_barcodes", "--mode", "tenX_v3", "-i", fq, "-o", tsv, "-t", "1"],
                           cwd=ROOT, stdout=subprocess.DEVNULL)
     print(json.dumps({"stage": 1, "reads": n, "wall_s": round(time.perf_counter() - t0, 2)}), flush=True)
+    if os.environ.get("S2_PROFILE"):               # where the time of one run goes (cProfile, top of the cumulative list)
+        prof = os.path.join(tmp, "s2.prof")
+        subprocess.check_call([sys.executable, "-m", "cProfile", "-o", prof, "-m", "badger_amd.badger", "-r", fq, "-d", "tenX_v3", "-l", wlf,
+                               "-c", "5000", "-t", os.environ["S2_PROFILE"], "-o", os.path.join(tmp, "s2_prof_out")], cwd=ROOT, stdout=subprocess.DEVNULL)
+        import pstats
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(45)
+        return
     outs = {}
     for thr in ("1", "2"):
         for label, reads in (("tsv", tsv), ("fastq", fq)):
