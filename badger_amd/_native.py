@@ -30,12 +30,12 @@ STRAND_RULE_DEFAULT, STRAND_RULE_NO_POLYA = 0, 1
 
 EXPORTS = [
     "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_device_count",
-    "bdg_mem_alloc", "bdg_mem_free", "bdg_mem_to_host", "bdg_set_stream", "bdg_synchronize", "bdg_set_overlap",
+    "bdg_mem_alloc", "bdg_mem_free", "bdg_mem_to_host", "bdg_mem_from_host", "bdg_set_stream", "bdg_synchronize", "bdg_set_overlap",
     "bdg_profile_enable", "bdg_profile_only", "bdg_profile_reset", "bdg_profile_read",
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_extract_set_strand_rule",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
-    "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev",
+    "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev", "bdg_rows_of_dev",
     "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host",
     "bdg_ingest_open", "bdg_ingest_open_mt", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error", "bdg_ingest_close", "bdg_format_rows",
 ]
@@ -88,6 +88,7 @@ def load():
     L.bdg_mem_alloc.argtypes = [vp, u64, C.POINTER(vp)]
     L.bdg_mem_free.argtypes = [vp, vp]
     L.bdg_mem_to_host.argtypes = [vp, vp, vp, u64]
+    L.bdg_mem_from_host.argtypes = [vp, vp, vp, u64]
     L.bdg_set_stream.argtypes = [vp, vp]
     L.bdg_synchronize.argtypes = [vp]
     L.bdg_set_overlap.argtypes = [vp, C.c_int]
@@ -111,6 +112,7 @@ def load():
     L.bdg_graph_edges_rows_dev.argtypes = [vp, vp, u32, u32, u32, u32, i32, vp, u64, vp]
     L.bdg_graph_set_algo.argtypes = [vp, C.c_int]
     L.bdg_distinct_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+    L.bdg_rows_of_dev.argtypes = [vp, vp, u32, vp, u64, u32, vp]
     L.bdg_extract_submit.argtypes = [vp, u32, vp, vp, u32, u32]
     L.bdg_extract_collect.argtypes = [vp, u32, vp]
     L.bdg_extract_keep_records.argtypes = [vp, C.c_int]
@@ -306,11 +308,19 @@ class Context:
     def graph_set_algo(self, algo):
         self._check(self.lib.bdg_graph_set_algo(self.h, algo))
 
+    def rows_of_dev(self, d_sorted, n, d_values, m, stride_words, d_rows, value_offset_words=0):
+        """d_rows[i] = position of d_values[value_offset_words + i * stride_words] in the ascending d_sorted[0..n), NONE if absent"""
+        self._check(self.lib.bdg_rows_of_dev(self.h, _ptr(d_sorted), n, _ptr(d_values, 4 * value_offset_words), m, stride_words, _ptr(d_rows)))
+
     def distinct_dev(self, d_recs, n, d_uniq, d_count, d_first, d_n):
         """d_recs: a torch tensor of records or a raw device pointer (kept_records())"""
         p = d_recs if isinstance(d_recs, int) else d_recs.data_ptr()
         self._check(self.lib.bdg_distinct_dev(self.h, p, n, d_uniq.data_ptr(), d_count.data_ptr(),
                                               d_first.data_ptr(), d_n.data_ptr()))
+
+
+def _ptr(x, byte_offset=0):
+    return (x if isinstance(x, int) else x.data_ptr()) + byte_offset
 
 
 class DeviceArray:
@@ -335,6 +345,15 @@ class DeviceArray:
         out = np.zeros((rows,) + self.shape[1:], dtype=self.dtype)
         self.ctx._check(self.ctx.lib.bdg_mem_to_host(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
         return out
+
+    @classmethod
+    def from_host(cls, ctx, arr):
+        """a device copy of a numpy array (at least one element is allocated)"""
+        arr = np.ascontiguousarray(arr)
+        d = cls(ctx, arr.shape if arr.size else (1,) + tuple(arr.shape[1:]), arr.dtype)
+        if arr.size:
+            ctx._check(ctx.lib.bdg_mem_from_host(ctx.h, d.ptr, arr.ctypes.data, arr.nbytes))
+        return d
 
     def free(self):
         if self.ptr and self.ctx.h:

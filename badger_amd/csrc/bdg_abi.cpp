@@ -17,6 +17,7 @@ int bdg_whitelist_load_impl(bdg_ctx*, const uint32_t*, uint32_t);
 int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, int, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
 int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*);
 int bdg_distinct_launch(bdg_ctx*, const bdg_extract_rec*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+int bdg_rows_of_launch(bdg_ctx*, const uint32_t*, uint32_t, const uint32_t*, uint64_t, uint32_t, uint32_t*);
 
 static thread_local std::string g_err_noctx;
 
@@ -154,6 +155,15 @@ int bdg_mem_to_host(bdg_ctx* ctx, void* dst, const void* d_src, uint64_t bytes)
     if (!ctx || (bytes && (!dst || !d_src))) return BDG_E_ARG;
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (bytes) BDG_HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDG_OK;
+}
+
+int bdg_mem_from_host(bdg_ctx* ctx, void* d_dst, const void* src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!d_dst || !src))) return BDG_E_ARG;
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (bytes) BDG_HIP_TRY(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return BDG_OK;
 }
@@ -618,6 +628,16 @@ int bdg_distinct_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
     if (!d_n || (n && (!d_recs || !d_uniq || !d_count || !d_first))) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return bdg_distinct_launch(ctx, d_recs, n, d_uniq, d_count, d_first, d_n);
+}
+
+int bdg_rows_of_dev(bdg_ctx* ctx, const uint32_t* d_sorted, uint32_t n, const uint32_t* d_values, uint64_t m,
+                    uint32_t stride_words, uint32_t* d_rows)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (m && (!d_values || !d_rows || (n && !d_sorted) || stride_words == 0)) return bdg_fail(ctx, BDG_E_ARG, "null pointer or zero stride");
+    if (m > (1ull << 39)) return bdg_fail(ctx, BDG_E_ARG, "too many values");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bdg_rows_of_launch(ctx, d_sorted, n, d_values, m, stride_words, d_rows);
 }
 
 }  // extern "C"

@@ -41,7 +41,35 @@ void k_distinct_finish(const unsigned long long* __restrict__ ukeys, const uint3
     first[j] = sorted_vals[uoffsets[j]];
 }
 
+// rows[i] = position of values[i * stride] in the ascending array sorted[0..n), NONE when absent: what turns an edge's
+// two ranks (the reference keys its edges dict by rank, barcode_graph.py:245-247) into indices of the distinct-barcode
+// arrays the stage-2 array code works on.
+__global__ __launch_bounds__(256)
+void k_rows_of(const uint32_t* __restrict__ sorted, uint32_t n, const uint32_t* __restrict__ values, uint64_t m,
+               uint32_t stride, uint32_t* __restrict__ rows)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256ull + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t v = values[i * stride];
+    uint32_t lo = 0, hi = n;                     // first position with sorted[pos] >= v
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (sorted[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    rows[i] = (lo < n && sorted[lo] == v) ? lo : 0xFFFFFFFFu;
+}
+
 }  // namespace
+
+int bdg_rows_of_launch(bdg_ctx* ctx, const uint32_t* d_sorted, uint32_t n, const uint32_t* d_values, uint64_t m,
+                       uint32_t stride, uint32_t* d_rows)
+{
+    if (m == 0) return BDG_OK;
+    ScopedKernelTimer tm(ctx, "k_rows_of");
+    hipLaunchKernelGGL(k_rows_of, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_sorted, n, d_values, m, stride, d_rows);
+    BDG_HIP_TRY(ctx, hipGetLastError());
+    return BDG_OK;
+}
 
 int bdg_distinct_launch(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
                         uint32_t* d_uniq, uint32_t* d_count, uint32_t* d_first, uint32_t* d_n)

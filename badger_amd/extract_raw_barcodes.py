@@ -119,13 +119,25 @@ def is_fastx(input_file):
     return ext.lower() in (".fq", ".fastq", ".fa", ".fasta")
 
 
-def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None, inflate_threads=0):
+def chunk_read_ids(ch):
+    """read ids of an ingest chunk, in order"""
+    import ctypes as C
+    n = ch.n
+    if not n:
+        return []
+    off = _native.np.ctypeslib.as_array(C.cast(ch.id_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).tolist()
+    text = C.string_at(ch.ids, off[n]).decode("ascii", "replace")
+    return [text[off[i]:off[i + 1]] for i in range(n)]
+
+
+def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None, inflate_threads=0, ids_only=False):
     """file -> native parser thread -> pinned chunks -> GPU(s) -> native row formatter -> on_chunk(rows, recs), in
     chunk order.  Two chunks per device are in flight (bdg_extract_submit / bdg_extract_collect), chunk k on device
     k mod N, so parsing, H2D + kernels and formatting / writing overlap and N devices run concurrently from this one
     thread.  Like the reference's chunk generator (:131-150) a trailing empty chunk is reported when the input ends on
     a chunk boundary (on_chunk(b"", empty records)).  A BGZF (bgzip) input is inflated by inflate_threads threads
-    (0 = min(8, cores)); plain gzip is one sequential stream and stays on one."""
+    (0 = min(8, cores)); plain gzip is one sequential stream and stays on one.  ids_only: the caller wants the read ids
+    and the records, not the TSV text (stage 2 from FASTX input): on_chunk(list of ids, recs)."""
     chunk_size = chunk_size or READ_CHUNK_SIZE
     ng = len(detectors)
     ing = _native.Ingest(input_file, chunk_size, ring_chunks=2 * ng + 2, inflate_threads=inflate_threads)
@@ -140,7 +152,7 @@ def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None, inflate
             if e.code == _native.E_BADBASE:
                 raise KeyError(str(e))      # the reference raises KeyError in reverese_complement
             raise
-        rows, _ = _native.format_rows(ch, recs)
+        rows = chunk_read_ids(ch) if ids_only else _native.format_rows(ch, recs)[0]
         ing.release(ch)
         on_chunk(rows, recs)
 
@@ -159,7 +171,7 @@ def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None, inflate
         while inflight:
             finish(inflight.popleft())
         if last_n is None or last_n == chunk_size:
-            on_chunk(b"", empty)
+            on_chunk([] if ids_only else b"", empty)
     finally:
         # chunks still in flight after an error: wait for the GPU before the pinned buffers go away
         for det, slot, ch in inflight:
@@ -246,10 +258,15 @@ class BarcodeCaller:
     def process(self, input_file, skip_secondary=False):
         logger.info("Processing " + input_file)
         if is_fastx(input_file):
+            ids_only = getattr(self.read_handler, "ids_only", False)
+
             def on_chunk(rows, recs):
-                self.read_handler.add_text(rows)
+                if ids_only:
+                    self.read_handler.add_ids(rows)
+                else:
+                    self.read_handler.add_text(rows)
                 self.read_stat.add_records(recs)
-            run_fastx_pipeline(input_file, [self.barcode_detector], on_chunk)
+            run_fastx_pipeline(input_file, [self.barcode_detector], on_chunk, ids_only=ids_only)
         else:
             records = open_reads(input_file, skip_secondary=skip_secondary)     # single-thread BAM path keeps all records (:110-118)
             if records is None:
@@ -369,6 +386,11 @@ class IdListHandler:
     def add_text(self, rows_bytes):
         if rows_bytes:
             self.read_ids.extend(line.split("\t", 1)[0] for line in rows_bytes.decode("ascii").split("\n")[:-1])
+
+    ids_only = True              # FASTX input: the pipeline hands over the ids themselves, no TSV text is formatted
+
+    def add_ids(self, ids):
+        self.read_ids.extend(ids)
 
     def dump_stats(self, read_stat):
         pass

@@ -103,30 +103,34 @@ class Stage2:
 
     # ------------------------------------------------------------------ graph
     def build_edges(self, ctx=None, on_device=False):
+        """edges as pairs of positions in uniq.  The distinct barcodes are on the device already after count_device();
+        after count_host() they are sent there.  Either way the edge list is built there (bdg_graph_edges_dev), its ranks
+        are turned into positions there (bdg_rows_of_dev) and only the positions come back."""
         nu = len(self.uniq)
         T = qgram_threshold(self.threshold, 16)
         if nu < 2:
             self.ea = self.eb = np.zeros(0, np.intp)
             return
-        if on_device:
-            cap = max(1024, 8 * nu)
-            while True:
-                d_edges = _native.DeviceArray(ctx, (cap, 3), np.uint32)
-                d_tot = _native.DeviceArray(ctx, 1, np.uint64)
-                ctx.graph_edges_dev(self._d_uniq, nu, self.threshold, T, d_edges, cap, d_tot)
-                tot = int(d_tot.to_host()[0])
-                if tot <= cap:
-                    break
-                cap = tot
-                d_edges.free()
-            e = d_edges.to_host(tot)
+        ctx = ctx or self._ctx()
+        d_uniq = self._d_uniq if on_device else _native.DeviceArray.from_host(ctx, self.uniq)
+        cap = max(1024, 8 * nu)
+        while True:
+            d_edges = _native.DeviceArray(ctx, (cap, 3), np.uint32)
+            d_tot = _native.DeviceArray(ctx, 1, np.uint64)
+            ctx.graph_edges_dev(d_uniq, nu, self.threshold, T, d_edges, cap, d_tot)
+            tot = int(d_tot.to_host()[0])
+            if tot <= cap:
+                break
+            cap = tot
             d_edges.free()
-            a, b = e[:, 0], e[:, 1]
-        else:
-            e = self._ctx().graph_edges(self.uniq, self.threshold, T)
-            a, b = e["a"], e["b"]
-        self.ea = np.searchsorted(self.uniq, a).astype(np.intp)
-        self.eb = np.searchsorted(self.uniq, b).astype(np.intp)
+        d_rows = _native.DeviceArray(ctx, (2, max(tot, 1)), np.uint32)
+        ctx.rows_of_dev(d_uniq, nu, d_edges, tot, 3, d_rows.data_ptr(), 0)
+        ctx.rows_of_dev(d_uniq, nu, d_edges, tot, 3, d_rows.data_ptr() + 4 * max(tot, 1), 1)
+        rows = d_rows.to_host()
+        for d in (d_edges, d_rows, d_tot) + (() if on_device else (d_uniq,)):
+            d.free()
+        self.ea = rows[0, :tot].astype(np.intp)
+        self.eb = rows[1, :tot].astype(np.intp)
 
     # ------------------------------------------------------------------ centres
     def get_cluster_centers(self, true_barcodes, bc_len, barcode_list, n_cells, interval):
@@ -199,15 +203,15 @@ class Stage2:
         """what badger.py prints at the end (:131-132): len(counts) - len(edges).  The reference's `edges` is a defaultdict:
         besides the barcodes that have an edge it holds a key for every barcode whose neighbours were looked up while
         clustering, i.e. for every centre (observed or not)."""
-        keys = set(np.concatenate([self.ea, self.eb]).tolist())
-        unobserved = 0
-        for c in self.centers:
-            i = int(np.searchsorted(self.uniq, np.uint32(c)))
-            if i < len(self.uniq) and int(self.uniq[i]) == int(c):
-                keys.add(i)
-            else:
-                unobserved += 1
-        return len(self.uniq) - (len(keys) + unobserved)
+        nu = len(self.uniq)
+        key = np.zeros(nu, bool)
+        key[self.ea] = True
+        key[self.eb] = True
+        cr = np.unique(np.array(self.centers, dtype=np.uint32))                # a dict key exists once however often it is looked up
+        pos = np.searchsorted(self.uniq, cr)
+        present = ((pos < nu) & (self.uniq[np.minimum(pos, nu - 1)] == cr)) if nu else np.zeros(len(cr), bool)
+        key[pos[present]] = True
+        return nu - (int(key.sum()) + int((~present).sum()))
 
     # ------------------------------------------------------------------ assignment and output
     def assigned_rank(self, high_sens=False):

@@ -95,12 +95,13 @@ const char* bdg_version(void);
  * reference's "-t threads" sizing becomes for "--gpus N" (extract_raw_barcodes.py:366, :208-214). */
 int  bdg_device_count(void);
 /* Plain device buffers on the context's device, for hosts that bring no allocator of their own (the command lines of
- * this package run without torch): zero-filled allocation, release, and a copy to host memory that waits for the
- * context's stream first.  Callers that do have one (torch tensors, hipMalloc of their own) pass those pointers to the
+ * this package run without torch): zero-filled allocation, release, and copies to and from host memory on the
+ * context's stream (both return when the copy is done).  Callers that do have one (torch tensors, hipMalloc of their own) pass those pointers to the
  * *_dev entry points just the same. */
 int  bdg_mem_alloc(bdg_ctx* ctx, uint64_t bytes, void** d_out);
 int  bdg_mem_free(bdg_ctx* ctx, void* d_ptr);
 int  bdg_mem_to_host(bdg_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
+int  bdg_mem_from_host(bdg_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);   /* returns when src may be reused */
 /* Use `hip_stream` (a hipStream_t) for all later work of this context.  NULL is the device's
  * default (null) stream -- which is what torch.cuda.current_stream().cuda_stream is unless the
  * caller made its own.  Until this is called the context works on a private non-blocking stream.
@@ -274,6 +275,12 @@ int  bdg_graph_set_algo(bdg_ctx* ctx, int algo);
  * Asynchronous. */
 int  bdg_distinct_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
                       uint32_t* d_uniq, uint32_t* d_count, uint32_t* d_first, uint32_t* d_n);
+/* d_rows[i] = position of d_values[i * stride_words] in the ascending array d_sorted[0..n), 0xFFFFFFFF when it is not
+ * there (asynchronous on the context's stream).  With d_values = the edge array of bdg_graph_edges_dev and stride 3 this
+ * turns the edges' ranks (the reference keys `edges` by rank, barcode_graph.py:245-247) into indices of the distinct
+ * barcode arrays of bdg_distinct_dev, which is what clustering on arrays needs (offset 0: a, offset 1: b). */
+int  bdg_rows_of_dev(bdg_ctx* ctx, const uint32_t* d_sorted, uint32_t n, const uint32_t* d_values, uint64_t m,
+                     uint32_t stride_words, uint32_t* d_rows);
 
 #ifdef __cplusplus
 }

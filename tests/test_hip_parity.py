@@ -702,3 +702,34 @@ def test_distinct_dev_small_and_edge_cases(ctx, orc):
     ctx.distinct_dev(d_recs, 0, uniq, cnt, first, dn)
     torch.cuda.synchronize()
     assert int(dn[0]) == 0
+
+
+def test_rows_of_dev_and_device_arrays(ctx):
+    """bdg_rows_of_dev (ranks -> positions in the sorted distinct array, strided values, absent -> NONE) and the
+    library's own device buffers (bdg_mem_alloc / bdg_mem_to_host), against numpy."""
+    rng = np.random.default_rng(21)
+    for n, m in ((0, 5), (1, 7), (1000, 0), (1000, 4097), (200000, 300001)):
+        srt = np.unique(rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32))
+        n_u = len(srt)
+        vals = rng.integers(0, 1 << 32, (m, 3), dtype=np.uint64).astype(np.uint32)
+        if n_u and m:
+            take = rng.random(m) < 0.7
+            vals[take, 0] = srt[rng.integers(0, n_u, int(take.sum()))]
+            vals[:, 1] = srt[rng.integers(0, n_u, m)]
+            vals[0, 0], vals[m - 1, 1] = srt[0], srt[-1]
+        d_srt = _native.DeviceArray.from_host(ctx, srt)
+        d_vals = _native.DeviceArray.from_host(ctx, vals)
+        d_rows = _native.DeviceArray(ctx, (2, max(m, 1)), np.uint32)
+        assert (d_rows.to_host() == 0).all()                                   # allocations arrive zero-filled
+        ctx.rows_of_dev(d_srt, n_u, d_vals, m, 3, d_rows.data_ptr(), 0)
+        ctx.rows_of_dev(d_srt, n_u, d_vals, m, 3, d_rows.data_ptr() + 4 * max(m, 1), 1)
+        got = d_rows.to_host()
+        for col in (0, 1):
+            v = vals[:, col]
+            pos = np.searchsorted(srt, v)
+            hit = (pos < n_u) & (srt[np.minimum(pos, max(n_u - 1, 0))] == v) if n_u else np.zeros(m, bool)
+            want = np.where(hit, pos, 0xFFFFFFFF).astype(np.uint32)
+            assert (got[col, :m] == want).all(), (n, m, col)
+        assert (d_vals.to_host(min(m, 5)) == vals[:5]).all()
+        for d in (d_srt, d_vals, d_rows):
+            d.free()
