@@ -17,6 +17,9 @@ before this process has touched a GPU, and exits with the child's code.
 `--config 3` / `--config 5` time the other GPU configurations of BASELINE.json instead (K3 graph edges over 500K
 distinct barcodes at threshold 1 / 2) and print a line of the same shape with their own unit and roofline block.
 
+Before the W warm-up steps the step runs untimed for a quarter of a second (`config.clock_ramp`; `--no-ramp` skips it): a
+step lasts a millisecond, and a handful of warm-up steps is over before the GPU has left its idle clocks.
+
 After the timed region the run is checked: the library's status word (queue overflow, bad base) and a sample of the
 final records and calls against the CPU oracle; a mismatch exits non-zero and prints no line.
 """
@@ -181,6 +184,22 @@ def observed_barcodes(n_distinct, wl, seed=3):
     return np.sort(out[:n_distinct])
 
 
+RAMP_S = 0.25
+
+
+def clock_ramp(step, dev, seconds=RAMP_S):
+    """Untimed steps for a fixed wall time before the W warm-up steps.  A step of this workload takes about a millisecond,
+    so W = 2..5 warm-up steps are over before the GPU has left its idle clocks (measured: the first timed steps of a cold
+    run are 3-5 % slower than the steady state a batch pipeline runs in).  Returns the number of steps it ran."""
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize(dev)
+        k += 8
+    return k
+
+
 def bench_graph(args, rank, world, dev, local_dev):
     """BASELINE configs 3 / 5 (graph part): K3 over 500K distinct barcodes, thr 1 (neighbourhood probes) or thr 2
     (q-gram join).  Rows shard over ranks in row blocks (every rank holds the whole sorted array), no collective."""
@@ -201,6 +220,7 @@ def bench_graph(args, rank, world, dev, local_dev):
     def step():
         ctx.graph_edges_rows_dev(d_ranks, n, lo, hi, thr, T, d_edges, cap, d_n)
 
+    ramp_steps = clock_ramp(step, dev) if not args.no_ramp else 0
     for _ in range(max(1, args.warmup)):
         step()
     ctx.profile(True)
@@ -244,7 +264,8 @@ def bench_graph(args, rank, world, dev, local_dev):
             "config": {"workload": "BASELINE config %d: barcode_graph edges, threshold %d, %d distinct observed barcodes (%s)"
                                    % (args.config, thr, n, "neighbourhood probes" if thr == 1 else "q-gram join"),
                        "rows": n, "edges_rank0": ne, "qgram_T": T,
-                       "parallelism": "row blocks per GPU, no collectives"},
+                       "parallelism": "row blocks per GPU, no collectives",
+                       "clock_ramp": "%d untimed steps (%.2f s) before the %d warm-up steps" % (ramp_steps, RAMP_S, args.warmup)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pc["traffic"], "traffic_source": pc["source"],
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": per_launch_ms[dom]},
@@ -268,8 +289,9 @@ def bench_graph(args, rank, world, dev, local_dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-ramp", action="store_true", help="skip the fixed-time untimed steps that bring the GPU off its idle clocks before the warm-up")
     ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU (weak scaling)")
     ap.add_argument("--whitelist", type=int, default=737280)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
@@ -340,6 +362,7 @@ def bench_calls(args, rank, world, dev, local_dev):
     # Warm-up with every kernel timed: it says which kernel dominates.  In the timed region only that kernel carries events
     # (a pair of events per kernel costs the step ~6 % when all eight kernels have one); the per-kernel table of the line
     # comes from a few more steps behind the timed region, all kernels timed again.
+    ramp_steps = clock_ramp(step, dev) if not args.no_ramp else 0
     ctx.profile(True)
     ctx.profile_reset()
     for _ in range(max(1, args.warmup)):
@@ -408,6 +431,7 @@ def bench_calls(args, rank, world, dev, local_dev):
                                    % (n, total_bytes / n, len(wl)),
                        "reads_per_gpu": n, "whitelist": len(wl), "sw_windows_per_step": int(nwin), "pipeline_counts": stats,
                        "parallelism": "reads sharded per GPU, no collectives",
+                       "clock_ramp": "%d untimed steps (%.2f s) before the %d warm-up steps" % (ramp_steps, RAMP_S, args.warmup),
                        "batch_pipelining": "off" if args.no_overlap else "K2 of batch i on a second stream beside K1 of batch i+1 (two record buffers)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pc["traffic"], "traffic_source": pc["source"],
