@@ -15,7 +15,7 @@
 // always runs with full lanes.
 //
 // k_graph_probe (thr = 1): instead of sweeping pairs, every barcode enumerates the 16-mers
-// that can have dmin <= 1 with it and looks them up in the sorted array (binary search);
+// that can have dmin <= 1 with it and looks them up in the sorted array (membership bitmap, then a prefix directory);
 // see graph_probe_candidates() below.
 #include "bdg_common.hpp"
 
@@ -284,30 +284,37 @@ __device__ __forceinline__ bool graph_probe_first(uint32_t a, uint32_t b, int t)
     return true;
 }
 
-__device__ __forceinline__ bool sorted_find(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t key)
+// Is `key` one of the ranks?  A candidate that passed the membership bitmap is looked up through a prefix directory over the
+// same top bits (dir[b] = first row whose rank >> shift is >= b): two round trips to memory (the range, then its one or two
+// rows) where a binary search over the sorted array made about log2(n) dependent ones.
+__device__ __forceinline__ bool dir_find(const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ dir, int shift, uint32_t key)
 {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t v = ranks[mid];
-        if (v < key) lo = mid + 1; else hi = mid;
-    }
-    return lo < n && ranks[lo] == key;
+    const uint32_t b = key >> shift;
+    const uint32_t lo = dir[b], hi = dir[b + 1];
+    bool found = false;
+    for (uint32_t k = lo; k < hi; ++k) found = found || ranks[k] == key;
+    return found;
 }
 
-// membership bitmap over the top `32 - shift` bits of the ranks: most candidates die here on one L2 hit instead of a binary search
+// membership bitmap over the top `32 - shift` bits of the ranks (most candidates die here on one L2 hit) and the directory
+// over the same bits: rows with equal top bits are neighbours in the sorted array, the first of them fills the directory
+// entries since the previous row's bucket
 __global__ __launch_bounds__(256)
-void k_graph_bitmap(const uint32_t* __restrict__ ranks, uint32_t n, int shift, uint32_t* __restrict__ bitmap)
+void k_graph_bitmap(const uint32_t* __restrict__ ranks, uint32_t n, int shift, uint32_t* __restrict__ bitmap, uint32_t* __restrict__ dir)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint32_t b = ranks[i] >> shift;
-    atomicOr(&bitmap[b >> 5], 1u << (b & 31u));
+    const uint32_t nb = 0xFFFFFFFFu >> shift;                                // last bucket
+    const uint32_t first = i ? (ranks[i - 1] >> shift) + 1u : 0u;            // buckets (previous row's, b] start at row i
+    if (i == 0 || first <= b) atomicOr(&bitmap[b >> 5], 1u << (b & 31u));
+    for (uint32_t q = first; q <= b; ++q) dir[q] = i;
+    if (i == n - 1) for (uint32_t q = b + 1u; q <= nb + 1u; ++q) dir[q] = n;
 }
 
 __global__ __launch_bounds__(256)
 void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_begin, uint32_t row_end, int32_t T,
-                   const uint32_t* __restrict__ bitmap, int shift,
+                   const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ dir, int shift,
                    bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges)
 {
     __shared__ EdgeStage s_edges[4];
@@ -323,7 +330,7 @@ void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
     for (int t = sub; t < NPROBE; t += 4) {                 // same trip count in every lane
         const uint32_t b = graph_probe_candidate(a, t);
         const uint32_t bb = b >> shift;
-        bool edge = on && b > a && ((bitmap[bb >> 5] >> (bb & 31u)) & 1u) != 0 && sorted_find(ranks, n, b);
+        bool edge = on && b > a && ((bitmap[bb >> 5] >> (bb & 31u)) & 1u) != 0 && dir_find(ranks, dir, shift, b);
         if (edge) edge = graph_probe_first(a, b, t);         // de-duplicate: only the lowest slot producing b emits
         uint32_t d = 0;
         if (edge) { d = dmin3(a, b); edge = d <= 1u && (int32_t)qgram_S(a, b) >= T; }
@@ -664,14 +671,16 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
         if ((rc = bdg_reserve(ctx, ctx->g_sig, bm_bytes))) return rc;       // (the scan path's signature buffer is free here)
         auto* bitmap = static_cast<uint32_t*>(ctx->g_sig.p);
         BDG_HIP_TRY(ctx, hipMemsetAsync(bitmap, 0, bm_bytes, st));
+        if ((rc = bdg_reserve(ctx, ctx->g_qj, sizeof(uint32_t) * ((size_t(1) << bbits) + 2)))) return rc;     // (the q-gram join's workspace is free here)
+        auto* dir = static_cast<uint32_t*>(ctx->g_qj.p);
         {
             ScopedKernelTimer tm(ctx, "k_graph_bitmap");
-            hipLaunchKernelGGL(k_graph_bitmap, dim3((n + 255) / 256), dim3(256), 0, st, d_ranks, n, 32 - bbits, bitmap);
+            hipLaunchKernelGGL(k_graph_bitmap, dim3((n + 255) / 256), dim3(256), 0, st, d_ranks, n, 32 - bbits, bitmap, dir);
         }
         ScopedKernelTimer tm(ctx, "k_graph_probe");
         const uint64_t threads = 4ull * (row_end - row_begin);
         hipLaunchKernelGGL(k_graph_probe, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st, d_ranks, n, row_begin, row_end, qgram_T,
-                           bitmap, 32 - bbits, d_out, cap, reinterpret_cast<unsigned long long*>(d_n_edges));
+                           bitmap, dir, 32 - bbits, d_out, cap, reinterpret_cast<unsigned long long*>(d_n_edges));
         BDG_HIP_TRY(ctx, hipGetLastError());
         return BDG_OK;
     }

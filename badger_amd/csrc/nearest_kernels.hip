@@ -10,7 +10,7 @@
 //          instead of the whitelist: the query itself, its 48 substitution neighbours,
 //          and -- one wave per still-unmatched query -- the 1080 double substitutions
 //          and 1024 delete+insert variants, each looked up in the sorted whitelist
-//          through an L2-resident prefix directory behind a membership bitmap.
+//          through a prefix directory behind a membership bitmap.
 //          Equal-length strings at distance 1 differ by one substitution; at distance 2
 //          by two substitutions or one deletion plus one insertion, so the enumeration
 //          is exhaustive.
@@ -244,7 +244,10 @@ __device__ __forceinline__ uint32_t low_mask(int bases) { return bases >= 16 ? 0
 // pairs to be sorted by variant (the second: WHICH entries own a variant).  Deleting a base inside a run of equal bases
 // gives the same variant as deleting its left neighbour: only the first of a run is emitted (key 0xFFFFFFFF sorts the
 // others to the end).
-constexpr int DV_DIR_SHIFT = 8;                          // directory over the top 22 of the 30 variant bits
+// directory over the top 25 of the 30 variant bits (128 MB): 0.35 entries per bucket.  A wave waits for the longest bucket among
+// its lanes' hits, one round trip to memory per entry: with 22 bits (2.8 entries per bucket) k_nearest_delins took 0.120 ms per
+// 1M calls, with 24 bits 0.089, 25 bits 0.084, 27 bits 0.080
+constexpr int DV_DIR_SHIFT = 5;
 constexpr uint32_t DV_DIR_N = 1u << (30 - DV_DIR_SHIFT);
 
 // The membership map exists four times, each copy addressed by a different permutation of the variant's bits.  The deletion
@@ -333,27 +336,50 @@ void k_nearest_delins(const uint2* __restrict__ list2,
         // variant)?  directory -> the few sorted {variant, rank, caller index} entries of its bucket.  Entries within Hamming
         // distance 2 were pass 1's.  Equal neighbours give equal variants: the first of a run stands for all.
         uint32_t found[4] = { 0, 0, 0, 0 }; int nf = 0; bool overflow = false;
+        auto take = [&](const uint4 en, uint32_t d) __attribute__((always_inline)) {
+            if (en.x != d) return;
+            if (hamming16(en.y ^ qq) <= 2u) return;
+            const uint32_t oo = en.z;
+            const bool dup = (nf > 0 && found[0] == oo) || (nf > 1 && found[1] == oo) ||
+                             (nf > 2 && found[2] == oo) || (nf > 3 && found[3] == oo);
+            if (!dup) {
+                if (nf < 4) { found[0] = nf == 0 ? oo : found[0]; found[1] = nf == 1 ? oo : found[1];
+                              found[2] = nf == 2 ? oo : found[2]; found[3] = nf == 3 ? oo : found[3]; ++nf; }
+                else overflow = true;
+            }
+        };
+        uint32_t dvar[4]; bool hit[4]; bool any_hit = false;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int i = 4 * sub + t;
-            const uint32_t d = variant(qq, t);
+            dvar[t] = variant(qq, t);
             const bool dup_del = i > 0 && (((qq >> (2 * i)) ^ (qq >> (2 * i - 2))) & 3u) == 0u;
-            const bool hit = on && !dup_del && ((word >> (delmap_index(d, sub) & 63u)) & 1ull);
-            if (hit) {
-                const uint32_t lo = dv_dir[d >> DV_DIR_SHIFT], hi = dv_dir[(d >> DV_DIR_SHIFT) + 1];
-                for (uint32_t k = lo; k < hi; ++k) {
-                    const uint4 en = dv_ent[k];
-                    if (en.x != d) continue;
-                    if (hamming16(en.y ^ qq) <= 2u) continue;
-                    const uint32_t oo = en.z;
-                    const bool dup = (nf > 0 && found[0] == oo) || (nf > 1 && found[1] == oo) ||
-                                     (nf > 2 && found[2] == oo) || (nf > 3 && found[3] == oo);
-                    if (!dup) {
-                        if (nf < 4) { found[0] = nf == 0 ? oo : found[0]; found[1] = nf == 1 ? oo : found[1];
-                                      found[2] = nf == 2 ? oo : found[2]; found[3] = nf == 3 ? oo : found[3]; ++nf; }
-                        else overflow = true;
-                    }
-                }
+            hit[t] = on && !dup_del && ((word >> (delmap_index(dvar[t], sub) & 63u)) & 1ull);
+            any_hit = any_hit || hit[t];
+        }
+        if (__ballot(any_hit)) {
+            // The look-ups behind the hits of a lane's four variants run side by side, not one after the other: first every
+            // directory range, then the first DV_AHEAD entries of every range (a directory bucket holds 0.35 entries on
+            // average), all of them unconditional loads (index 0 stands in where there is nothing to load); what a longer
+            // bucket holds beyond that is walked afterwards.
+            constexpr int DV_AHEAD = 3;
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t b = hit[t] ? (dvar[t] >> DV_DIR_SHIFT) : 0u;
+                lo[t] = dv_dir[b]; hi[t] = dv_dir[b + 1];
+                if (!hit[t]) hi[t] = lo[t] = 0u;
+            }
+            uint4 en[4][DV_AHEAD];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < DV_AHEAD; ++e) en[t][e] = dv_ent[lo[t] + (uint32_t)e < hi[t] ? lo[t] + (uint32_t)e : 0u];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int e = 0; e < DV_AHEAD; ++e) if (lo[t] + (uint32_t)e < hi[t]) take(en[t][e], dvar[t]);
+                for (uint32_t k = lo[t] + DV_AHEAD; k < hi[t]; ++k) take(dv_ent[k], dvar[t]);
             }
         }
         // merge inside the query's four lanes: distinct hits, lowest caller index
