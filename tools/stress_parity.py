@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--reads", type=int, default=1000000)
     ap.add_argument("--cases", type=int, default=len(PROFILES))
     ap.add_argument("--n-rate", type=float, default=0.0, help="probability of replacing a base by N")
+    ap.add_argument("--seed-base", type=int, default=100, help="case k uses seed seed-base + k")
+    ap.add_argument("--no-polya-rule", action="store_true", help="the reference's second strand rule (find_barcode_umi_no_polya)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cores = len(os.sched_getaffinity(0))
@@ -36,11 +38,13 @@ def main():
     ctx = _native.Context(0)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     ctx.whitelist_load(wl)
+    rule = 1 if args.no_polya_rule else 0
+    ctx.extract_set_strand_rule(rule)
     bad = 0
     for case in range(args.cases):
         prof = PROFILES[case % len(PROFILES)]
         n = args.reads
-        bases, off = synth.make_reads(n, wl, seed=100 + case, device=dev, **prof)
+        bases, off = synth.make_reads(n, wl, seed=args.seed_base + case, device=dev, **prof)
         total = int(off[-1])
         if args.n_rate > 0:                                   # sprinkle N: exercises the exact per-byte path of the scan at scale
             g = torch.Generator(device=dev)
@@ -56,7 +60,7 @@ def main():
         assert rc == 0
         got = recs.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
         t0 = time.time()
-        want = orc.extract_batch(bases[:total].cpu().numpy(), off.cpu().numpy().astype(np.uint64), 12, threads=cores)
+        want = orc.extract_batch(bases[:total].cpu().numpy(), off.cpu().numpy().astype(np.uint64), 12, threads=cores, rule=rule)
         t_orc = time.time() - t0
         mism = int((got != want).sum())
         # nearest16 on a sample of the extracted barcodes
