@@ -130,15 +130,18 @@ void k_nearest_scan(const uint32_t* __restrict__ q, uint32_t qstride, int recs,
 // deletion variants of the whitelist (one 64-bit word, see delmap_index); only on a hit are the
 // owners of the variant looked up.
 struct PairTables {
-    // Blocks of 16 words (64 bytes, one memory sector): word 0 = entries in the block (<= 15) | next block of the bucket << 8
-    // (0 = none), words 1..15 = ranks.  Block p * 65536 + key is the head of bucket `key` of table p; longer buckets
-    // continue in blocks appended behind the 6 * 65536 heads.  `idx` has the same shape and holds the caller index of each
-    // entry (read only on a hit).  One sector per bucket probe instead of an offset pair plus the entries.
+    // Blocks of 16 words (64 bytes, one memory sector): word 0 = entries in the block (<= 30) | next block of the bucket << 8
+    // (0 = none), words 1..15 = 30 entries of 16 bits: the two 8-bit blocks of the rank that are NOT the bucket's key (the key
+    // spells the other two), lower block in the low byte.  Block p * 65536 + key is the head of bucket `key` of table p; longer
+    // buckets continue in blocks appended behind the 6 * 65536 heads.  `idx` holds the caller index of each entry, 32 words
+    // per block (read only on a hit).  One sector per bucket probe; a bucket of the 737,280-entry list (11 entries on
+    // average) never chains, one of a 4.9 M list (75) takes 3 blocks.
     const uint32_t* rank;
     const uint32_t* idx;
     const uint32_t* delmap;  // 2^30 bits
     uint32_t nw;
 };
+constexpr uint32_t PAIR_BLOCK_ENTRIES = 30;
 
 __device__ __forceinline__ uint32_t pair_key(uint32_t r, int p)
 {
@@ -188,6 +191,10 @@ void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t qstride, int recs,
     if (usable) {
         uint32_t best = 3u, bidx = NONE_IDX, ties = 0u;
         auto scan_bucket = [&](int p) {
+            // the two blocks outside the key: (k, l) = the complement of pair p's (i, j)
+            const int bk = p < 3 ? (p == 0 ? 2 : 1) : (p < 5 ? 0 : 0);
+            const int bl = p < 3 ? (p == 2 ? 2 : 3) : (p == 3 ? 3 : (p == 4 ? 2 : 1));
+            const uint32_t qrest = ((qq >> (8 * bk)) & 0xFFu) | (((qq >> (8 * bl)) & 0xFFu) << 8);
             uint32_t blk = (uint32_t)p * 65536u + pair_key(qq, p);
             do {
                 const uint4* rb = reinterpret_cast<const uint4*>(pt.rank + (size_t)blk * 16u);
@@ -195,13 +202,17 @@ void k_nearest_pairs(const uint32_t* __restrict__ q, uint32_t qstride, int recs,
                 const uint32_t wr[16] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
                 const uint32_t cnt = wr[0] & 0xFFu;
 #pragma unroll
-                for (uint32_t u = 1; u < 16; ++u) {
-                    const uint32_t x = qq ^ wr[u];
-                    const uint32_t h = hamming16(x);
-                    if (u <= cnt && h <= 2u && h <= best && canonical_pair(x) == p) {
-                        const uint32_t wo = pt.idx[(size_t)blk * 16u + u];
-                        if (h < best) { best = h; bidx = wo; ties = 1u; }
-                        else { ties++; bidx = wo < bidx ? wo : bidx; }
+                for (uint32_t u = 0; u < PAIR_BLOCK_ENTRIES; ++u) {
+                    const uint32_t e = (wr[1 + (u >> 1)] >> (16 * (u & 1u))) & 0xFFFFu;
+                    const uint32_t xr = e ^ qrest;                                     // differences in the two blocks outside the key
+                    const uint32_t h = __popc((xr | (xr >> 1)) & 0x5555u);
+                    if (u < cnt && h <= 2u && h <= best) {
+                        const uint32_t x = ((xr & 0xFFu) << (8 * bk)) | ((xr >> 8) << (8 * bl));   // query ^ entry (zero in the key blocks)
+                        if (canonical_pair(x) == p) {
+                            const uint32_t wo = pt.idx[(size_t)blk * 32u + u];
+                            if (h < best) { best = h; bidx = wo; ties = 1u; }
+                            else { ties++; bidx = wo < bidx ? wo : bidx; }
+                        }
                     }
                 }
                 blk = wr[0] >> 8;
@@ -480,27 +491,30 @@ static int build_probe_index(bdg_ctx* ctx)
     const std::vector<uint32_t>& srt = ctx->w_host_sorted;
     const std::vector<uint32_t>& order = ctx->w_host_order;
     int rc;
-    // six block-pair tables as chains of 16-word blocks (see PairTables)
-    std::vector<uint32_t> prank(6ull * 65536ull * 16ull, 0u), pidx(6ull * 65536ull * 16ull, 0u);
+    // six block-pair tables as chains of 16-word blocks of 30 16-bit entries (see PairTables)
+    std::vector<uint32_t> prank(6ull * 65536ull * 16ull, 0u), pidx(6ull * 65536ull * 32ull, 0u);
     for (int p = 0; p < 6; ++p) {
         const int bi = p < 3 ? 0 : (p < 5 ? 1 : 2);
         const int bj = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
+        int bk = -1, bl = -1;
+        for (int b = 0; b < 4; ++b) if (b != bi && b != bj) { if (bk < 0) bk = b; else bl = b; }
         auto key = [&](uint32_t r) { return ((r >> (8 * bi)) & 0xFFu) | (((r >> (8 * bj)) & 0xFFu) << 8); };
+        auto rest = [&](uint32_t r) { return ((r >> (8 * bk)) & 0xFFu) | (((r >> (8 * bl)) & 0xFFu) << 8); };
         std::vector<uint32_t> tail(65536);                 // block currently being filled, per bucket
         for (uint32_t k = 0; k < 65536u; ++k) tail[k] = (uint32_t)p * 65536u + k;
         for (uint32_t i = 0; i < nw; ++i) {                // ascending rank inside a bucket
             const uint32_t k = key(srt[i]);
             uint32_t blk = tail[k];
             uint32_t cnt = prank[(size_t)blk * 16] & 0xFFu;
-            if (cnt == 15u) {                              // chain a fresh block
+            if (cnt == PAIR_BLOCK_ENTRIES) {               // chain a fresh block
                 const uint32_t nb = (uint32_t)(prank.size() / 16);
                 if (nb >= (1u << 24)) return bdg_fail(ctx, BDG_E_ARG, "whitelist too large for the pair tables");
-                prank.resize(prank.size() + 16, 0u); pidx.resize(pidx.size() + 16, 0u);
+                prank.resize(prank.size() + 16, 0u); pidx.resize(pidx.size() + 32, 0u);
                 prank[(size_t)blk * 16] |= nb << 8;
                 tail[k] = blk = nb; cnt = 0;
             }
-            prank[(size_t)blk * 16 + 1 + cnt] = srt[i];
-            pidx[(size_t)blk * 16 + 1 + cnt] = order[i];
+            prank[(size_t)blk * 16 + 1 + (cnt >> 1)] |= rest(srt[i]) << (16 * (cnt & 1u));
+            pidx[(size_t)blk * 32 + cnt] = order[i];
             prank[(size_t)blk * 16] = (prank[(size_t)blk * 16] & ~0xFFu) | (cnt + 1u);
         }
     }
