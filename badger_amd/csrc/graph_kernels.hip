@@ -284,17 +284,9 @@ __device__ __forceinline__ bool graph_probe_first(uint32_t a, uint32_t b, int t)
     return true;
 }
 
-// Is `key` one of the ranks?  A candidate that passed the membership bitmap is looked up through a prefix directory over the
-// same top bits (dir[b] = first row whose rank >> shift is >= b): two round trips to memory (the range, then its one or two
-// rows) where a binary search over the sorted array made about log2(n) dependent ones.
-__device__ __forceinline__ bool dir_find(const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ dir, int shift, uint32_t key)
-{
-    const uint32_t b = key >> shift;
-    const uint32_t lo = dir[b], hi = dir[b + 1];
-    bool found = false;
-    for (uint32_t k = lo; k < hi; ++k) found = found || ranks[k] == key;
-    return found;
-}
+// Is a candidate one of the ranks?  One that passed the membership bitmap is looked up through a prefix directory over the
+// same top bits (dir[b] = first row whose rank >> shift is >= b): the range, then its one or two rows, where a binary search
+// over the sorted array made about log2(n) dependent round trips (k_graph_probe does this for four candidates at a time).
 
 // membership bitmap over the top `32 - shift` bits of the ranks (most candidates die here on one L2 hit) and the directory
 // over the same bits: rows with equal top bits are neighbours in the sorted array, the first of them fills the directory
@@ -327,14 +319,39 @@ void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
     const bool on = i < row_end;
     const uint32_t a = on ? ranks[i] : 0u;
     uint32_t ne = 0;
-    for (int t = sub; t < NPROBE; t += 4) {                 // same trip count in every lane
-        const uint32_t b = graph_probe_candidate(a, t);
-        const uint32_t bb = b >> shift;
-        bool edge = on && b > a && ((bitmap[bb >> 5] >> (bb & 31u)) & 1u) != 0 && dir_find(ranks, dir, shift, b);
-        if (edge) edge = graph_probe_first(a, b, t);         // de-duplicate: only the lowest slot producing b emits
-        uint32_t d = 0;
-        if (edge) { d = dmin3(a, b); edge = d <= 1u && (int32_t)qgram_S(a, b) >= T; }
-        edge_push(edge, a, b, d, s_edges[wv], ne, lane, out, cap, n_edges);
+    // Four candidates per round: their bitmap words are loaded together, then the directory ranges of those that passed,
+    // then the rows; a round costs three round trips to L2 / memory instead of up to twelve.  (NPROBE = 176 = 11 rounds of
+    // 4 candidates for each of the 4 lanes of a barcode: same trip count in every lane.)
+    static_assert(NPROBE % 16 == 0, "rounds of four candidates per lane");
+    for (int t0 = sub; t0 < NPROBE; t0 += 16) {
+        uint32_t b[4], word[4]; bool cand[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            b[u] = graph_probe_candidate(a, t0 + 4 * u);
+            cand[u] = on && b[u] > a;
+            word[u] = bitmap[(cand[u] ? b[u] >> shift : 0u) >> 5];
+        }
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t bb = b[u] >> shift;
+            cand[u] = cand[u] && ((word[u] >> (bb & 31u)) & 1u) != 0;
+            const uint32_t q = cand[u] ? bb : 0u;
+            lo[u] = dir[q]; hi[u] = dir[q + 1];
+            if (!cand[u]) hi[u] = lo[u] = 0u;
+        }
+        uint32_t first_row[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) first_row[u] = ranks[lo[u] < hi[u] ? lo[u] : 0u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bool edge = cand[u] && lo[u] < hi[u] && first_row[u] == b[u];
+            for (uint32_t k = lo[u] + 1u; k < hi[u]; ++k) edge = edge || (cand[u] && ranks[k] == b[u]);   // buckets of several rows: rare
+            if (edge) edge = graph_probe_first(a, b[u], t0 + 4 * u);         // de-duplicate: only the lowest slot producing b emits
+            uint32_t d = 0;
+            if (edge) { d = dmin3(a, b[u]); edge = d <= 1u && (int32_t)qgram_S(a, b[u]) >= T; }
+            edge_push(edge, a, b[u], d, s_edges[wv], ne, lane, out, cap, n_edges);
+        }
     }
     edge_finish(s_edges, ne, s_ecnt, &s_ebase, out, cap, n_edges);
 }
