@@ -8,8 +8,9 @@
 //
 // Launches per batch, no host round trip in between:
 //   k_scan_reads     persistent waves take tasks of 16 reads and stream them as 16-byte vectors, 63 per step, straight from
-//                    the ASCII buffer (through LDS-DMA, two steps ahead): polyT start of both strands (T-windows of the reverse complement are A-windows of
-//                    the read) and every R1 6-mer hit of both strands (7-mer probe table in LDS).  The hits of a vector -
+//                    the ASCII buffer (through LDS-DMA, two steps ahead): polyT start of both strands (T-windows of the
+//                    reverse complement are A-windows of the read) and every R1 6-mer hit of both strands (7-mer probe
+//                    table in LDS).  The hits of a vector -
 //                    or of two neighbouring vectors cut through one adapter copy - form one CLUSTER
 //                    {read, (first hit << 1) | strand, offset mask}; queue A takes clusters whose first hit lies left of
 //                    polyT (relaxed search applies), queue B the other hits one by one.

@@ -15,8 +15,10 @@
 // always runs with full lanes.
 //
 // k_graph_probe (thr = 1): instead of sweeping pairs, every barcode enumerates the 16-mers
-// that can have dmin <= 1 with it and looks them up in the sorted array (membership bitmap, then a prefix directory);
-// see graph_probe_candidates() below.
+// that can have dmin <= 1 with it and looks them up in the sorted array (membership bitmap,
+// then a prefix directory); see graph_probe_candidate() below.
+//
+// k_graph_qjoin (thr >= 2): the device form of the reference's QGramIndex, see further down.
 #include "bdg_common.hpp"
 
 #include <hipcub/hipcub.hpp>

@@ -6,14 +6,13 @@
 //   scan   k_nearest_scan: exhaustive.  One query per lane (its four 16-bit match
 //          vectors live in registers), whitelist tiles staged in LDS and broadcast to
 //          the wave, Myers/Hyyro bit-vector distance per pair.  Any max_ed.
-//   probe  k_nearest_l01 + k_nearest_l2: for max_ed <= 2 the candidates are enumerated
-//          instead of the whitelist: the query itself, its 48 substitution neighbours,
-//          and -- one wave per still-unmatched query -- the 1080 double substitutions
-//          and 1024 delete+insert variants, each looked up in the sorted whitelist
-//          through a prefix directory behind a membership bitmap.
-//          Equal-length strings at distance 1 differ by one substitution; at distance 2
-//          by two substitutions or one deletion plus one insertion, so the enumeration
-//          is exhaustive.
+//   probe  k_nearest_pairs + k_nearest_delins (+ k_nearest_scan for the rare query whose hit list overflows), max_ed <= 2:
+//          instead of the whitelist the places are visited where a neighbour can sit.  An entry within Hamming distance 2
+//          shares two whole 4-base blocks with the query: six tables of buckets keyed by a block pair (pass 1, which
+//          settles distance 0 and 1 and the two-substitution neighbours).  Equal-length strings at distance 2 that are
+//          not two substitutions apart are one deletion plus one insertion apart, i.e. share a 15-base deletion variant:
+//          a 2^30-bit map of the whitelist's variants, then the owners of a variant that is present (pass 2).  Details
+//          at PairTables / delmap_index below.
 #include "bdg_common.hpp"
 
 #include <hipcub/hipcub.hpp>
