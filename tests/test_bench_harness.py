@@ -58,3 +58,20 @@ def test_profile_counters_only_for_the_measured_build(monkeypatch, tmp_path):
     json.dump({"k_scan_reads": 123.0, "_meta": {"lib": lib, "tag": "new"}}, open(prof / "traffic.json", "w"))
     pc = bench.profile_counters("k_scan_reads")
     assert pc["traffic"] == 123.0 and "new" in pc["source"]
+
+
+def test_clock_ramp_runs_whole_groups_of_steps_for_the_stated_time(monkeypatch):
+    """bench.clock_ramp: untimed steps for a fixed wall time before the warm-up, synchronising between groups."""
+    import time
+    import bench
+    calls = {"steps": 0, "syncs": 0}
+    monkeypatch.setattr(bench.torch.cuda, "synchronize", lambda dev=None: calls.__setitem__("syncs", calls["syncs"] + 1))
+
+    def step():
+        calls["steps"] += 1
+        time.sleep(0.001)
+    t0 = time.perf_counter()
+    k = bench.clock_ramp(step, None, seconds=0.05)
+    dt = time.perf_counter() - t0
+    assert k == calls["steps"] and k % 8 == 0 and k >= 8 and calls["syncs"] == k // 8
+    assert 0.05 <= dt < 0.5

@@ -134,3 +134,20 @@ def test_synthetic_workload_is_pinned_and_chunk_invariant():
     assert bool((o == o2).all()) and bool((b == b2).all())
     b3, o3 = synth.make_reads(2000, wl, seed=2)
     assert int(o3[-1]) != int(o[-1])
+
+
+def test_rank_packing_and_the_whitelist_filter():
+    """common._pack (an OR-reduction of shifted 2-bit codes) against rank() for several lengths; rank_valid_many keeps
+    exactly the strings an unrank() output can equal (right length, ACGT only), in input order."""
+    from badger_amd.common import rank, rank_many, rank_valid_many
+    rng = np.random.default_rng(5)
+    for length in (1, 12, 16, 17, 31):
+        seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, length)) for _ in range(300)]
+        want = [rank(s, length) for s in seqs]
+        assert [int(x) for x in rank_many(seqs, length)] == want
+        assert [int(x) for x in rank_valid_many(seqs, length)] == want
+    mixed = ["ACGTACGTACGTACGT", "ACGT", "", "NCGTACGTACGTACGT", "acgtacgtacgtacgt", "TTTTTTTTTTTTTTTT", "ACGTACGTACGTACGé", "ACGTACGTACGTACGTA"]
+    assert [int(x) for x in rank_valid_many(mixed, 16)] == [rank(mixed[0], 16), rank(mixed[5], 16)]
+    assert len(rank_valid_many([], 16)) == 0 and len(rank_valid_many(["AC"], 16)) == 0
+    with pytest.raises(KeyError):
+        rank_many(["ACGTACGTACGTACGN"], 16)
