@@ -259,3 +259,28 @@ def test_command_lines_run_without_torch(tmp_path, golden_dir):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "| torch" not in r.stderr and "badger_amd.stage2" in r.stderr
     assert open(prefix + "_output_file.tsv").read() == open(os.path.join(golden_dir, "c1_stage2_output_file.tsv")).read()
+
+
+def test_stage1_from_bgzf_and_gzip_inputs(tmp_path):
+    """The same 120,000 reads as plain FASTQ, as BGZF (blocks inflated by a pool of threads) and as plain gzip (one zlib
+    stream): the three TSVs are identical, rows as the oracle's records give them; -t sets the inflate threads."""
+    import gzip
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_ingest import _bgzf
+    path, rows, recs = _fastq_of(tmp_path, 120000, 29)
+    raw = open(path, "rb").read()
+    header = "#read_id\tbarcode\tUMI\tBC_score\tvalid_UMI\tstrand\tpolyT_start\tR1_end"
+    want = "\n".join([header] + rows) + "\n"
+    bg = str(tmp_path / "reads_bgzf.fastq.gz")
+    open(bg, "wb").write(_bgzf(raw, level=1))
+    gz = str(tmp_path / "reads_plain.fastq.gz")
+    with gzip.open(gz, "wb", compresslevel=1) as f:
+        f.write(raw)
+    for k, src in enumerate((path, bg, gz)):
+        out = str(tmp_path / ("o%d.tsv" % k))
+        erb.main(["--mode", "tenX_v3", "-i", src, "-o", out, "-t", "1"])
+        assert open(out).read() == want, src
+    out = str(tmp_path / "o_t3.tsv")
+    erb.main(["--mode", "tenX_v3", "-i", bg, "-o", out, "-t", "3"])           # three inflate threads, one header per chunk
+    assert open(out).read() == "\n".join([header] + rows[:100000] + [header] + rows[100000:]) + "\n"
