@@ -24,7 +24,7 @@ FLAG_BC16 = 4
 FLAG_INCOMPLETE = 8
 NONE_IDX = 0xFFFFFFFF
 
-E_ARG, E_HIP, E_NOMEM, E_CAPACITY, E_BADBASE, E_FORMAT = -1, -2, -3, -4, -5, -6
+E_ARG, E_HIP, E_NOMEM, E_CAPACITY, E_BADBASE, E_FORMAT, E_NOSEQ = -1, -2, -3, -4, -5, -6, -7
 SLOTS = 4
 STRAND_RULE_DEFAULT, STRAND_RULE_NO_POLYA = 0, 1
 
@@ -37,7 +37,8 @@ EXPORTS = [
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev", "bdg_rows_of_dev",
     "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host",
-    "bdg_ingest_open", "bdg_ingest_open_mt", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error", "bdg_ingest_close", "bdg_format_rows",
+    "bdg_ingest_open", "bdg_ingest_open_mt", "bdg_ingest_open_ex", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error",
+    "bdg_ingest_reads", "bdg_ingest_close", "bdg_format_rows", "bdg_stage1_run",
 ]
 
 
@@ -49,6 +50,27 @@ class IngestChunk(C.Structure):
     """bdg_ingest_chunk (include/badger_hip.h): one chunk of reads in (pinned) host memory"""
     _fields_ = [("id", C.c_uint32), ("n", C.c_uint32), ("bases", C.c_void_p), ("off", C.c_void_p),
                 ("total_bytes", C.c_uint64), ("ids", C.c_void_p), ("id_off", C.c_void_p)]
+
+
+class IngestOpts(C.Structure):
+    """bdg_ingest_opts"""
+    _fields_ = [("chunk_reads", C.c_uint32), ("ring_chunks", C.c_uint32), ("pinned", C.c_int32), ("threads", C.c_uint32),
+                ("segment_bytes", C.c_uint64), ("skip_secondary", C.c_int32), ("reserved", C.c_uint32)]
+
+
+class Stage1Opts(C.Structure):
+    """bdg_stage1_opts"""
+    _fields_ = [("umi_len", C.c_uint32), ("threads", C.c_uint32), ("format_threads", C.c_uint32), ("header_every", C.c_uint32),
+                ("chunk_reads", C.c_uint32), ("skip_secondary", C.c_int32), ("segment_bytes", C.c_uint64)]
+
+
+class Stage1Result(C.Structure):
+    """bdg_stage1_result"""
+    _fields_ = [("reads", C.c_uint64), ("barcodes", C.c_uint64), ("polyt", C.c_uint64), ("r1", C.c_uint64),
+                ("first_polyt", C.c_uint64), ("first_r1", C.c_uint64), ("bad_read", C.c_uint64),
+                ("chunks", C.c_uint64), ("out_bytes", C.c_uint64), ("seconds_total", C.c_double),
+                ("seconds_wait_parse", C.c_double), ("seconds_submit", C.c_double), ("seconds_wait_gpu", C.c_double),
+                ("seconds_wait_format", C.c_double), ("seconds_format", C.c_double), ("seconds_write", C.c_double)]
 
 
 class BadgerHipError(RuntimeError):
@@ -120,6 +142,10 @@ def load():
     L.bdg_kept_records_to_host.argtypes = [vp, vp, u64]
     L.bdg_ingest_open.argtypes = [C.c_char_p, u32, u32, C.c_int, C.POINTER(vp)]
     L.bdg_ingest_open_mt.argtypes = [C.c_char_p, u32, u32, C.c_int, u32, C.POINTER(vp)]
+    L.bdg_ingest_open_ex.argtypes = [C.c_char_p, C.POINTER(IngestOpts), C.POINTER(vp)]
+    L.bdg_ingest_reads.argtypes = [vp]
+    L.bdg_ingest_reads.restype = C.c_uint64
+    L.bdg_stage1_run.argtypes = [C.POINTER(vp), u32, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Stage1Opts), C.POINTER(Stage1Result)]
     L.bdg_ingest_next.argtypes = [vp, C.POINTER(IngestChunk)]
     L.bdg_ingest_release.argtypes = [vp, u32]
     L.bdg_ingest_error.argtypes = [vp]
@@ -368,14 +394,16 @@ class DeviceArray:
 
 
 class Ingest:
-    """[gzipped] FASTA / FASTQ -> chunks of reads in pinned host memory, parsed by a native background thread
-    (bdg_ingest_*).  Iterating yields IngestChunk structures; release(chunk) hands the memory back to the parser."""
+    """[gzipped / BGZF] FASTA / FASTQ / SAM / BAM -> chunks of reads in pinned host memory, parsed by native threads
+    (bdg_ingest_*).  next() yields IngestChunk structures; release(chunk) hands the memory back to the readers."""
 
-    def __init__(self, path, chunk_reads=100000, ring_chunks=4, pinned=True, inflate_threads=0):
-        """inflate_threads: threads that inflate a BGZF (bgzip) input; 0 = min(8, cores), 1 = zlib's sequential reader"""
+    def __init__(self, path, chunk_reads=100000, ring_chunks=4, pinned=True, inflate_threads=0, segment_bytes=0,
+                 skip_secondary=False):
+        """inflate_threads: reader threads (inflate + parse); 0 = min(12, cores), 1 = one sequential reader"""
         self.lib = load()
         h = C.c_void_p()
-        rc = self.lib.bdg_ingest_open_mt(os.fsencode(path), chunk_reads, ring_chunks, 1 if pinned else 0, inflate_threads, C.byref(h))
+        o = IngestOpts(chunk_reads, ring_chunks, 1 if pinned else 0, inflate_threads, segment_bytes, 1 if skip_secondary else 0, 0)
+        rc = self.lib.bdg_ingest_open_ex(os.fsencode(path), C.byref(o), C.byref(h))
         if rc != 0:
             raise BadgerHipError(rc, "cannot read %s (unknown extension or unreadable file)" % path)
         self.h = h
@@ -385,12 +413,18 @@ class Ingest:
         rc = self.lib.bdg_ingest_next(self.h, C.byref(ch))
         if rc == E_FORMAT:
             raise ValueError(self.lib.bdg_ingest_error(self.h).decode())
+        if rc == E_NOSEQ:
+            raise TypeError(self.lib.bdg_ingest_error(self.h).decode())      # the reference: len(None) in find_barcode_umi
         if rc != 0:
             raise BadgerHipError(rc, self.lib.bdg_ingest_error(self.h).decode())
         return ch
 
     def release(self, ch):
         self.lib.bdg_ingest_release(self.h, ch.id)
+
+    def reads(self):
+        """reads in the chunks made so far"""
+        return int(self.lib.bdg_ingest_reads(self.h))
 
     def close(self):
         if getattr(self, "h", None):
@@ -402,6 +436,41 @@ class Ingest:
             self.close()
         except Exception:
             pass
+
+
+def chunk_reads(ch):
+    """(read id, sequence) pairs of an ingest chunk, in order (tests and small tools; the pipeline never builds strings)"""
+    n = ch.n
+    if not n:
+        return []
+    off = np.ctypeslib.as_array(C.cast(ch.off, C.POINTER(C.c_uint64)), shape=(n + 1,)).tolist()
+    idoff = np.ctypeslib.as_array(C.cast(ch.id_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).tolist()
+    bases = C.string_at(ch.bases + off[0], off[n] - off[0])
+    ids = C.string_at(ch.ids + idoff[0], idoff[n] - idoff[0])
+    return [(ids[idoff[i] - idoff[0]:idoff[i + 1] - idoff[0]].decode("ascii", "replace"),
+             bases[off[i] - off[0]:off[i + 1] - off[0]].decode("ascii", "replace")) for i in range(n)]
+
+
+def stage1_run(contexts, in_path, out_path, header, umi_len, threads=0, header_every=0, skip_secondary=False,
+               chunk_reads=0, segment_bytes=0, format_threads=0):
+    """bdg_stage1_run: input file -> TSV in native threads over the given contexts.  Returns the Stage1Result; raises what
+    the reference raises: KeyError for a base outside ACGTN, ValueError for a malformed file, TypeError for a record
+    without a sequence."""
+    L = load()
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    o = Stage1Opts(umi_len, threads, format_threads, header_every, chunk_reads, 1 if skip_secondary else 0, segment_bytes)
+    res = Stage1Result()
+    rc = L.bdg_stage1_run(arr, len(contexts), os.fsencode(in_path), os.fsencode(out_path), header.encode("ascii"), C.byref(o), C.byref(res))
+    if rc != 0:
+        msg = L.bdg_last_error(contexts[0].h).decode()
+        if rc == E_BADBASE:
+            raise KeyError(msg)
+        if rc == E_FORMAT:
+            raise ValueError(msg)
+        if rc == E_NOSEQ:
+            raise TypeError(msg)
+        raise BadgerHipError(rc, msg)
+    return res
 
 
 def format_rows(ch, recs):

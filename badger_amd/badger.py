@@ -15,8 +15,7 @@ from traceback import print_exc
 
 from . import _native
 from .barcode_graph import BarcodeGraph
-from .extract_raw_barcodes import (BARCODE_CALLING_MODES, extract_barcodes_in_parallel, extract_barcodes_single_thread,
-                                   extract_read_ids, is_fastx)
+from .extract_raw_barcodes import BARCODE_CALLING_MODES, extract_read_ids, is_native_input
 
 logger = logging.getLogger("BarcodeGraph")
 
@@ -115,13 +114,15 @@ def main(args):
         logger.info("Initializing Graph")
         st2.count_host(obs_rank, usable)
         st2.build_edges()
-    elif is_fastx(args.reads):
-        # FASTA / FASTQ: the records of every chunk stay on the device (stage 1 -> stage 2 hand-off without host strings):
-        # counting and the edge build run there, the host only gets the per-read ranks for the output file
+    elif is_native_input(args.reads):
+        # FASTA / FASTQ / SAM / BAM: the records of every chunk stay on the device (stage 1 -> stage 2 hand-off without host
+        # strings): counting and the edge build run there, the host only gets the per-read ranks for the output file.
+        # Like the reference (:112-117) one thread keeps every SAM / BAM record, several skip secondary / supplementary ones.
         import numpy as np
         ctx = _native.default_context(args.device)
         ctx.extract_keep_records(True)
-        read_ids = extract_read_ids(args.reads, args.data_type, device=args.device, skip_secondary=args.threads != 1)
+        read_ids = extract_read_ids(args.reads, args.data_type, device=args.device, skip_secondary=args.threads != 1,
+                                    threads=args.threads if args.threads > 1 else 0)
         logger.info("Initializing Graph")
         st2.count_device(ctx)
         st2.build_edges(ctx, on_device=True)
@@ -130,16 +131,8 @@ def main(args):
         obs_rank = host["bc_rank"].astype(np.uint32)
         ctx.extract_keep_records(False)
     else:
-        # BAM / SAM: the reference's chunk loop (pysam), barcodes as strings
-        if args.threads == 1:
-            read_assignment = extract_barcodes_single_thread(args.reads, args.data_type, device=args.device)
-        else:
-            read_assignment = extract_barcodes_in_parallel(args.reads, args.data_type, args.threads, device=args.device)
-        read_ids = [ra[0] for ra in read_assignment]
-        obs_rank, usable = observed_from_strings([ra[1] for ra in read_assignment], bc_len)
-        logger.info("Initializing Graph")
-        st2.count_host(obs_rank, usable)
-        st2.build_edges()
+        logger.error("Unknown file format " + args.reads)
+        sys.exit(-1)
     logger.info("Graph construction done")
     st2.cluster(true_barcodes, barcode_list, args.n_cells, bc_len, args.interval)
     logger.info("Clustering done")

@@ -1,0 +1,304 @@
+// Stage 1 as one native pipeline, and its row formatter:
+//   bdg_format_rows  one TSV row per read from the device's 32-byte records (TenXBarcodeDetectionResult.__str__,
+//                    barcode_callers.py:40-42,91-93,117-119); the barcode / UMI text is sliced from the chunk's bases, for
+//                    reverse-strand results from the reverse complement (barcode_extraction/common.py:34-39).
+//   bdg_stage1_run   input file -> TSV, everything between in native threads: the readers of ingest.cpp fill pinned chunks,
+//                    this thread submits them to the GPU(s) (bdg_extract_submit / collect, chunk k on context k mod N, two
+//                    in flight per context), a few formatter threads turn records into rows and a writer thread writes them
+//                    in input order.  What the reference spreads over a ProcessPoolExecutor, temporary files and a final
+//                    concatenation (extract_raw_barcodes.py:176-261) - with the two file shapes it produces:
+//                    one header on top (process_single_thread, :162-173), or a header in front of every READ_CHUNK_SIZE
+//                    reads plus one for the trailing, possibly empty chunk (process_in_parallel, :131-159,243-246).
+#include "bdg_common.hpp"
+
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+inline char comp_base(char c)
+{
+    switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return c; }   // N -> N
+}
+
+inline char* put_int(char* o, int v)
+{
+    char t[16]; int k = 0;
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *o++ = '-';
+    while (k) *o++ = t[--k];
+    return o;
+}
+
+struct RowStats { uint64_t reads = 0, bc = 0, pt = 0, r1 = 0, first_pt = ~0ull, first_r1 = ~0ull; };
+
+// upper bound of the text of a chunk's rows (+ the headers that fall inside it)
+uint64_t rows_bound(const bdg_ingest_chunk* ch, const bdg_extract_rec* recs, uint64_t g0, uint32_t header_every, size_t header_len)
+{
+    uint64_t need = 0;
+    for (uint32_t i = 0; i < ch->n; ++i) {
+        const uint64_t L = ch->off[i + 1] - ch->off[i];
+        need += (ch->id_off[i + 1] - ch->id_off[i]) + 64 + (recs[i].valid ? 16 + std::min<uint64_t>(L, (uint64_t)std::max(0, recs[i].umi_end - recs[i].umi_start)) : 2);
+    }
+    if (header_every) need += (ch->n / header_every + 2) * (header_len + 1);
+    (void)g0;
+    return need;
+}
+
+// rows of a chunk whose first read is read g0 of the input; header_every > 0: the header line goes in front of every read
+// whose index is a multiple of it
+char* write_rows(const bdg_ingest_chunk* ch, const bdg_extract_rec* recs, char* o, uint64_t g0, uint32_t header_every,
+                 const char* header, size_t header_len, RowStats& st)
+{
+    for (uint32_t i = 0; i < ch->n; ++i) {
+        if (header_every && (g0 + i) % header_every == 0) { memcpy(o, header, header_len); o += header_len; *o++ = '\n'; }
+        const bdg_extract_rec& r = recs[i];
+        const uint8_t* seq = ch->bases + ch->off[i];
+        const int64_t L = (int64_t)(ch->off[i + 1] - ch->off[i]);
+        const size_t idl = (size_t)(ch->id_off[i + 1] - ch->id_off[i]);
+        memcpy(o, ch->ids + ch->id_off[i], idl); o += idl;
+        *o++ = '\t';
+        const bool rev = (r.flags & BDG_FLAG_REV) != 0;
+        auto slice = [&](int64_t a, int64_t b) {                       // Python slice s[a:b] of the strand's text (a, b >= 0)
+            a = std::min<int64_t>(std::max<int64_t>(a, 0), L); b = std::min<int64_t>(std::max<int64_t>(b, 0), L);
+            if (rev) for (int64_t x = a; x < b; ++x) *o++ = comp_base((char)seq[L - 1 - x]);
+            else if (b > a) { memcpy(o, seq + a, (size_t)(b - a)); o += b - a; }
+        };
+        if (r.valid) {
+            slice(r.bc_start, (int64_t)r.bc_start + 16); *o++ = '\t';
+            slice(r.umi_start, r.umi_end);
+            memcpy(o, "\t0\tFalse\t", 9); o += 9;
+            ++st.bc;
+        } else {
+            memcpy(o, "*\t*\t-1\tFalse\t", 13); o += 13;
+        }
+        *o++ = r.strand > 0 ? '+' : (r.strand < 0 ? '-' : '.');
+        *o++ = '\t';
+        o = put_int(o, r.polyT); *o++ = '\t';
+        o = put_int(o, r.valid ? r.r1_end : -1);
+        *o++ = '\n';
+        if (r.polyT != -1) { ++st.pt; if (st.first_pt == ~0ull) st.first_pt = g0 + i; }
+        if (r.valid && r.r1_end != -1) { ++st.r1; if (st.first_r1 == ~0ull) st.first_r1 = g0 + i; }
+    }
+    st.reads += ch->n;
+    return o;
+}
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Job {
+    uint64_t seq = 0, g0 = 0;
+    bdg_ingest_chunk ch;
+    bdg_ctx* ctx = nullptr; uint32_t slot = 0;
+    std::vector<bdg_extract_rec> recs;
+    std::vector<char> text; size_t text_len = 0;
+    RowStats st;
+};
+
+struct Pipeline {
+    bdg_ingest* ing = nullptr;
+    int fd = -1;
+    std::string header;
+    uint32_t header_every = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job*> to_format;
+    std::map<uint64_t, Job*> formatted;
+    uint64_t next_write = 0, outstanding = 0;
+    bool closing = false, write_failed = false;
+    RowStats total;
+    double t_format = 0, t_write = 0;
+    uint64_t out_bytes = 0;
+
+    void format_loop()
+    {
+        for (;;) {
+            Job* j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return closing || !to_format.empty(); });
+                if (to_format.empty()) return;
+                j = to_format.front(); to_format.pop_front();
+            }
+            const double t0 = now_s();
+            j->text.resize((size_t)rows_bound(&j->ch, j->recs.data(), j->g0, header_every, header.size()));
+            char* e = write_rows(&j->ch, j->recs.data(), j->text.data(), j->g0, header_every, header.data(), header.size(), j->st);
+            j->text_len = (size_t)(e - j->text.data());
+            bdg_ingest_release(ing, j->ch.id);
+            std::vector<bdg_extract_rec>().swap(j->recs);
+            const double dt = now_s() - t0;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                formatted[j->seq] = j;
+                --outstanding;
+                t_format += dt;
+            }
+            cv.notify_all();
+        }
+    }
+    void write_loop()
+    {
+        for (;;) {
+            Job* j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return (closing && to_format.empty() && outstanding == 0 && formatted.empty()) || formatted.count(next_write); });
+                auto it = formatted.find(next_write);
+                if (it == formatted.end()) return;
+                j = it->second; formatted.erase(it); ++next_write;
+            }
+            const double t0 = now_s();
+            const char* p = j->text.data(); size_t left = j->text_len;
+            bool bad = false;
+            while (left) {
+                const ssize_t w = ::write(fd, p, left);
+                if (w < 0) { if (errno == EINTR) continue; bad = true; break; }
+                p += w; left -= (size_t)w;
+            }
+            const double dt = now_s() - t0;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (bad) write_failed = true;
+                total.reads += j->st.reads; total.bc += j->st.bc; total.pt += j->st.pt; total.r1 += j->st.r1;
+                total.first_pt = std::min(total.first_pt, j->st.first_pt); total.first_r1 = std::min(total.first_r1, j->st.first_r1);
+                t_write += dt; out_bytes += j->text_len;
+            }
+            delete j;
+        }
+    }
+};
+
+bool write_all(int fd, const char* p, size_t n)
+{
+    while (n) {
+        const ssize_t w = ::write(fd, p, n);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        p += w; n -= (size_t)w;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t bdg_format_rows(const bdg_ingest_chunk* ch, const bdg_extract_rec* recs, char* out, uint64_t cap, uint64_t counts[4])
+{
+    if (!ch || (ch->n && (!recs || !ch->bases || !ch->off || !ch->ids || !ch->id_off))) return BDG_E_ARG;
+    const uint64_t need = rows_bound(ch, recs, 0, 0, 0);
+    if (!out || need > cap) return (int64_t)need;
+    RowStats st;
+    char* e = write_rows(ch, recs, out, 0, 0, nullptr, 0, st);
+    if (counts) { counts[0] = ch->n; counts[1] = st.bc; counts[2] = st.pt; counts[3] = st.r1; }
+    return (int64_t)(e - out);
+}
+
+int bdg_stage1_run(bdg_ctx* const* ctxs, uint32_t n_ctx, const char* in_path, const char* out_path, const char* header,
+                   const bdg_stage1_opts* o, bdg_stage1_result* res)
+{
+    if (!ctxs || n_ctx == 0 || !ctxs[0] || !in_path || !out_path || !header || !o || !res) return BDG_E_ARG;
+    bdg_ctx* const c0 = ctxs[0];
+    memset(res, 0, sizeof(*res));
+    res->first_polyt = res->first_r1 = res->bad_read = ~0ull;
+    if (o->umi_len == 0 || o->umi_len > 64) return bdg_fail(c0, BDG_E_ARG, "umi_len out of range");
+    const double t_start = now_s();
+    const uint32_t fthreads = o->format_threads ? std::min(o->format_threads, 32u) : 3u;
+    const uint32_t per_ctx = 2;                                  // chunks in flight per context (BDG_SLOTS >= 2)
+    bdg_ingest_opts io;
+    memset(&io, 0, sizeof(io));
+    io.chunk_reads = o->chunk_reads ? o->chunk_reads : 100000u;
+    io.ring_chunks = per_ctx * n_ctx + 2 * fthreads + 4;         // views this pipeline holds at once
+    io.pinned = 1; io.threads = o->threads; io.segment_bytes = o->segment_bytes; io.skip_secondary = o->skip_secondary;
+    const uint64_t max_outstanding = 2 * fthreads + 2;           // collected chunks waiting for / in the formatters
+    Pipeline P;
+    int rc = bdg_ingest_open_ex(in_path, &io, &P.ing);
+    if (rc) return bdg_fail(c0, rc, std::string("cannot read ") + in_path + " (unknown extension or unreadable file)");
+    P.fd = ::open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (P.fd < 0) { bdg_ingest_close(P.ing); return bdg_fail(c0, BDG_E_ARG, std::string("cannot write ") + out_path); }
+    P.header = header; P.header_every = o->header_every;
+    bool ok_io = true;
+    if (!o->header_every) ok_io = write_all(P.fd, (P.header + "\n").data(), P.header.size() + 1);
+    std::vector<std::thread> fmt;
+    for (uint32_t i = 0; i < fthreads; ++i) fmt.emplace_back(&Pipeline::format_loop, &P);
+    std::thread writer(&Pipeline::write_loop, &P);
+
+    std::deque<Job*> inflight;
+    double t_parse_wait = 0, t_gpu_wait = 0, t_fmt_wait = 0, t_submit = 0;
+    std::string err; uint64_t bad_read = ~0ull;
+    auto collect = [&](Job* j) -> int {
+        j->recs.resize(j->ch.n);
+        const double t0 = now_s();
+        int r = bdg_extract_collect(j->ctx, j->slot, j->recs.data());
+        t_gpu_wait += now_s() - t0;
+        if (r) {
+            err = bdg_last_error(j->ctx);
+            if (r == BDG_E_BADBASE) { uint64_t b = ~0ull, w = 0; (void)bdg_extract_status(j->ctx, &b, &w); if (b != ~0ull) bad_read = j->g0 + b; }
+            bdg_ingest_release(P.ing, j->ch.id);
+            delete j;
+            return r;
+        }
+        const double t1 = now_s();
+        {
+            std::unique_lock<std::mutex> lk(P.mu);
+            P.cv.wait(lk, [&] { return P.outstanding < max_outstanding; });
+            ++P.outstanding;
+            P.to_format.push_back(j);
+        }
+        P.cv.notify_all();
+        t_fmt_wait += now_s() - t1;
+        return BDG_OK;
+    };
+    uint64_t k = 0, g0 = 0;
+    while (rc == BDG_OK) {
+        bdg_ingest_chunk ch;
+        const double t0 = now_s();
+        rc = bdg_ingest_next(P.ing, &ch);
+        t_parse_wait += now_s() - t0;
+        if (rc) { err = bdg_ingest_error(P.ing); break; }
+        if (ch.n == 0) break;
+        if (inflight.size() >= (size_t)per_ctx * n_ctx) { Job* j = inflight.front(); inflight.pop_front(); if ((rc = collect(j))) { bdg_ingest_release(P.ing, ch.id); break; } }
+        Job* j = new Job();
+        j->seq = k; j->g0 = g0; j->ch = ch; j->ctx = ctxs[k % n_ctx]; j->slot = (uint32_t)((k / n_ctx) % per_ctx);
+        const double t1 = now_s();
+        rc = bdg_extract_submit(j->ctx, j->slot, ch.bases, ch.off, ch.n, o->umi_len);
+        t_submit += now_s() - t1;
+        if (rc) { err = bdg_last_error(j->ctx); bdg_ingest_release(P.ing, ch.id); delete j; break; }
+        inflight.push_back(j);
+        g0 += ch.n; ++k;
+    }
+    while (!inflight.empty()) {
+        Job* j = inflight.front(); inflight.pop_front();
+        if (rc == BDG_OK) rc = collect(j);
+        else { j->recs.resize(j->ch.n); (void)bdg_extract_collect(j->ctx, j->slot, j->recs.data()); bdg_ingest_release(P.ing, j->ch.id); delete j; }   // wait for the GPU before the pinned buffers go
+    }
+    { std::lock_guard<std::mutex> lk(P.mu); P.closing = true; }
+    P.cv.notify_all();
+    for (auto& t : fmt) t.join();
+    writer.join();
+    // rows of the chunks before a failure are in the file, like in the reference's loop
+    if (rc == BDG_OK && o->header_every && g0 % o->header_every == 0) ok_io = write_all(P.fd, (P.header + "\n").data(), P.header.size() + 1) && ok_io;
+    if (::close(P.fd) != 0) ok_io = false;
+    bdg_ingest_close(P.ing);
+    res->reads = P.total.reads; res->barcodes = P.total.bc; res->polyt = P.total.pt; res->r1 = P.total.r1;
+    res->first_polyt = P.total.first_pt; res->first_r1 = P.total.first_r1; res->bad_read = bad_read;
+    res->chunks = k; res->out_bytes = P.out_bytes;
+    res->seconds_total = now_s() - t_start; res->seconds_wait_parse = t_parse_wait; res->seconds_wait_gpu = t_gpu_wait;
+    res->seconds_wait_format = t_fmt_wait; res->seconds_submit = t_submit; res->seconds_format = P.t_format; res->seconds_write = P.t_write;
+    if (rc) return bdg_fail(c0, rc, err);
+    if (!ok_io || P.write_failed) return bdg_fail(c0, BDG_E_ARG, std::string("write error on ") + out_path);
+    return BDG_OK;
+}
+
+}  // extern "C"

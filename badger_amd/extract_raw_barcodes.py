@@ -11,12 +11,12 @@ What differs from the reference, by design:
     and a tab-separated .stats (reference :162-173); threads > 1 writes a header per chunk
     and a space-separated .stats (reference :243-259) -- here always in input order, where
     the reference concatenates chunks in completion order.
-  * FASTA/FASTQ (optionally gzipped) go through the native pipeline (run_fastx_pipeline): a parser thread
-    fills pinned chunks, chunk k+1 is on its way to / on the GPU while the rows of chunk k are
-    formatted (natively) and written.  BAM/SAM needs pysam like the reference and takes the
-    plain chunk loop.
+  * every input format (FASTA / FASTQ / SAM, optionally gzipped or BGZF, and BAM) goes through the native pipeline
+    (bdg_stage1_run): reader threads parse segments of the input into pinned chunks, chunk k+1 is on its way to / on
+    the GPU while the rows of chunk k are formatted and written by further native threads.  `--threads` is the number
+    of reader threads (1: one sequential reader).  No pysam, no Bio.
   * new optional flag: --gpus N.  Chunk k goes to device k mod N; submission is asynchronous, so
-    the N devices work at the same time; rows are written in chunk order.
+    the N devices work at the same time; rows are written in input order.
 """
 import argparse
 import gzip
@@ -72,15 +72,19 @@ def _fastq_records(handle):
         yield (fields[0] if fields else ""), seq
 
 
-def _bam_records(path, skip_secondary):
+def _native_records(path, skip_secondary):
+    """(read_id, sequence) through the native reader (SAM / BAM: the library's own decoder, no pysam)"""
+    ing = _native.Ingest(path, READ_CHUNK_SIZE, 4, pinned=False, skip_secondary=skip_secondary)
     try:
-        import pysam
-    except ImportError:
-        raise RuntimeError("BAM/SAM input needs pysam, which is not installed")
-    for r in pysam.AlignmentFile(path, "rb"):
-        if skip_secondary and (r.is_secondary or r.is_supplementary):     # reference :144-145
-            continue
-        yield r.query_name, r.query_sequence
+        while True:
+            ch = ing.next()
+            if ch.n == 0:
+                return
+            recs = _native.chunk_reads(ch)
+            ing.release(ch)
+            yield from recs
+    finally:
+        ing.close()
 
 
 def open_reads(input_file, skip_secondary=True):
@@ -97,7 +101,7 @@ def open_reads(input_file, skip_secondary=True):
     if ext in (".fa", ".fasta"):
         return _fasta_records(handle or open(input_file))
     if ext in (".bam", ".sam"):
-        return _bam_records(input_file, skip_secondary)
+        return _native_records(input_file, skip_secondary)
     return None
 
 
@@ -111,12 +115,21 @@ def read_chunks(records, size=READ_CHUNK_SIZE):
     yield chunk                      # the reference also yields the trailing (possibly empty) chunk
 
 
-def is_fastx(input_file):
-    """True for [gzipped] FASTA / FASTQ by extension (reference :80-97)"""
+def _ext(input_file):
     fname, ext = os.path.splitext(os.path.basename(input_file))
     if ext.lower() in (".gz", ".gzip"):
         fname, ext = os.path.splitext(fname)
-    return ext.lower() in (".fq", ".fastq", ".fa", ".fasta")
+    return ext.lower()
+
+
+def is_fastx(input_file):
+    """True for [gzipped] FASTA / FASTQ by extension (reference :80-97)"""
+    return _ext(input_file) in (".fq", ".fastq", ".fa", ".fasta")
+
+
+def is_native_input(input_file):
+    """True for every format the reference reads (:80-97): [gzipped] FASTA / FASTQ, BAM, SAM - all parsed natively"""
+    return _ext(input_file) in (".fq", ".fastq", ".fa", ".fasta", ".bam", ".sam")
 
 
 def chunk_read_ids(ch):
@@ -126,23 +139,25 @@ def chunk_read_ids(ch):
     if not n:
         return []
     off = _native.np.ctypeslib.as_array(C.cast(ch.id_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).tolist()
-    text = C.string_at(ch.ids, off[n]).decode("ascii", "replace")
-    return [text[off[i]:off[i + 1]] for i in range(n)]
+    o0 = off[0]
+    text = C.string_at(ch.ids + o0, off[n] - o0).decode("ascii", "replace")
+    return [text[off[i] - o0:off[i + 1] - o0] for i in range(n)]
 
 
-def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None, inflate_threads=0, ids_only=False):
-    """file -> native parser thread -> pinned chunks -> GPU(s) -> native row formatter -> on_chunk(rows, recs), in
-    chunk order.  Two chunks per device are in flight (bdg_extract_submit / bdg_extract_collect), chunk k on device
-    k mod N, so parsing, H2D + kernels and formatting / writing overlap and N devices run concurrently from this one
-    thread.  Like the reference's chunk generator (:131-150) a trailing empty chunk is reported when the input ends on
-    a chunk boundary (on_chunk(b"", empty records)).  A BGZF (bgzip) input is inflated by inflate_threads threads
-    (0 = min(8, cores)); plain gzip is one sequential stream and stays on one.  ids_only: the caller wants the read ids
-    and the records, not the TSV text (stage 2 from FASTX input): on_chunk(list of ids, recs)."""
+def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None, inflate_threads=0, ids_only=False, skip_secondary=False,
+                       segment_bytes=0):
+    """file -> native reader threads -> pinned chunks -> GPU(s) -> native row formatter -> on_chunk(rows, recs), in
+    input order, driven from Python (callers that want the rows or ids in Python; file-to-file runs use
+    _native.stage1_run, which keeps everything native).  Two chunks per device are in flight (bdg_extract_submit /
+    bdg_extract_collect), chunk k on device k mod N.  A chunk holds at most chunk_size reads and never spans two parse
+    segments of the input, so chunks may be shorter in the middle of a large file.  ids_only: the caller wants the read
+    ids and the records, not the TSV text (stage 2 from read input): on_chunk(list of ids, recs).  Returns the number of
+    reads."""
     chunk_size = chunk_size or READ_CHUNK_SIZE
     ng = len(detectors)
-    ing = _native.Ingest(input_file, chunk_size, ring_chunks=2 * ng + 2, inflate_threads=inflate_threads)
+    ing = _native.Ingest(input_file, chunk_size, ring_chunks=2 * ng + 2, inflate_threads=inflate_threads,
+                         skip_secondary=skip_secondary, segment_bytes=segment_bytes)
     inflight = deque()
-    empty = _native.np.zeros(0, dtype=_native.REC_DTYPE)
 
     def finish(item):
         det, slot, ch = item
@@ -156,8 +171,9 @@ def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None, inflate
         ing.release(ch)
         on_chunk(rows, recs)
 
+    total = 0
     try:
-        k, last_n = 0, None
+        k = 0
         while True:
             ch = ing.next()
             if ch.n == 0:
@@ -167,11 +183,9 @@ def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None, inflate
             det, slot = detectors[k % ng], (k // ng) % 2
             det._ctx().extract_submit(slot, ch.bases, ch.off, ch.n, det.UMI_LEN_10X)
             inflight.append((det, slot, ch))
-            k, last_n = k + 1, ch.n
+            k, total = k + 1, total + ch.n
         while inflight:
             finish(inflight.popleft())
-        if last_n is None or last_n == chunk_size:
-            on_chunk([] if ids_only else b"", empty)
     finally:
         # chunks still in flight after an error: wait for the GPU before the pinned buffers go away
         for det, slot, ch in inflight:
@@ -180,6 +194,7 @@ def run_fastx_pipeline(input_file, detectors, on_chunk, chunk_size=None, inflate
             except Exception:
                 pass
         ing.close()
+    return total
 
 
 # ----------------------------------------------------------------------------- handlers
@@ -255,9 +270,11 @@ class BarcodeCaller:
         self.read_handler.add_rows([record_to_row(rid, s, r) for (rid, s), r in zip(read_chunk, recs)])
         self.read_stat.add_records(recs)
 
-    def process(self, input_file, skip_secondary=False):
+    def process(self, input_file, skip_secondary=False, threads=0):
+        """every read of the file through the detector's device into the handler (reference :78-118).  The handler gets
+        TSV text (add_text) or, if it says ids_only, the read ids (add_ids)."""
         logger.info("Processing " + input_file)
-        if is_fastx(input_file):
+        if is_native_input(input_file):
             ids_only = getattr(self.read_handler, "ids_only", False)
 
             def on_chunk(rows, recs):
@@ -266,20 +283,19 @@ class BarcodeCaller:
                 else:
                     self.read_handler.add_text(rows)
                 self.read_stat.add_records(recs)
-            run_fastx_pipeline(input_file, [self.barcode_detector], on_chunk, ids_only=ids_only)
+            run_fastx_pipeline(input_file, [self.barcode_detector], on_chunk, ids_only=ids_only, inflate_threads=threads,
+                               skip_secondary=skip_secondary)
         else:
-            records = open_reads(input_file, skip_secondary=skip_secondary)     # single-thread BAM path keeps all records (:110-118)
-            if records is None:
-                logger.error("Unknown file format " + input_file)
-            else:
-                for chunk in read_chunks(records):
-                    self.process_chunk(chunk)
+            logger.error("Unknown file format " + input_file)
         logger.info("Finished " + input_file)
 
 
 # ----------------------------------------------------------------------------- drivers
 def _detectors(mode, gpus):
     gpus = max(1, gpus)
+    if os.environ.get("BADGER_AMD_CONTEXTS_ON_ONE_DEVICE") == "1":
+        # rehearsal of --gpus N on a one-GPU box: N independent contexts (own streams, workspaces, staging) on device 0
+        return [BARCODE_CALLING_MODES[mode](device=0, instance=g) for g in range(gpus)]
     if gpus > 1:
         have = _native.device_count()
         if gpus > have:
@@ -287,65 +303,55 @@ def _detectors(mode, gpus):
     return [BARCODE_CALLING_MODES[mode](device=g) for g in range(gpus)]
 
 
+def _stats_lines(res):
+    """ReadStats.__str__ (barcode_callers.py:138-143) from the native run's counters: the attribute lines come in the order
+    in which the first read showing each was met (a dict's insertion order in the reference)."""
+    lines = [("Total reads", res.reads), ("Barcode detected", res.barcodes), ("Reliable UMI", 0)]
+    attrs = []
+    if res.polyt:
+        attrs.append((res.first_polyt, 0, "PolyT detected", res.polyt))
+    if res.r1:
+        attrs.append((res.first_r1, 1, "R1 detected", res.r1))       # one read adds "PolyT detected" before "R1 detected"
+    return lines + [(name, v) for _, _, name, v in sorted(attrs)]
+
+
+def _run_native(args, header_every, threads, skip_secondary):
+    if not is_native_input(args.input):
+        logger.error("Unknown file format " + args.input)
+        sys.exit(-1)
+    detectors = _detectors(args.mode, getattr(args, "gpus", 1))
+    logger.info("Barcode caller created")
+    res = _native.stage1_run([d._ctx() for d in detectors], args.input, args.output, detectors[0].result_type().header(),
+                             detectors[0].UMI_LEN_10X, threads=threads, header_every=header_every, skip_secondary=skip_secondary)
+    timing = os.environ.get("BADGER_AMD_STAGE1_TIMING")
+    if timing:                                   # where the run's time went (tools/cli_throughput.py reads it)
+        import json
+        with open(timing, "a") as f:
+            f.write(json.dumps({k: getattr(res, k) for k, _ in res._fields_}) + "\n")
+    return res
+
+
 def process_single_thread(args):
+    """one header on top, tab-separated .stats (reference :162-173); every SAM / BAM record is used (:110-118)"""
     logger.info("Processing " + args.input)
-    handler = FileReadHandler(args.output)
-    caller = BarcodeCaller(_detectors(args.mode, 1)[0], handler)
-    caller.process(args.input)
-    handler.dump_stats(caller.read_stat)
-    handler.close()
-    for line in str(caller.read_stat).split("\n"):
-        if line:
-            logger.info(line)
+    res = _run_native(args, 0, 1, False)
+    with open(args.output + ".stats", "w") as f:
+        for k, v in _stats_lines(res):
+            f.write("%s:\t%d\n" % (k, v))
+            logger.info("%s:\t%d" % (k, v))
     logger.info("Finished barcode calling")
 
 
 def process_in_parallel(args):
-    """Chunk k goes to device k mod N (all N work concurrently); output is written in chunk order, one header per
-    chunk and a space-separated merged .stats (the reference's parallel-mode file shape, :243-259)."""
+    """a header in front of every READ_CHUNK_SIZE reads (+ one for the trailing chunk) and a space-separated merged .stats:
+    the reference's parallel-mode file shape (:131-159,243-259), rows in input order; secondary and supplementary SAM / BAM
+    records are skipped (:144-145).  Chunk k goes to device k mod N (all N work concurrently)."""
     logger.info("Processing " + args.input)
-    fastx = is_fastx(args.input)
-    records = None
-    if not fastx:
-        records = open_reads(args.input, skip_secondary=True)
-        if records is None:
-            logger.error("Unknown file format " + args.input)
-            sys.exit(-1)
-    detectors = _detectors(args.mode, getattr(args, "gpus", 1))
-    logger.info("Barcode caller created")
-    stat_dict = defaultdict(int)
-    header = detectors[0].result_type().header()
-
-    def merge_stats(stats):
-        for line in str(stats).split("\n"):
-            v = line.strip().split("\t")
-            if len(v) == 2:
-                stat_dict[v[0]] += int(v[1])
-
-    with open(args.output, "w") as outf:
-        if fastx:
-            def on_chunk(rows, recs):
-                outf.write(header + "\n")
-                stats = ReadStats()
-                if len(recs):
-                    outf.write(rows.decode("ascii"))
-                    stats.add_records(recs)
-                merge_stats(stats)
-            run_fastx_pipeline(args.input, detectors, on_chunk, inflate_threads=args.threads if args.threads > 1 else 0)
-        else:
-            for k, chunk in enumerate(read_chunks(records)):
-                det = detectors[k % len(detectors)]
-                outf.write(header + "\n")
-                stats = ReadStats()
-                if chunk:
-                    recs = det.extract_records([s for _, s in chunk])
-                    outf.write("\n".join(record_to_row(rid, s, r) for (rid, s), r in zip(chunk, recs)) + "\n")
-                    stats.add_records(recs)
-                merge_stats(stats)
+    res = _run_native(args, READ_CHUNK_SIZE, args.threads, True)
     with open(args.output + ".stats", "w") as out_stats:
-        for k, v in stat_dict.items():
-            logger.info("%s %d" % (k, v))
-            out_stats.write("%s %d\n" % (k, v))
+        for k, v in _stats_lines(res):
+            logger.info("%s: %d" % (k, v))
+            out_stats.write("%s: %d\n" % (k, v))
     logger.info("Finished barcode calling")
 
 
@@ -359,11 +365,11 @@ def extract_barcodes_single_thread(input_file, mode, device=0):
 
 def extract_barcodes_in_parallel(input_file, mode, threads, device=0):
     logger.info("Extracting from " + input_file)
-    if not is_fastx(input_file) and open_reads(input_file) is None:
+    if not is_native_input(input_file):
         logger.error("Unknown file format " + input_file)
         sys.exit(-1)
     handler = ListReadHandler()
-    BarcodeCaller(BARCODE_CALLING_MODES[mode](device=device), handler).process(input_file, skip_secondary=True)
+    BarcodeCaller(BARCODE_CALLING_MODES[mode](device=device), handler).process(input_file, skip_secondary=True, threads=threads)
     logger.info("Finished barcode extraction")
     return handler.read_storage
 
@@ -396,11 +402,11 @@ class IdListHandler:
         pass
 
 
-def extract_read_ids(input_file, mode, device=0, skip_secondary=False):
+def extract_read_ids(input_file, mode, device=0, skip_secondary=False, threads=0):
     """run the extraction (records stay with the context if it keeps them) and return the read ids in order"""
     logger.info("Extracting from " + input_file)
     handler = IdListHandler()
-    BarcodeCaller(BARCODE_CALLING_MODES[mode](device=device), handler).process(input_file, skip_secondary=skip_secondary)
+    BarcodeCaller(BARCODE_CALLING_MODES[mode](device=device), handler).process(input_file, skip_secondary=skip_secondary, threads=threads)
     logger.info("Finished barcode extraction")
     return handler.read_ids
 

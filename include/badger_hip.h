@@ -44,7 +44,9 @@ extern "C" {
 #define BDG_E_CAPACITY   -4   /* output capacity too small (graph edges: see *n_edges) */
 #define BDG_E_BADBASE    -5   /* a read holds a byte outside "ACGTN" (reference: KeyError,
                                  barcode_extraction/common.py:34-38) */
-#define BDG_E_FORMAT     -6   /* malformed FASTA / FASTQ input (reference: ValueError from Bio.SeqIO) */
+#define BDG_E_FORMAT     -6   /* malformed FASTA / FASTQ / SAM / BAM input (reference: ValueError from Bio.SeqIO / pysam) */
+#define BDG_E_NOSEQ      -7   /* a SAM / BAM record without a sequence (reference: query_sequence is None and
+                                 find_barcode_umi raises TypeError on it, barcode_callers.py:183) */
 
 typedef struct bdg_ctx bdg_ctx;
 
@@ -188,40 +190,85 @@ int  bdg_kept_records(bdg_ctx* ctx, const bdg_extract_rec** d_recs, uint64_t* n)
 int  bdg_kept_records_to_host(bdg_ctx* ctx, bdg_extract_rec* out, uint64_t cap);
 
 /* ---- read ingest and row output (host side) --------------------------------------------- */
-/* [gzipped] FASTA / FASTQ -> chunks of at most chunk_reads reads {concatenated bases, offsets, ids}, parsed by a
- * background thread into a ring of ring_chunks chunks (>= 2) of pinned host memory (pinned = 0: pageable, for hosts
- * without a GPU).  Format by extension like the reference (extract_raw_barcodes.py:78-98): .fa .fasta .fq .fastq,
- * optionally + .gz / .gzip; anything else returns BDG_E_ARG (BAM / SAM stay with the caller's pysam).  Record
- * semantics are Bio.SeqIO's: id = first word of the header; FASTA sequence = its lines joined. */
+/* [gzipped / BGZF] FASTA / FASTQ / SAM and BAM -> chunks of at most chunk_reads reads {concatenated bases, offsets, ids}
+ * in pinned host memory (pinned = 0: pageable, for hosts without a GPU), in file order.  Replaces the reference's record
+ * loops over Bio.SeqIO.parse / pysam.AlignmentFile (extract_raw_barcodes.py:78-118,131-150).  Format by extension like the
+ * reference (:80-97,181-197): .fa .fasta .fq .fastq .sam .bam, optionally + .gz / .gzip; anything else returns BDG_E_ARG.
+ * Record semantics: Bio.SeqIO's (id = first word of the header; FASTA sequence = its lines joined; FASTQ = four-line
+ * records) and pysam's (query_name, query_sequence).  The text is parsed by several threads, one segment of the input
+ * each (csrc/ingest.cpp says how and why the result equals a one-thread parse); a chunk never spans two segments, so a
+ * chunk may be shorter than chunk_reads in the middle of a large file. */
 typedef struct bdg_ingest bdg_ingest;
 typedef struct bdg_ingest_chunk {
-    uint32_t        id;           /* ring position, for bdg_ingest_release */
+    uint32_t        id;           /* for bdg_ingest_release */
     uint32_t        n;            /* reads in the chunk; 0 = end of input */
-    const uint8_t*  bases;        /* concatenated ASCII, 64 readable bytes behind the end */
-    const uint64_t* off;          /* n + 1 offsets into bases, off[0] = 0 */
-    uint64_t        total_bytes;  /* off[n] */
-    const char*     ids;          /* concatenated read ids */
+    const uint8_t*  bases;        /* concatenated ASCII; read i is bases[off[i] .. off[i+1]); 64 readable bytes behind the end */
+    const uint64_t* off;          /* n + 1 offsets into bases (off[0] is 0 only for the first chunk cut from a segment) */
+    uint64_t        total_bytes;  /* off[n] - off[0] */
+    const char*     ids;          /* concatenated read ids; id i is ids[id_off[i] .. id_off[i+1]) */
     const uint64_t* id_off;       /* n + 1 offsets into ids */
 } bdg_ingest_chunk;
+typedef struct bdg_ingest_opts {
+    uint32_t chunk_reads;         /* reads per chunk at most (the reference's READ_CHUNK_SIZE = 100000) */
+    uint32_t ring_chunks;         /* chunks the caller may hold at once (taken and not yet released), >= 2 */
+    int32_t  pinned;              /* bases in pinned host memory (hipHostMalloc) */
+    uint32_t threads;             /* threads that inflate and parse: 0 = min(12, cores); 1 = one, and every compressed input is read as
+                                     the sequential gzip stream it is for gzip.open in the reference (extract_raw_barcodes.py:86-87) */
+    uint64_t segment_bytes;       /* text per parse segment (0 = 64 MiB) */
+    int32_t  skip_secondary;      /* SAM / BAM: drop secondary and supplementary records (flag 0x100 / 0x800) like the reference's
+                                     chunk reader (:144-145); its single-thread loop keeps them (:110-118) */
+    uint32_t reserved;
+} bdg_ingest_opts;
 int  bdg_ingest_open(const char* path, uint32_t chunk_reads, uint32_t ring_chunks, int pinned, bdg_ingest** out);
-/* The same with the number of inflate threads stated.  A BGZF file (blocked gzip as bgzip / htslib write it: members of
- * <= 64 KiB that carry their compressed size) is cut into its blocks and inflated by that many threads, results taken
- * in file order; 0 = min(8, cores), 1 = zlib's sequential reader for every input (what gzip.open does in the reference,
- * extract_raw_barcodes.py:86-87).  Plain gzip and uncompressed files are read by one thread whatever the number.  This
- * is what the reference's "-t threads" can still buy on the input side. */
-int  bdg_ingest_open_mt(const char* path, uint32_t chunk_reads, uint32_t ring_chunks, int pinned, uint32_t inflate_threads,
+/* The same with the number of reader threads stated (bdg_ingest_opts.threads).  What the reference's "-t threads" buys on
+ * the input side. */
+int  bdg_ingest_open_mt(const char* path, uint32_t chunk_reads, uint32_t ring_chunks, int pinned, uint32_t threads,
                         bdg_ingest** out);
+int  bdg_ingest_open_ex(const char* path, const bdg_ingest_opts* opts, bdg_ingest** out);
 /* Blocks until the next chunk is parsed.  The chunk's memory stays untouched until bdg_ingest_release(id); at most
- * ring_chunks - 1 chunks can be held.  BDG_E_FORMAT: malformed record (bdg_ingest_error says where). */
+ * ring_chunks chunks can be held.  BDG_E_FORMAT: malformed record (bdg_ingest_error says where; the chunks in front of it
+ * have been delivered); BDG_E_NOSEQ: a SAM / BAM record without a sequence. */
 int  bdg_ingest_next(bdg_ingest* g, bdg_ingest_chunk* out);
 int  bdg_ingest_release(bdg_ingest* g, uint32_t id);
 const char* bdg_ingest_error(bdg_ingest* g);
+uint64_t bdg_ingest_reads(bdg_ingest* g);      /* reads in the chunks made so far (all of them once bdg_ingest_next has returned n = 0) */
 void bdg_ingest_close(bdg_ingest* g);
 /* TSV rows of a chunk (TenXBarcodeDetectionResult.__str__, barcode_callers.py:40-42,91-93,117-119), one line per read,
  * "\n"-terminated, into out[cap].  Returns the bytes written, or the bytes needed if cap is too small (nothing
  * written then; call with out = NULL to size), or < 0.  counts (may be NULL): reads, barcodes detected, polyT
  * detected, R1 detected (ReadStats, barcode_callers.py:122-143). */
 int64_t bdg_format_rows(const bdg_ingest_chunk* chunk, const bdg_extract_rec* recs, char* out, uint64_t cap, uint64_t counts[4]);
+
+/* Stage 1 from file to file in native threads: readers -> GPU(s) -> row formatters -> one writer, rows in input order
+ * (extract_raw_barcodes.py:162-173 process_single_thread, :176-261 process_in_parallel).  Chunk k goes to context k mod
+ * n_ctx, two chunks in flight per context.  header: the column line without its newline.  Returns BDG_E_BADBASE (reference:
+ * KeyError), BDG_E_FORMAT (ValueError), BDG_E_NOSEQ (TypeError) with the rows of the chunks in front of the failure
+ * written, like the reference's loop; the message is bdg_last_error(ctxs[0]). */
+typedef struct bdg_stage1_opts {
+    uint32_t umi_len;             /* 10 (tenX_v2) or 12 (tenX_v3) */
+    uint32_t threads;             /* reader threads (bdg_ingest_opts.threads) */
+    uint32_t format_threads;      /* 0 = 3 */
+    uint32_t header_every;        /* 0: the header once, on top (the reference's single-thread file shape); N: in front of every N
+                                     reads and once more when the input ends on a multiple of N - the reference's parallel shape,
+                                     one header per READ_CHUNK_SIZE chunk including the trailing empty one (:131-150,243-246) */
+    uint32_t chunk_reads;         /* reads per GPU batch at most (0 = 100000) */
+    int32_t  skip_secondary;      /* bdg_ingest_opts.skip_secondary */
+    uint64_t segment_bytes;       /* bdg_ingest_opts.segment_bytes */
+} bdg_stage1_opts;
+typedef struct bdg_stage1_result {
+    uint64_t reads, barcodes, polyt, r1;      /* ReadStats: total, barcode detected, polyT detected, R1 detected */
+    uint64_t first_polyt, first_r1;           /* index of the first read showing each attribute (~0: none): the order of the .stats lines */
+    uint64_t bad_read;                        /* BDG_E_BADBASE: index of the read, ~0 if unknown */
+    uint64_t chunks, out_bytes;
+    double   seconds_total;
+    double   seconds_wait_parse;              /* this thread waiting for the readers */
+    double   seconds_submit;                  /* ... queueing copies and kernels */
+    double   seconds_wait_gpu;                /* ... waiting for a chunk's records */
+    double   seconds_wait_format;             /* ... waiting for the formatters / the writer to take a chunk */
+    double   seconds_format, seconds_write;   /* busy time of the formatter threads (summed) / of the writer */
+} bdg_stage1_result;
+int  bdg_stage1_run(bdg_ctx* const* ctxs, uint32_t n_ctx, const char* in_path, const char* out_path, const char* header,
+                    const bdg_stage1_opts* opts, bdg_stage1_result* res);
 
 /* ---- B-N: nearest whitelist barcode ----------------------------------- */
 /* Per query: the whitelist entry with the smallest Levenshtein distance (ties ->

@@ -4,6 +4,7 @@ import io
 import os
 from contextlib import redirect_stdout
 
+import numpy as np
 import pytest
 
 from badger_amd import badger, extract_raw_barcodes as erb
@@ -79,10 +80,28 @@ def test_pipeline_over_several_contexts_keeps_chunk_order(tmp_path):
         def on_chunk(text, r):
             got.append(text)
             sizes.append(len(r))
-        erb.run_fastx_pipeline(path, dets, on_chunk, chunk_size=size)
+        assert erb.run_fastx_pipeline(path, dets, on_chunk, chunk_size=size) == 9000
         assert b"".join(got).decode() == "\n".join(rows) + "\n"
         full, rest = divmod(9000, size)
-        assert sizes == [size] * full + ([rest] if rest else [0])
+        assert sizes == [size] * full + ([rest] if rest else [])
+    # the same through the native file-to-file pipeline: contexts x parse segments x both file shapes; the header goes in
+    # front of every `every` reads and once more when the input ends on a multiple (the reference's trailing empty chunk)
+    from badger_amd import _native
+    header = "#read_id\tbarcode\tUMI\tBC_score\tvalid_UMI\tstrand\tpolyT_start\tR1_end"
+    out = str(tmp_path / "n.tsv")
+    for ndet, seg, every, chunk in ((3, 0, 0, 700), (3, 1 << 20, 1000, 0), (2, 300000, 4500, 1300), (1, 50000, 9000, 0), (3, 2000, 7, 50)):
+        ctxs = [_native.default_context(0, i) for i in range(ndet)]
+        res = _native.stage1_run(ctxs, path, out, header, 12, threads=3, header_every=every, chunk_reads=chunk, segment_bytes=seg)
+        want = []
+        for i, r in enumerate(rows):
+            if (every and i % every == 0) or (not every and i == 0):
+                want.append(header)
+            want.append(r)
+        if every and len(rows) % every == 0:
+            want.append(header)
+        assert open(out).read() == "\n".join(want) + "\n", (ndet, seg, every)
+        assert (res.reads, res.barcodes, res.polyt, res.r1) == (9000, int(recs["valid"].sum()), int((recs["polyT"] != -1).sum()), int((recs["r1_end"] != -1).sum()))
+        assert res.first_polyt == int(np.argmax(recs["polyT"] != -1)) and res.first_r1 == int(np.argmax(recs["r1_end"] != -1))
 
 
 def test_stage1_empty_and_tiny_inputs(tmp_path):
@@ -284,3 +303,63 @@ def test_stage1_from_bgzf_and_gzip_inputs(tmp_path):
     out = str(tmp_path / "o_t3.tsv")
     erb.main(["--mode", "tenX_v3", "-i", bg, "-o", out, "-t", "3"])           # three inflate threads, one header per chunk
     assert open(out).read() == "\n".join([header] + rows[:100000] + [header] + rows[100000:]) + "\n"
+
+
+def _c1_reads(golden_dir):
+    return list(erb.open_reads(os.path.join(golden_dir, "c1_reads.fa.gz")))
+
+
+@pytest.mark.parametrize("container", ["bam", "sam", "sam.gz"])
+def test_stage1_from_sam_and_bam(tmp_path, golden_dir, container):
+    """The config-1 reads as BAM / SAM written by tests/bamio.py, with secondary and supplementary copies sprinkled in:
+    -t 1 (reference :110-118) uses every record, -t N (:144-145) only the primary ones, which gives exactly the reference's
+    TSV for the FASTA form of the same reads."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bamio
+    reads = _c1_reads(golden_dir)
+    recs, every = [], []
+    for i, (rid, seq) in enumerate(reads):
+        flag = 4 if i % 3 else (16 if i % 2 else 0)
+        recs.append((rid, flag, seq, [] if flag & 4 else [(len(seq), "M")], b"" if i % 2 else b"NMC\x00"))
+        every.append(i)
+        if i % 10 == 0:                                          # a secondary / supplementary copy of the read, clipped
+            recs.append((rid, 256 if i % 20 else 2048, seq[:len(seq) // 2], [(len(seq) // 2, "M")]))
+            every.append(-1)
+    p = str(tmp_path / ("r." + container))
+    if container == "bam":
+        open(p, "wb").write(bamio.bgzf(bamio.bam_raw(recs), block=20000))
+    else:
+        import gzip
+        data = bamio.sam_text(recs).encode()
+        open(p, "wb").write(gzip.compress(data) if container.endswith("gz") else data)
+    golden = open(os.path.join(golden_dir, "c1_expected.tsv")).read().split("\n")
+    out = str(tmp_path / "o.tsv")
+    erb.main(["--mode", "tenX_v3", "-i", p, "-o", out, "-t", "4"])
+    got = open(out).read().split("\n")
+    assert [l for l in got if not l.startswith("#")] == [l for l in golden if not l.startswith("#")]
+    erb.main(["--mode", "tenX_v3", "-i", p, "-o", out, "-t", "1"])
+    got = open(out).read().split("\n")
+    assert got[0] == golden[0] and len(got) == len(recs) + 2
+    assert [l for l, k in zip(got[1:], every) if k >= 0] == golden[1:-1]            # the primary records' rows are the reference's
+    assert all(l.split("\t")[0] == r[0] for l, r in zip(got[1:], recs))
+    # stage 2 straight from the BAM / SAM (records stay on the device), both thread settings of the reference
+    prefix = str(tmp_path / "s2")
+    with redirect_stdout(io.StringIO()):
+        badger.main(["-r", p, "-d", "tenX_v3", "-l", os.path.join(golden_dir, "c1_whitelist.txt"), "-c", "50", "-o", prefix, "-tr", "2"])
+    assert open(prefix + "_output_file.tsv").read() == open(os.path.join(golden_dir, "c1_stage2_output_file.tsv")).read()
+
+
+def test_stage1_iupac_codes_in_bam_raise_keyerror(tmp_path):
+    """a BAM sequence may hold any of =ACMGRSVTWYHKDBN; anything outside ACGTN raises KeyError in the reference's
+    reverese_complement"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bamio
+    p = str(tmp_path / "i.bam")
+    open(p, "wb").write(bamio.bgzf(bamio.bam_raw([("a", 4, "ACGTNACGTACGTACGTTTTTT"), ("b", 4, "ACGTRYACGT")])))
+    with pytest.raises(KeyError):
+        erb.main(["--mode", "tenX_v3", "-i", p, "-o", str(tmp_path / "o.tsv"), "-t", "1"])
+    open(p, "wb").write(bamio.bgzf(bamio.bam_raw([("a", 4, "ACGTNACGTACGTACGTTTTTT"), ("b", 4, "")])))
+    with pytest.raises(TypeError):
+        erb.main(["--mode", "tenX_v3", "-i", p, "-o", str(tmp_path / "o.tsv"), "-t", "1"])

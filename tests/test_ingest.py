@@ -14,20 +14,15 @@ from badger_amd.barcode_extraction.barcode_callers import record_to_row
 from oracle import pyoracle as orc
 
 
-def _chunks(path, size, ring=3):
-    ing = _native.Ingest(path, size, ring, pinned=False)
+def _chunks(path, size, ring=3, **kw):
+    ing = _native.Ingest(path, size, ring, pinned=False, **kw)
     out = []
     try:
         while True:
             ch = ing.next()
             if ch.n == 0:
                 break
-            off = np.ctypeslib.as_array(C.cast(ch.off, C.POINTER(C.c_uint64)), shape=(ch.n + 1,)).copy()
-            idoff = np.ctypeslib.as_array(C.cast(ch.id_off, C.POINTER(C.c_uint64)), shape=(ch.n + 1,)).copy()
-            bases = C.string_at(ch.bases, int(ch.total_bytes))
-            ids = C.string_at(ch.ids, int(idoff[-1]))
-            recs = [(ids[int(idoff[i]):int(idoff[i + 1])].decode(), bases[int(off[i]):int(off[i + 1])].decode()) for i in range(ch.n)]
-            out.append(recs)
+            out.append(_native.chunk_reads(ch))
             ing.release(ch)
     finally:
         ing.close()
@@ -94,10 +89,10 @@ def test_fastq_records_and_errors(tmp_path, name):
             _chunks(str(p), 4)
         with pytest.raises(ValueError):
             list(erb.open_reads(str(p)))
-    # chunks before the malformed record are still delivered
+    # the reads in front of the malformed record are still delivered
     _write(p, text[:text.index("@r9 ")] + "oops\n")
     ing = _native.Ingest(str(p), 4, 3, pinned=False)
-    assert ing.next().n == 4 and ing.next().n == 4
+    assert ing.next().n == 4 and ing.next().n == 4 and ing.next().n == 1
     with pytest.raises(ValueError):
         ing.next()
     ing.close()
@@ -135,21 +130,7 @@ def test_bgzf_input_is_inflated_in_parallel_and_in_order(tmp_path, threads):
     assert len(want) == 1500
 
     def chunks_of(path, size=256):
-        ing = _native.Ingest(str(path), size, 3, pinned=False, inflate_threads=threads)
-        out = []
-        try:
-            while True:
-                ch = ing.next()
-                if ch.n == 0:
-                    return out
-                off = np.ctypeslib.as_array(C.cast(ch.off, C.POINTER(C.c_uint64)), shape=(ch.n + 1,))
-                idoff = np.ctypeslib.as_array(C.cast(ch.id_off, C.POINTER(C.c_uint64)), shape=(ch.n + 1,))
-                bases = C.string_at(ch.bases, int(ch.total_bytes))
-                ids = C.string_at(ch.ids, int(idoff[-1]))
-                out += [(ids[int(idoff[i]):int(idoff[i + 1])].decode(), bases[int(off[i]):int(off[i + 1])].decode()) for i in range(ch.n)]
-                ing.release(ch)
-        finally:
-            ing.close()
+        return _flat(_chunks(str(path), size, inflate_threads=threads))
 
     p = tmp_path / "r.fastq.gz"
     for block, marker in ((65280, True), (1000, True), (65280, False)):
@@ -193,8 +174,8 @@ def test_bgzf_input_is_inflated_in_parallel_and_in_order(tmp_path, threads):
 
 
 def test_unknown_extension_is_refused(tmp_path):
-    p = tmp_path / "reads.bam"
-    p.write_bytes(b"BAM\1")
+    p = tmp_path / "reads.txt"
+    p.write_bytes(b"@r\nACGT\n+\nIIII\n")
     with pytest.raises(_native.BadgerHipError):
         _native.Ingest(str(p), 10, 2, pinned=False)
     assert not erb.is_fastx(str(p)) and erb.is_fastx("x.FASTQ.gz") and erb.is_fastx("a/b.fa")
