@@ -34,11 +34,13 @@ EXPORTS = [
     "bdg_profile_enable", "bdg_profile_only", "bdg_profile_reset", "bdg_profile_read",
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_extract_set_strand_rule",
-    "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo",
+    "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo", "bdg_nearest16_index_bytes",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev", "bdg_rows_of_dev",
     "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host",
     "bdg_ingest_open", "bdg_ingest_open_mt", "bdg_ingest_open_ex", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error",
     "bdg_ingest_reads", "bdg_ingest_close", "bdg_format_rows", "bdg_stage1_run",
+    "bdg_cluster_dev", "bdg_assign_reads_dev", "bdg_idstore_new", "bdg_idstore_free", "bdg_idstore_count", "bdg_idstore_append",
+    "bdg_idstore_get", "bdg_stage1_collect", "bdg_write_assignments",
 ]
 
 
@@ -129,6 +131,8 @@ def load():
     L.bdg_nearest16_dev.argtypes = [vp, vp, u32, u32, vp, vp, vp]
     L.bdg_nearest16_recs_dev.argtypes = [vp, vp, u32, u32, vp, vp, vp]
     L.bdg_nearest16_set_algo.argtypes = [vp, C.c_int]
+    L.bdg_nearest16_index_bytes.argtypes = [vp]
+    L.bdg_nearest16_index_bytes.restype = C.c_uint64
     L.bdg_graph_edges.argtypes = [vp, vp, u32, u32, i32, vp, u64, C.POINTER(u64)]
     L.bdg_graph_edges_dev.argtypes = [vp, vp, u32, u32, i32, vp, u64, vp]
     L.bdg_graph_edges_rows_dev.argtypes = [vp, vp, u32, u32, u32, u32, i32, vp, u64, vp]
@@ -146,6 +150,17 @@ def load():
     L.bdg_ingest_reads.argtypes = [vp]
     L.bdg_ingest_reads.restype = C.c_uint64
     L.bdg_stage1_run.argtypes = [C.POINTER(vp), u32, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Stage1Opts), C.POINTER(Stage1Result)]
+    L.bdg_cluster_dev.argtypes = [vp, vp, vp, u64, u32, vp]
+    L.bdg_assign_reads_dev.argtypes = [vp, vp, u64, vp, u32, vp, vp, vp, vp]
+    L.bdg_idstore_new.restype = vp
+    L.bdg_idstore_free.argtypes = [vp]
+    L.bdg_idstore_free.restype = None
+    L.bdg_idstore_count.argtypes = [vp]
+    L.bdg_idstore_count.restype = C.c_uint64
+    L.bdg_idstore_append.argtypes = [vp, vp, vp, u64]
+    L.bdg_idstore_get.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(u32)]
+    L.bdg_stage1_collect.argtypes = [vp, C.c_char_p, C.POINTER(Stage1Opts), vp, C.POINTER(Stage1Result)]
+    L.bdg_write_assignments.argtypes = [vp, vp, vp, u64, C.c_char_p]
     L.bdg_ingest_next.argtypes = [vp, C.POINTER(IngestChunk)]
     L.bdg_ingest_release.argtypes = [vp, u32]
     L.bdg_ingest_error.argtypes = [vp]
@@ -307,6 +322,10 @@ class Context:
     def nearest16_set_algo(self, algo):
         self._check(self.lib.bdg_nearest16_set_algo(self.h, algo))
 
+    def nearest16_index_bytes(self):
+        """device bytes of the probe index of the loaded whitelist (0: never built)"""
+        return int(self.lib.bdg_nearest16_index_bytes(self.h))
+
     # -- graph -----------------------------------------------------------------
     def graph_edges(self, ranks, thr, qgram_T):
         ranks = np.ascontiguousarray(ranks, dtype=np.uint32)
@@ -337,6 +356,15 @@ class Context:
     def rows_of_dev(self, d_sorted, n, d_values, m, stride_words, d_rows, value_offset_words=0):
         """d_rows[i] = position of d_values[value_offset_words + i * stride_words] in the ascending d_sorted[0..n), NONE if absent"""
         self._check(self.lib.bdg_rows_of_dev(self.h, _ptr(d_sorted), n, _ptr(d_values, 4 * value_offset_words), m, stride_words, _ptr(d_rows)))
+
+    def cluster_dev(self, d_ea, d_eb, m, nu, d_owner):
+        """the two clustering levels over m edges given as positions in the distinct array (bdg_cluster_dev)"""
+        self._check(self.lib.bdg_cluster_dev(self.h, _ptr(d_ea), _ptr(d_eb), m, nu, _ptr(d_owner)))
+
+    def assign_reads_dev(self, d_recs, n, d_uniq, nu, d_assigned, d_has, d_out_rank, d_out_has):
+        """per record: the barcode its observed barcode was corrected to (bdg_assign_reads_dev)"""
+        self._check(self.lib.bdg_assign_reads_dev(self.h, _ptr(d_recs), n, _ptr(d_uniq), nu, _ptr(d_assigned), _ptr(d_has),
+                                                  _ptr(d_out_rank), _ptr(d_out_has)))
 
     def distinct_dev(self, d_recs, n, d_uniq, d_count, d_first, d_n):
         """d_recs: a torch tensor of records or a raw device pointer (kept_records())"""
@@ -471,6 +499,80 @@ def stage1_run(contexts, in_path, out_path, header, umi_len, threads=0, header_e
             raise TypeError(msg)
         raise BadgerHipError(rc, msg)
     return res
+
+
+class IdStore:
+    """read ids of a run, kept natively (bdg_idstore_*)"""
+
+    def __init__(self, ids=None):
+        self.lib = load()
+        self.h = C.c_void_p(self.lib.bdg_idstore_new())
+        if ids:
+            self.extend(ids)
+
+    def __len__(self):
+        return int(self.lib.bdg_idstore_count(self.h))
+
+    def extend(self, ids):
+        """append a list of str"""
+        if not len(ids):
+            return
+        text = "".join(ids).encode("ascii", "replace")
+        off = np.zeros(len(ids) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(np.fromiter((len(x) for x in ids), dtype=np.uint64, count=len(ids)))
+        if int(off[-1]) != len(text):
+            raise ValueError("read ids must be ASCII")
+        if self.lib.bdg_idstore_append(self.h, text, off.ctypes.data, len(ids)) != 0:
+            raise BadgerHipError(E_ARG, "bdg_idstore_append")
+
+    def __getitem__(self, i):
+        p, n = C.c_void_p(), C.c_uint32()
+        if self.lib.bdg_idstore_get(self.h, i, C.byref(p), C.byref(n)) != 0:
+            raise IndexError(i)
+        return C.string_at(p.value, n.value).decode("ascii", "replace")
+
+    def to_list(self):
+        return [self[i] for i in range(len(self))]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bdg_idstore_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def stage1_collect(ctx, in_path, umi_len, ids, threads=0, skip_secondary=False, chunk_reads=0, segment_bytes=0):
+    """bdg_stage1_collect: every read of the file through the context (records stay on the device if it keeps them), the
+    read ids into the IdStore.  Raises like stage1_run."""
+    L = load()
+    o = Stage1Opts(umi_len, threads, 0, 0, chunk_reads, 1 if skip_secondary else 0, segment_bytes)
+    res = Stage1Result()
+    rc = L.bdg_stage1_collect(ctx.h, os.fsencode(in_path), C.byref(o), ids.h, C.byref(res))
+    if rc != 0:
+        msg = L.bdg_last_error(ctx.h).decode()
+        if rc == E_BADBASE:
+            raise KeyError(msg)
+        if rc == E_FORMAT:
+            raise ValueError(msg)
+        if rc == E_NOSEQ:
+            raise TypeError(msg)
+        raise BadgerHipError(rc, msg)
+    return res
+
+
+def write_assignments(ids, rank, has, path):
+    """<path>: "readID\tbarcode" and one line per read (bdg_write_assignments)"""
+    L = load()
+    rank = np.ascontiguousarray(rank, dtype=np.uint32)
+    has = np.ascontiguousarray(has, dtype=np.uint8)
+    rc = L.bdg_write_assignments(ids.h, rank.ctypes.data, has.ctypes.data, len(rank), os.fsencode(path))
+    if rc != 0:
+        raise BadgerHipError(rc, "bdg_write_assignments(%s): %d reads, %d ids" % (path, len(rank), len(ids)))
 
 
 def format_rows(ch, recs):

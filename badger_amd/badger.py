@@ -15,7 +15,7 @@ from traceback import print_exc
 
 from . import _native
 from .barcode_graph import BarcodeGraph
-from .extract_raw_barcodes import BARCODE_CALLING_MODES, extract_read_ids, is_native_input
+from .extract_raw_barcodes import BARCODE_CALLING_MODES, is_native_input
 
 logger = logging.getLogger("BarcodeGraph")
 
@@ -106,6 +106,7 @@ def main(args):
 
     from .stage2 import Stage2, observed_from_strings
     st2 = Stage2(args.threshold, device=args.device)
+    from_device = None
     if args.reads.endswith("tsv"):
         read_assignment, _ = import_tsv(args.reads, bc_len)
         logger.info("Imported barcodes from file")
@@ -118,25 +119,34 @@ def main(args):
         # FASTA / FASTQ / SAM / BAM: the records of every chunk stay on the device (stage 1 -> stage 2 hand-off without host
         # strings): counting and the edge build run there, the host only gets the per-read ranks for the output file.
         # Like the reference (:112-117) one thread keeps every SAM / BAM record, several skip secondary / supplementary ones.
-        import numpy as np
         ctx = _native.default_context(args.device)
         ctx.extract_keep_records(True)
-        read_ids = extract_read_ids(args.reads, args.data_type, device=args.device, skip_secondary=args.threads != 1,
-                                    threads=args.threads if args.threads > 1 else 0)
+        logger.info("Extracting from " + args.reads)
+        read_ids = _native.IdStore()
+        umi_len = BARCODE_CALLING_MODES[args.data_type](device=args.device).UMI_LEN_10X
+        try:
+            _native.stage1_collect(ctx, args.reads, umi_len, read_ids, threads=args.threads if args.threads > 1 else 0,
+                                   skip_secondary=args.threads != 1)
+        except BaseException:
+            ctx.extract_keep_records(False)
+            raise
+        logger.info("Finished barcode extraction")
         logger.info("Initializing Graph")
         st2.count_device(ctx)
         st2.build_edges(ctx, on_device=True)
-        host = ctx.kept_records_to_host()
-        usable = (host["valid"] == 1) & ((host["flags"] & _native.FLAG_RANK_OK) != 0)
-        obs_rank = host["bc_rank"].astype(np.uint32)
-        ctx.extract_keep_records(False)
+        from_device = ctx
     else:
         logger.error("Unknown file format " + args.reads)
         sys.exit(-1)
     logger.info("Graph construction done")
     st2.cluster(true_barcodes, barcode_list, args.n_cells, bc_len, args.interval)
     logger.info("Clustering done")
-    st2.output_file(read_ids, obs_rank, usable, args.output, args.high_sens)
+    if from_device is not None:
+        st2.output_file_from_device(read_ids, from_device, args.output, args.high_sens)
+        from_device.extract_keep_records(False)
+    else:
+        st2.output_file(read_ids, obs_rank, usable, args.output, args.high_sens)
+    st2.release_device()
     print(st2.disconnected())          # "disconnected" count (reference :131-132)
 
 

@@ -18,6 +18,8 @@ int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, int, uint32_t, uin
 int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*);
 int bdg_distinct_launch(bdg_ctx*, const bdg_extract_rec*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 int bdg_rows_of_launch(bdg_ctx*, const uint32_t*, uint32_t, const uint32_t*, uint64_t, uint32_t, uint32_t*);
+int bdg_cluster_launch(bdg_ctx*, const uint32_t*, const uint32_t*, uint64_t, uint32_t, int32_t*);
+int bdg_assign_reads_launch(bdg_ctx*, const bdg_extract_rec*, uint64_t, const uint32_t*, uint32_t, const uint32_t*, const uint8_t*, uint32_t*, uint8_t*);
 
 static thread_local std::string g_err_noctx;
 
@@ -145,7 +147,8 @@ int bdg_mem_free(bdg_ctx* ctx, void* d_ptr)
     if (!ctx) return BDG_E_ARG;
     if (!d_ptr) return BDG_OK;
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));         // work that still uses the buffer
+    int rc = sync_all(ctx);                                      // work that still uses the buffer, on either stream
+    if (rc) return rc;
     BDG_HIP_TRY(ctx, hipFree(d_ptr));
     return BDG_OK;
 }
@@ -347,7 +350,7 @@ int bdg_extract_batch(bdg_ctx* ctx, const uint8_t* bases, const uint64_t* off, u
 static int pinned_reserve(bdg_ctx* ctx, void*& p, size_t& have, size_t want)
 {
     if (want <= have && p) return BDG_OK;
-    if (p) { BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(p); p = nullptr; have = 0; }
+    if (p) { int rc = sync_all(ctx); if (rc) return rc; (void)hipHostFree(p); p = nullptr; have = 0; }
     want += want / 4 + 4096;
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return bdg_fail(ctx, BDG_E_NOMEM, "hipHostMalloc failed"); }
@@ -504,6 +507,15 @@ int bdg_nearest16_set_algo(bdg_ctx* ctx, int algo)
     return BDG_OK;
 }
 
+uint64_t bdg_nearest16_index_bytes(bdg_ctx* ctx)
+{
+    if (!ctx || ctx->w_n == 0) return 0;
+    uint64_t b = 0;
+    if (ctx->w_probe_ready) b += ctx->w_pent.bytes;
+    if (ctx->w_delins_ready) b += ctx->w_delmap.bytes + ctx->w_dv.bytes;
+    return b;
+}
+
 int bdg_nearest16_dev(bdg_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t max_ed,
                       uint32_t* d_best_idx, uint8_t* d_best_ed, uint16_t* d_n_ties)
 {
@@ -651,6 +663,23 @@ int bdg_rows_of_dev(bdg_ctx* ctx, const uint32_t* d_sorted, uint32_t n, const ui
     if (m > (1ull << 39)) return bdg_fail(ctx, BDG_E_ARG, "too many values");
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return bdg_rows_of_launch(ctx, d_sorted, n, d_values, m, stride_words, d_rows);
+}
+
+int bdg_cluster_dev(bdg_ctx* ctx, const uint32_t* d_ea, const uint32_t* d_eb, uint64_t m, uint32_t nu, int32_t* d_owner)
+{
+    if (!ctx) return BDG_E_ARG;
+    if ((nu && !d_owner) || (m && (!d_ea || !d_eb))) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bdg_cluster_launch(ctx, d_ea, d_eb, m, nu, d_owner);
+}
+
+int bdg_assign_reads_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint64_t n, const uint32_t* d_uniq, uint32_t nu,
+                         const uint32_t* d_assigned, const uint8_t* d_has, uint32_t* d_out_rank, uint8_t* d_out_has)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (n && (!d_recs || !d_out_rank || !d_out_has || (nu && (!d_uniq || !d_assigned || !d_has)))) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bdg_assign_reads_launch(ctx, d_recs, n, d_uniq, nu, d_assigned, d_has, d_out_rank, d_out_has);
 }
 
 }  // extern "C"

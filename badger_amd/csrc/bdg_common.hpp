@@ -82,7 +82,8 @@ struct bdg_ctx {
     DevBuf w_dv;         // the same variants as (variant, sorted-whitelist position) pairs sorted by variant, + directory
     uint32_t w_n = 0;        // 0: no whitelist loaded (set last, after every table of the list is complete)
     uint64_t w_fp = 0;       // fingerprint of the caller's list: the same list again is not rebuilt
-    bool w_probe_ready = false;                       // pair tables / deletion variants built (on first use of the probe path)
+    bool w_probe_ready = false;                       // pair tables built (on first use of the probe path)
+    bool w_delins_ready = false;                      // deletion-variant maps and entries built (first probe call with max_ed = 2)
     std::vector<uint32_t> w_host_sorted, w_host_order;  // host copy the probe index is built from
     int w_pbits = 0, w_bbits = 0;
     bool w_identity = false;
@@ -95,6 +96,7 @@ struct bdg_ctx {
     DevBuf g_sig;        // uint32 [n] letter-count signatures
     DevBuf g_tmp0, g_tmp1, g_cnt;
     DevBuf g_qj;         // q-gram join: sorted (six-mer, row) entries, inverse positions, bucket and slice starts
+    int g_cus = 0, g_qj_per_cu = 0, g_qjw_per_cu = 0, g_qjw_variant = 0;   // compute units and resident blocks per unit of the join kernels (asked once)
 };
 
 #define BDG_HIP_TRY(ctx, expr)                                                           \

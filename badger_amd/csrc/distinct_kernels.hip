@@ -118,3 +118,102 @@ int bdg_distinct_launch(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
     BDG_HIP_TRY(ctx, hipGetLastError());
     return BDG_OK;
 }
+
+// ---------------------------------------------------------------------------
+// The two clustering levels of BarcodeGraph.cluster (barcode_graph.py:279-301) over the edge array that is already on the
+// device.  The reference walks breadth-first from every centre, two levels deep, and marks a barcode reached by two
+// different centres on one level as nobody's - whatever the visiting order (the order-independence
+// argument) - so a level is: every edge (u, v), u expanding on this level and v still unclustered, offers owner[u] to v;
+// v takes it if every offer on this level names the same centre.  "The same" = minimum equals maximum: two atomics per
+// offer, no sort, no set.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int32_t OWN_NONE = -2, OWN_CONFLICT = -1;
+
+__global__ __launch_bounds__(256)
+void k_cluster_offer(const uint32_t* __restrict__ ea, const uint32_t* __restrict__ eb, uint64_t m, int level,
+                     const int32_t* __restrict__ owner, const uint8_t* __restrict__ reached,
+                     int32_t* __restrict__ lo, int32_t* __restrict__ hi)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * 256ull + threadIdx.x;
+    if (e >= m) return;
+    const uint32_t a = ea[e], b = eb[e];
+    const int32_t oa = owner[a], ob = owner[b];
+    // level 1: the centres expand (owner[c] == c); level 2: the barcodes level 1 gave to exactly one centre
+    const bool xa = level == 1 ? oa == (int32_t)a : reached[a] != 0;
+    const bool xb = level == 1 ? ob == (int32_t)b : reached[b] != 0;
+    if (xa && ob == OWN_NONE) { atomicMin(&lo[b], oa); atomicMax(&hi[b], oa); }
+    if (xb && oa == OWN_NONE) { atomicMin(&lo[a], ob); atomicMax(&hi[a], ob); }
+}
+
+__global__ __launch_bounds__(256)
+void k_cluster_apply(uint32_t nu, int32_t* __restrict__ owner, uint8_t* __restrict__ reached,
+                     int32_t* __restrict__ lo, int32_t* __restrict__ hi)
+{
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= nu) return;
+    const int32_t l = lo[v], h = hi[v];
+    uint8_t r = 0;
+    if (h >= 0) { owner[v] = l == h ? l : OWN_CONFLICT; r = l == h ? 1 : 0; }
+    reached[v] = r;
+    lo[v] = 0x7FFFFFFF; hi[v] = -1;
+}
+
+__global__ __launch_bounds__(256)
+void k_cluster_init(uint32_t nu, uint8_t* __restrict__ reached, int32_t* __restrict__ lo, int32_t* __restrict__ hi)
+{
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= nu) return;
+    reached[v] = 0; lo[v] = 0x7FFFFFFF; hi[v] = -1;
+}
+
+// per read: position of its barcode in the distinct array -> what that barcode was corrected to (assign_by_cluster +
+// output_file, barcode_graph.py:322-329,388-410): rank and "has one"
+__global__ __launch_bounds__(256)
+void k_assign_reads(const bdg_extract_rec* __restrict__ recs, uint64_t n, const uint32_t* __restrict__ uniq, uint32_t nu,
+                    const uint32_t* __restrict__ assigned, const uint8_t* __restrict__ has,
+                    uint32_t* __restrict__ out_rank, uint8_t* __restrict__ out_has)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256ull + threadIdx.x;
+    if (i >= n) return;
+    const bdg_extract_rec r = recs[i];
+    uint32_t rank = 0; uint8_t ok = 0;
+    if (r.valid && (r.flags & BDG_FLAG_RANK_OK)) {
+        uint32_t lo = 0, hi = nu;
+        while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (uniq[mid] < r.bc_rank) lo = mid + 1; else hi = mid; }
+        if (lo < nu && uniq[lo] == r.bc_rank && has[lo]) { rank = assigned[lo]; ok = 1; }
+    }
+    out_rank[i] = rank; out_has[i] = ok;
+}
+
+}  // namespace
+
+int bdg_cluster_launch(bdg_ctx* ctx, const uint32_t* d_ea, const uint32_t* d_eb, uint64_t m, uint32_t nu, int32_t* d_owner)
+{
+    if (nu == 0) return BDG_OK;
+    int rc;
+    if ((rc = bdg_reserve(ctx, ctx->g_tmp0, (size_t)nu * 9 + 256))) return rc;
+    auto* lo = static_cast<int32_t*>(ctx->g_tmp0.p);
+    auto* hi = lo + nu;
+    auto* reached = reinterpret_cast<uint8_t*>(hi + nu);
+    hipStream_t st = ctx->stream;
+    ScopedKernelTimer tm(ctx, "k_cluster_levels");
+    hipLaunchKernelGGL(k_cluster_init, dim3((nu + 255) / 256), dim3(256), 0, st, nu, reached, lo, hi);
+    for (int level = 1; level <= 2; ++level) {
+        if (m) hipLaunchKernelGGL(k_cluster_offer, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_ea, d_eb, m, level, d_owner, reached, lo, hi);
+        hipLaunchKernelGGL(k_cluster_apply, dim3((nu + 255) / 256), dim3(256), 0, st, nu, d_owner, reached, lo, hi);
+    }
+    BDG_HIP_TRY(ctx, hipGetLastError());
+    return BDG_OK;
+}
+
+int bdg_assign_reads_launch(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint64_t n, const uint32_t* d_uniq, uint32_t nu,
+                            const uint32_t* d_assigned, const uint8_t* d_has, uint32_t* d_out_rank, uint8_t* d_out_has)
+{
+    if (n == 0) return BDG_OK;
+    ScopedKernelTimer tm(ctx, "k_assign_reads");
+    hipLaunchKernelGGL(k_assign_reads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_recs, n, d_uniq, nu, d_assigned, d_has, d_out_rank, d_out_has);
+    BDG_HIP_TRY(ctx, hipGetLastError());
+    return BDG_OK;
+}

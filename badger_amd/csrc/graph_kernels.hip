@@ -30,6 +30,12 @@ namespace {
 
 constexpr int GT = 2048;     // column tile
 
+__device__ __forceinline__ uint32_t lanes_below_u64(unsigned long long m, int lane)     // set bits of m in the lanes below this one
+{
+    (void)lane;
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 __device__ __forceinline__ uint32_t letter_sig(uint32_t r)
 {
     // byte k = number of bases with rank code k
@@ -133,7 +139,8 @@ __device__ __forceinline__ void edge_push(bool want, uint32_t a, uint32_t b, uin
     }
     n += cnt;
 }
-// block-wide, every thread: one reservation for the four waves' stages
+// block-wide, every thread: one reservation for the waves' stages (NW waves per block)
+template <int NW = 4>
 __device__ __forceinline__ void edge_finish(EdgeStage* stages, uint32_t n, uint32_t* s_cnt, unsigned long long* s_base,
                                             bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* n_edges)
 {
@@ -141,7 +148,9 @@ __device__ __forceinline__ void edge_finish(EdgeStage* stages, uint32_t n, uint3
     if (lane == 0) s_cnt[wv] = n;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += s_cnt[w];
         *s_base = tot ? atomicAdd(n_edges, (unsigned long long)tot) : 0ull;
     }
     __syncthreads();
@@ -626,6 +635,184 @@ void k_graph_qjoin(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
     edge_finish(s_edges, ne, s_ecnt, &s_ebase, out, cap, n_edges);
 }
 
+// ---------------------------------------------------------------------------
+// k_graph_qjoin_w: the same join with ONE WAVE per row and no block barrier at all (round 3; k_graph_qjoin above spent its
+// time in three __syncthreads and a 32 KB clear per slice of ~900 entries).  A wave keeps S(i, j) for a slice of WQ rows in
+// WQ bytes of LDS that only it touches, walks the row's 11 bucket tails with 11 cursors - a tail is sorted by row, so the
+// entries of a slice are the next ones behind the cursor: every lane loads entry cursor + lane of every tail (11 coalesced
+// loads in flight), a ballot says how many of them belong to the slice - and needs neither the per-slice bounds table nor a
+// search.  The loads of the NEXT slice are issued before the counters of this one are touched (the cursors move as soon as
+// the ballots are in), the counters a lane has touched are cleared by that lane (a byte store each) instead of clearing the
+// slice, and slices without entries are skipped (the next slice is the one of the smallest unconsumed row).  Rows whose
+// counter reaches T are listed per wave and verified 64 at a time.
+// ---------------------------------------------------------------------------
+constexpr uint32_t QW_HCAP = 128;                // listed rows per wave
+constexpr uint32_t QW_SENT = 0x0FFFFFFFu;        // "no entry": a row beyond every slice (rows are < 2^25)
+
+// dmin3 with the pattern's four match vectors in named registers (an array here ends up in scratch memory: the compiler
+// turns the letter select into an indexed load)
+__device__ __forceinline__ uint32_t dmin3_peq4(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t b)
+{
+    uint32_t pv = 0xFFFFu, mv = 0u, score = 16u, score15 = 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t c = (b >> (2 * j)) & 3u;
+        const uint32_t lo = (c & 1u) ? p1 : p0, hi = (c & 1u) ? p3 : p2;
+        const uint32_t eq = (c & 2u) ? hi : lo;
+        const uint32_t xv = eq | mv;
+        const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+        uint32_t ph = mv | ~(xh | pv);
+        uint32_t mh = pv & xh;
+        score += (ph >> 15) & 1u;
+        score -= (mh >> 15) & 1u;
+        ph = (ph << 1) | 1u;
+        mh = mh << 1;
+        pv = mh | ~(xv | ph);
+        mv = ph & xv;
+        if (j == 14) score15 = score;
+    }
+    const uint32_t d1516 = score - ((pv >> 15) & 1u) + ((mv >> 15) & 1u);
+    uint32_t d = score < score15 ? score : score15;
+    return d < d1516 ? d : d1516;
+}
+
+// ROWS: rows per slice = bytes of LDS counters per wave; WAVES: waves per block (the block's static LDS stays below 64 KB);
+// T_GE2: T >= 2, which lets a spare word (always 0) stand in for "no entry" without a check
+template <uint32_t ROWS, int WAVES, bool T_GE2>
+__global__ __launch_bounds__(64 * WAVES)
+void k_graph_qjoin_w(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_begin, uint32_t row_end,
+                     const uint32_t* __restrict__ vals, const uint32_t* __restrict__ pos_of, const uint32_t* __restrict__ bucket_off,
+                     uint32_t thr, int32_t T,
+                     bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges)
+{
+    // per wave: the counters, 64 spare words behind them (lanes without an entry add 0 / store there: every LDS operation
+    // below is unconditional, so the compiler issues a slice's eleven of each kind together and waits once), the list
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[WAVES][ROWS / 4 + 64];
+    __shared__ uint32_t s_hit[WAVES][QW_HCAP];
+    __shared__ EdgeStage s_edges[WAVES];
+    __shared__ uint32_t s_ecnt[WAVES];
+    __shared__ unsigned long long s_ebase;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* const cnt = s_cnt[wv];
+    uint8_t* const cnt8 = reinterpret_cast<uint8_t*>(cnt);
+    uint32_t* const hits = s_hit[wv];
+    const uint32_t spare = ROWS + 4u * (uint32_t)lane;             // byte offset of this lane's spare word
+    uint32_t ne = 0;
+    for (uint32_t k = (uint32_t)lane; k < ROWS / 4 + 64; k += 64u) cnt[k] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t Tc = T < 1 ? 1u : (uint32_t)T;
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (uint32_t)WAVES + (uint32_t)wv), nwaves = gridDim.x * (uint32_t)WAVES;
+    const uint32_t m_last = n * (uint32_t)QJ_NQ - 1u;              // last entry of vals: where a lane without an entry loads from
+
+    for (uint32_t i = row_begin + wave_id; i < row_end; i += nwaves) {
+        const uint32_t a = __builtin_amdgcn_readfirstlane(ranks[i]);
+        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t c = (a >> (2 * u)) & 3u;
+            p0 |= (c == 0u ? 1u : 0u) << u; p1 |= (c == 1u ? 1u : 0u) << u;
+            p2 |= (c == 2u ? 1u : 0u) << u; p3 |= (c == 3u ? 1u : 0u) << u;
+        }
+        uint32_t nh = 0;
+        auto flush_hits = [&]() {
+            for (uint32_t h0 = 0; h0 < nh; h0 += 64u) {
+                const uint32_t h = h0 + (uint32_t)lane;
+                const bool on = h < nh;
+                const uint32_t b = ranks[on ? hits[h] : i];
+                const uint32_t d = on ? dmin3_peq4(p0, p1, p2, p3, b) : 99u;
+                edge_push(on && d <= thr, a, b, d, s_edges[wv], ne, lane, out, cap, n_edges);
+            }
+            nh = 0;
+            __builtin_amdgcn_wave_barrier();
+        };
+        // the 11 tails: behind row i's own entry of each of its six-mers, to the end of that six-mer's bucket
+        uint32_t my_cur = 0, my_end = 0;
+        if (lane < QJ_NQ) { my_cur = pos_of[(size_t)i * QJ_NQ + lane] + 1u; my_end = bucket_off[((a >> (2 * lane)) & 0xFFFu) + 1u]; }
+        uint32_t cur[QJ_NQ], end[QJ_NQ];
+#pragma unroll
+        for (int b = 0; b < QJ_NQ; ++b) { cur[b] = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, b); end[b] = (uint32_t)__builtin_amdgcn_readlane((int)my_end, b); }
+        uint32_t jv[QJ_NQ];
+        uint32_t base_row = QW_SENT;                                   // the slice starts at the smallest row not yet counted
+        {
+            uint32_t raw[QJ_NQ];
+#pragma unroll
+            for (int b = 0; b < QJ_NQ; ++b) { const uint32_t t = cur[b] + (uint32_t)lane; raw[b] = vals[t < m_last ? t : m_last]; }
+#pragma unroll
+            for (int b = 0; b < QJ_NQ; ++b) {
+                jv[b] = cur[b] + (uint32_t)lane < end[b] ? raw[b] >> 4 : QW_SENT;
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)jv[b], 0);
+                base_row = f < base_row ? f : base_row;
+            }
+        }
+        // A slice is [base_row, slice_end): at most ROWS rows, and cut short where a tail has more entries in it than the 64
+        // loaded (then the slice ends at that tail's last loaded row, whose entries wait for the next slice): every entry
+        // of a slice is in registers when it is counted, so the lanes can clear exactly what they touched.  A tail holds a
+        // row at most 11 times, so a slice always gets past its first row.
+        while (base_row != QW_SENT) {
+            uint32_t slice_end = base_row + ROWS;
+#pragma unroll
+            for (int b = 0; b < QJ_NQ; ++b) { const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)jv[b], 63); slice_end = l < slice_end ? l : slice_end; }
+            uint32_t c[QJ_NQ], next_min = QW_SENT;
+#pragma unroll
+            for (int b = 0; b < QJ_NQ; ++b) {
+                c[b] = (uint32_t)__popcll(__ballot(jv[b] < slice_end));         // (sorted by row: the first c[b] lanes; lane 63 never)
+                cur[b] += c[b];
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)jv[b], (int)c[b]);
+                next_min = f < next_min ? f : next_min;
+            }
+            // what comes next is known: its loads fly while this slice is counted
+            uint32_t raw[QJ_NQ];
+#pragma unroll
+            for (int b = 0; b < QJ_NQ; ++b) { const uint32_t t = cur[b] + (uint32_t)lane; raw[b] = vals[t < m_last ? t : m_last]; }
+            uint32_t old[QJ_NQ], boff[QJ_NQ];
+#pragma unroll
+            for (int b = 0; b < QJ_NQ; ++b) {
+                const bool on = (uint32_t)lane < c[b] && jv[b] > i;               // (j == i: row i's own repeat of the six-mer)
+                boff[b] = on ? jv[b] - base_row : spare;
+                old[b] = atomicAdd(&cnt[boff[b] >> 2], on ? 1u << ((boff[b] & 3u) * 8u) : 0u);
+            }
+            uint32_t hitmask = 0;
+#pragma unroll
+            for (int b = 0; b < QJ_NQ; ++b) {                                      // this entry lifts S(i, j) to T: list j
+                const bool lifts = __builtin_amdgcn_ubfe(old[b], (boff[b] & 3u) * 8u, 8u) == Tc - 1u;
+                hitmask |= (lifts && (T_GE2 || boff[b] < ROWS)) ? 1u << b : 0u;
+            }
+            if (__ballot(hitmask != 0u)) {
+                // listed rows go to the wave's list in rounds of what it still holds (one round unless a slice lists more than
+                // QW_HCAP rows): lane l writes its hits at the positions its prefix count gives
+                const uint32_t mine = (uint32_t)__popc(hitmask);
+                const uint32_t incl = wave_incl_scan(mine);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                uint32_t taken = 0;
+                for (;;) {
+                    const uint32_t room = QW_HCAP - nh;
+                    uint32_t k = incl - mine;                                      // index of this lane's next hit among the iteration's hits
+#pragma unroll
+                    for (int b = 0; b < QJ_NQ; ++b) {
+                        if ((hitmask >> b) & 1u) {
+                            if (k >= taken && k - taken < room) hits[nh + k - taken] = jv[b];
+                            ++k;
+                        }
+                    }
+                    const uint32_t now = total - taken < room ? total - taken : room;
+                    nh += now; taken += now;
+                    __builtin_amdgcn_wave_barrier();
+                    if (taken == total) break;
+                    flush_hits();
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < QJ_NQ; ++b) cnt8[boff[b]] = 0;                    // every lane clears what it touched
+#pragma unroll
+            for (int b = 0; b < QJ_NQ; ++b) jv[b] = cur[b] + (uint32_t)lane < end[b] ? raw[b] >> 4 : QW_SENT;
+            base_row = next_min;
+        }
+        flush_hits();
+    }
+    __syncthreads();
+    edge_finish<WAVES>(s_edges, ne, s_ecnt, &s_ebase, out, cap, n_edges);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -647,6 +834,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
         const size_t m = (size_t)n * QJ_NQ;
         const uint32_t W = QJ_W;
         const uint32_t G = (n + W - 1) / W;
+        const bool closed_form = ctx->graph_algo == 4;
         size_t t_sort = 0;
         uint32_t* nul = nullptr;
         BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, nul, nul, nul, nul, (int)m, 0, 12, st));
@@ -665,20 +853,46 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             hipLaunchKernelGGL(k_qj_emit, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, d_ranks, n, k_in, v_in);
             BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(temp, t_sort, k_in, k_out, v_in, v_out, (int)m, 0, 12, st));
             hipLaunchKernelGGL(k_qj_index, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, k_out, v_out, (uint32_t)m, pos_of, bucket_off);
-            hipLaunchKernelGGL(k_qj_split, dim3((4096u * (G + 1) + 255) / 256), dim3(256), 0, st, v_out, bucket_off, G, W, split);
+            if (closed_form) hipLaunchKernelGGL(k_qj_split, dim3((4096u * (G + 1) + 255) / 256), dim3(256), 0, st, v_out, bucket_off, G, W, split);
         }
-        {
-            ScopedKernelTimer tm(ctx, "k_graph_qjoin");
-            auto kern = k_graph_qjoin<QJ_W>;
-            int per_cu = 0;
-            BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0));
-            if (per_cu < 1) per_cu = 1;
+        if (!ctx->g_cus) {                                           // once per context: resident grids are sized from these
             hipDeviceProp_t prop;
             BDG_HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
-            uint32_t grid = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;      // resident grid, rows interleaved
+            int per_cu = 0, per_cu_w = 0;
+            BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_graph_qjoin<QJ_W>, 256, 0));
+            ctx->g_qjw_variant = 0;
+            if (const char* e = getenv("BADGER_AMD_QJ_VARIANT")) ctx->g_qjw_variant = atoi(e);      // (for measurements: slice size per wave)
+            if (ctx->g_qjw_variant < 0 || ctx->g_qjw_variant > 3) ctx->g_qjw_variant = 0;
+            switch (ctx->g_qjw_variant) {
+            case 1:  BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<16384, 2, true>, 128, 0)); break;
+            case 2:  BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<32768, 1, true>, 64, 0)); break;
+            case 3:  BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<4096, 4, true>, 256, 0)); break;
+            default: BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<8192, 4, true>, 256, 0)); break;
+            }
+            ctx->g_cus = prop.multiProcessorCount; ctx->g_qj_per_cu = per_cu < 1 ? 1 : per_cu; ctx->g_qjw_per_cu = per_cu_w < 1 ? 1 : per_cu_w;
+        }
+        if (closed_form) {
+            ScopedKernelTimer tm(ctx, "k_graph_qjoin");
+            uint32_t grid = (uint32_t)ctx->g_qj_per_cu * (uint32_t)ctx->g_cus;          // resident grid, rows interleaved
             if (grid > row_end - row_begin) grid = row_end - row_begin;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, d_ranks, n, row_begin, row_end, v_out, pos_of, split, G,
-                               thr, qgram_T, ctx->graph_algo == 4 ? 1 : 0, d_out, cap, reinterpret_cast<unsigned long long*>(d_n_edges));
+            hipLaunchKernelGGL(k_graph_qjoin<QJ_W>, dim3(grid), dim3(256), 0, st, d_ranks, n, row_begin, row_end, v_out, pos_of, split, G,
+                               thr, qgram_T, 1, d_out, cap, reinterpret_cast<unsigned long long*>(d_n_edges));
+        } else {
+            ScopedKernelTimer tm(ctx, "k_graph_qjoin");
+            const int var = ctx->g_qjw_variant;
+            const uint32_t waves = qgram_T < 2 ? 4u : (var == 1 ? 2u : (var == 2 ? 1u : 4u));
+            uint32_t grid = (uint32_t)ctx->g_qjw_per_cu * (uint32_t)ctx->g_cus;         // resident grid, one row per wave at a time, rows interleaved
+            const uint32_t want = (row_end - row_begin + waves - 1u) / waves;
+            if (grid > want) grid = want;
+            auto* ne = reinterpret_cast<unsigned long long*>(d_n_edges);
+#define BDG_QJW(ROWS, WAVES, GE2) hipLaunchKernelGGL((k_graph_qjoin_w<ROWS, WAVES, GE2>), dim3(grid), dim3(64 * WAVES), 0, st, d_ranks, n, \
+                                                     row_begin, row_end, v_out, pos_of, bucket_off, thr, qgram_T, d_out, cap, ne)
+            if (qgram_T < 2) BDG_QJW(8192, 4, false);
+            else if (var == 1) BDG_QJW(16384, 2, true);
+            else if (var == 2) BDG_QJW(32768, 1, true);
+            else if (var == 3) BDG_QJW(4096, 4, true);
+            else BDG_QJW(8192, 4, true);
+#undef BDG_QJW
         }
         BDG_HIP_TRY(ctx, hipGetLastError());
         return BDG_OK;

@@ -46,20 +46,60 @@
 
 namespace {
 
+// Pinned buffers are kept when a reader closes and handed to the next one (hipHostMalloc / hipHostFree of some tens of
+// 32 MB buffers are a sizeable part of a one-second run): a process-wide cache of at most PINNED_CACHE_MAX bytes, never
+// returned before the process ends.
+struct PinnedCache {
+    std::mutex mu;
+    std::vector<std::pair<void*, size_t>> idle;
+    std::vector<std::pair<void*, size_t>> live;          // size of every pinned buffer handed out
+    size_t idle_bytes = 0;
+    double alloc_s = 0; uint64_t allocs = 0, alloc_bytes = 0;      // hipHostMalloc calls so far (BADGER_AMD_INGEST_DEBUG prints them)
+};
+constexpr size_t PINNED_CACHE_MAX = size_t(3) << 30;
+PinnedCache& pinned_cache() { static PinnedCache* c = new PinnedCache(); return *c; }    // (leaked on purpose: no teardown order problems)
+
 void* pinned_alloc(size_t bytes, bool pinned)
 {
-    void* p = nullptr;
-    if (pinned) {
-        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) return p;
-        (void)hipGetLastError();
-        return nullptr;
+    if (!pinned) return malloc(bytes);
+    PinnedCache& pc = pinned_cache();
+    {
+        std::lock_guard<std::mutex> lk(pc.mu);
+        size_t best = pc.idle.size();
+        for (size_t i = 0; i < pc.idle.size(); ++i)
+            if (pc.idle[i].second >= bytes && pc.idle[i].second <= 2 * bytes + (1u << 20) && (best == pc.idle.size() || pc.idle[i].second < pc.idle[best].second)) best = i;
+        if (best != pc.idle.size()) {
+            const std::pair<void*, size_t> e = pc.idle[best];
+            pc.idle.erase(pc.idle.begin() + (long)best);
+            pc.idle_bytes -= e.second;
+            pc.live.push_back(e);
+            return e.first;
+        }
     }
-    return malloc(bytes);
+    void* p = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(pc.mu);
+    pc.live.emplace_back(p, bytes);
+    pc.alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); pc.allocs++; pc.alloc_bytes += bytes;
+    return p;
 }
 void pinned_free(void* p, bool pinned)
 {
     if (!p) return;
-    if (pinned) (void)hipHostFree(p); else free(p);
+    if (!pinned) { free(p); return; }
+    PinnedCache& pc = pinned_cache();
+    {
+        std::lock_guard<std::mutex> lk(pc.mu);
+        for (size_t i = 0; i < pc.live.size(); ++i) {
+            if (pc.live[i].first != p) continue;
+            const std::pair<void*, size_t> e = pc.live[i];
+            pc.live[i] = pc.live.back(); pc.live.pop_back();
+            if (pc.idle_bytes + e.second <= PINNED_CACHE_MAX) { pc.idle.push_back(e); pc.idle_bytes += e.second; return; }
+            break;
+        }
+    }
+    (void)hipHostFree(p);
 }
 
 template <typename T>
@@ -846,6 +886,7 @@ int bdg_ingest_open_ex(const char* path, const bdg_ingest_opts* o, bdg_ingest** 
     std::string err;
     if (!g->src.open(path, err)) { delete g; return BDG_E_ARG; }
     if (o->segment_bytes) g->src.seg_bytes = std::max<uint64_t>(o->segment_bytes, 64);
+    else if (const char* e = getenv("BADGER_AMD_SEGMENT_MB")) { const long mb = atol(e); if (mb > 0 && mb <= 4096) g->src.seg_bytes = (size_t)mb << 20; }
     g->src.bgzf_parallel = o->threads != 1;                  // 1: every compressed input as one sequential gzip stream (what gzip.open does)
     // pysam opens BAM and SAM by content; so does this, as far as the first bytes of an uncompressed file tell
     if (!g->src.compressed && (format == F_SAM || format == F_BAM))
@@ -921,6 +962,12 @@ void bdg_ingest_close(bdg_ingest* g)
     g->cv.notify_all();
     for (auto& w : g->workers) if (w.joinable()) w.join();
     if (g->assembler.joinable()) g->assembler.join();
+    if (getenv("BADGER_AMD_INGEST_DEBUG")) {
+        PinnedCache& pc = pinned_cache();
+        std::lock_guard<std::mutex> lk(pc.mu);
+        fprintf(stderr, "ingest: %llu pinned allocations, %.1f MB, %.3f s inside hipHostMalloc (summed over threads); %u reader threads, %zu segments\n",
+                (unsigned long long)pc.allocs, pc.alloc_bytes / 1e6, pc.alloc_s, g->n_workers, (size_t)g->next_seq);
+    }
     for (IngestChunk* c : g->all_chunks) {
         pinned_free(c->bases, g->pinned);
         free(c->off); free(c->ids); free(c->id_off);

@@ -434,16 +434,19 @@ static uint64_t wl_fingerprint(const uint32_t* wl, uint32_t nw)
     return h ? h : 1;
 }
 
-static int build_probe_index(bdg_ctx* ctx);
-
 int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
 {
     // the same list again (bdg_nearest16 is called per batch with the same centres): everything is still in place
     const uint64_t fp = nw ? wl_fingerprint(wl, nw) : 0;
-    if (nw && ctx->w_n == nw && ctx->w_fp == fp) return BDG_OK;
+    if (nw && ctx->w_n == nw && ctx->w_fp == fp && ctx->w_host_sorted.size() == nw) {
+        // (the fingerprint only says "probably": a collision must not match later queries against the old list)
+        bool same = true;
+        for (uint32_t i = 0; i < nw && same; ++i) same = wl[ctx->w_host_order[i]] == ctx->w_host_sorted[i];
+        if (same) return BDG_OK;
+    }
     // nothing is published until every table of the new list is complete: a failure below leaves "no whitelist loaded"
     if (ctx->aux_pending) { BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream)); ctx->aux_pending = false; }
-    ctx->w_n = 0; ctx->w_fp = 0; ctx->w_probe_ready = false;
+    ctx->w_n = 0; ctx->w_fp = 0; ctx->w_probe_ready = false; ctx->w_delins_ready = false;
     if (nw == 0) return BDG_OK;
     std::vector<uint32_t> order(nw);
     std::iota(order.begin(), order.end(), 0u);
@@ -481,10 +484,10 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
     return BDG_OK;
 }
 
-// The neighbourhood-probe index (pair tables, deletion-variant map and sorted variant pairs): ~180 MB of tables for
-// 737K entries.  Built when the probe path first runs on a whitelist, not by bdg_whitelist_load: a call with
-// max_ed > 2 or a forced scan never needs it.
-static int build_probe_index(bdg_ctx* ctx)
+// The neighbourhood-probe index, built when the probe path first needs it on a whitelist, not by bdg_whitelist_load (a call with
+// max_ed > 2, a forced scan or a small job never needs it): the block-pair tables for pass 1 (25 + 50 MB at 737 K entries),
+// and - only once a call with max_ed = 2 reaches pass 2 - the deletion-variant maps and the sorted variant entries.
+static int build_pair_tables(bdg_ctx* ctx)
 {
     const uint32_t nw = ctx->w_n;
     const std::vector<uint32_t>& srt = ctx->w_host_sorted;
@@ -518,10 +521,18 @@ static int build_probe_index(bdg_ctx* ctx)
         }
     }
     if ((rc = bdg_reserve(ctx, ctx->w_pent, sizeof(uint32_t) * (prank.size() + pidx.size())))) return rc;
-    if ((rc = bdg_reserve(ctx, ctx->w_delmap, size_t(4) << 27))) return rc;          // four copies of 2^30 bits
     ctx->w_pwords = prank.size();
     BDG_HIP_TRY(ctx, hipMemcpy(ctx->w_pent.p, prank.data(), sizeof(uint32_t) * prank.size(), hipMemcpyHostToDevice));
     BDG_HIP_TRY(ctx, hipMemcpy(static_cast<uint32_t*>(ctx->w_pent.p) + prank.size(), pidx.data(), sizeof(uint32_t) * pidx.size(), hipMemcpyHostToDevice));
+    ctx->w_probe_ready = true;
+    return BDG_OK;
+}
+
+static int build_delins_index(bdg_ctx* ctx)
+{
+    const uint32_t nw = ctx->w_n;
+    int rc;
+    if ((rc = bdg_reserve(ctx, ctx->w_delmap, size_t(4) << 27))) return rc;          // four copies of 2^30 bits
     BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->w_delmap.p, 0, size_t(4) << 27, ctx->stream));
     {
         // deletion variants: map bits + (variant, entry) pairs sorted by variant on the device + directory
@@ -555,9 +566,15 @@ static int build_probe_index(bdg_ctx* ctx)
         BDG_HIP_TRY(ctx, e);
     }
     BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->w_probe_ready = true;
+    ctx->w_delins_ready = true;
     return BDG_OK;
 }
+
+// Pair evaluations below which the exhaustive scan is taken when the probe index does not exist yet: building the index costs
+// tens of milliseconds (and up to 0.9 GB of tables), the scan does about 3 x 10^11 pair evaluations a second.  Stage 2's
+// --high_sens pass (a few hundred thousand unassigned barcodes against ~5,000 centres, barcode_graph.py:370-385) stays far
+// below it; a whitelist-sized list (737 K entries) crosses it with 5,500 queries.
+constexpr uint64_t SCAN_PAIR_EVALS_MAX = 4000000000ull;
 
 int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t qstride, int recs, uint32_t nq, uint32_t max_ed,
                          uint32_t* d_best_idx, uint8_t* d_best_ed, uint16_t* d_n_ties)
@@ -567,7 +584,10 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t qstride, in
     hipStream_t st = ctx->launch_stream ? ctx->launch_stream : ctx->stream;
     const auto* srt = static_cast<const uint32_t*>(ctx->w_sorted.p);
     const auto* org = static_cast<const uint32_t*>(ctx->w_orig.p);
-    const bool probe = ctx->n16_algo == 2 || (ctx->n16_algo == 0 && max_ed <= 2);
+    // automatic: the probe path when it applies (max_ed <= 2) and either its index exists already or the job is large enough to
+    // pay for building it
+    const bool built = ctx->w_probe_ready && (max_ed < 2 || ctx->w_delins_ready);
+    const bool probe = ctx->n16_algo == 2 || (ctx->n16_algo == 0 && max_ed <= 2 && (built || (uint64_t)ctx->w_n * nq > SCAN_PAIR_EVALS_MAX));
     if (ctx->n16_algo == 2 && max_ed > 2) return bdg_fail(ctx, BDG_E_ARG, "probe path needs max_ed <= 2");
     if (!probe) {
         ScopedKernelTimer tm(ctx, "k_nearest_scan");
@@ -577,7 +597,8 @@ int bdg_nearest16_launch(bdg_ctx* ctx, const uint32_t* d_q, uint32_t qstride, in
         return BDG_OK;
     }
     int rc;
-    if (!ctx->w_probe_ready && (rc = build_probe_index(ctx))) return rc;
+    if (!ctx->w_probe_ready && (rc = build_pair_tables(ctx))) return rc;
+    if (max_ed >= 2 && !ctx->w_delins_ready && (rc = build_delins_index(ctx))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->n_list, sizeof(uint32_t) * (2ull * LSH + 1ull) * nq))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->n_counters, NCTR_BYTES))) return rc;
     auto* list2 = static_cast<uint2*>(ctx->n_list.p);                          // LSH segments of nq {index, query} entries

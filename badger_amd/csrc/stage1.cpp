@@ -59,8 +59,17 @@ uint64_t rows_bound(const bdg_ingest_chunk* ch, const bdg_extract_rec* recs, uin
 char* write_rows(const bdg_ingest_chunk* ch, const bdg_extract_rec* recs, char* o, uint64_t g0, uint32_t header_every,
                  const char* header, size_t header_len, RowStats& st)
 {
+    constexpr uint32_t AHEAD = 12;              // a row needs one or two lines of its read's bases, nowhere near the last row's: ask early
     for (uint32_t i = 0; i < ch->n; ++i) {
         if (header_every && (g0 + i) % header_every == 0) { memcpy(o, header, header_len); o += header_len; *o++ = '\n'; }
+        if (i + AHEAD < ch->n) {
+            const bdg_extract_rec& f = recs[i + AHEAD];
+            if (f.valid) {
+                const uint64_t a = ch->off[i + AHEAD], b = ch->off[i + AHEAD + 1];
+                const uint8_t* q = (f.flags & BDG_FLAG_REV) ? ch->bases + b - 1 - (uint64_t)std::min<int64_t>(f.umi_end, (int64_t)(b - a)) : ch->bases + a + (uint64_t)std::max(f.bc_start, 0);
+                __builtin_prefetch(q); __builtin_prefetch(q + 40);
+            }
+        }
         const bdg_extract_rec& r = recs[i];
         const uint8_t* seq = ch->bases + ch->off[i];
         const int64_t L = (int64_t)(ch->off[i + 1] - ch->off[i]);
@@ -214,7 +223,8 @@ int bdg_stage1_run(bdg_ctx* const* ctxs, uint32_t n_ctx, const char* in_path, co
     res->first_polyt = res->first_r1 = res->bad_read = ~0ull;
     if (o->umi_len == 0 || o->umi_len > 64) return bdg_fail(c0, BDG_E_ARG, "umi_len out of range");
     const double t_start = now_s();
-    const uint32_t fthreads = o->format_threads ? std::min(o->format_threads, 32u) : 3u;
+    uint32_t fthreads = o->format_threads ? std::min(o->format_threads, 32u) : 4u;
+    if (!o->format_threads) if (const char* e = getenv("BADGER_AMD_FORMAT_THREADS")) { const long v = atol(e); if (v > 0 && v <= 32) fthreads = (uint32_t)v; }
     const uint32_t per_ctx = 2;                                  // chunks in flight per context (BDG_SLOTS >= 2)
     bdg_ingest_opts io;
     memset(&io, 0, sizeof(io));
@@ -290,7 +300,9 @@ int bdg_stage1_run(bdg_ctx* const* ctxs, uint32_t n_ctx, const char* in_path, co
     // rows of the chunks before a failure are in the file, like in the reference's loop
     if (rc == BDG_OK && o->header_every && g0 % o->header_every == 0) ok_io = write_all(P.fd, (P.header + "\n").data(), P.header.size() + 1) && ok_io;
     if (::close(P.fd) != 0) ok_io = false;
+    const double t_close0 = now_s();
     bdg_ingest_close(P.ing);
+    if (getenv("BADGER_AMD_INGEST_DEBUG")) fprintf(stderr, "stage1: reader closed in %.3f s\n", now_s() - t_close0);
     res->reads = P.total.reads; res->barcodes = P.total.bc; res->polyt = P.total.pt; res->r1 = P.total.r1;
     res->first_polyt = P.total.first_pt; res->first_r1 = P.total.first_r1; res->bad_read = bad_read;
     res->chunks = k; res->out_bytes = P.out_bytes;
@@ -299,6 +311,122 @@ int bdg_stage1_run(bdg_ctx* const* ctxs, uint32_t n_ctx, const char* in_path, co
     if (rc) return bdg_fail(c0, rc, err);
     if (!ok_io || P.write_failed) return bdg_fail(c0, BDG_E_ARG, std::string("write error on ") + out_path);
     return BDG_OK;
+}
+
+// ---- stage 2's read-side plumbing ------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct bdg_idstore {
+    std::vector<char> text;
+    std::vector<uint64_t> off{ 0 };
+};
+
+extern "C" {
+
+bdg_idstore* bdg_idstore_new(void) { return new bdg_idstore(); }
+void bdg_idstore_free(bdg_idstore* s) { delete s; }
+uint64_t bdg_idstore_count(const bdg_idstore* s) { return s ? s->off.size() - 1 : 0; }
+
+int bdg_idstore_append(bdg_idstore* s, const char* ids, const uint64_t* off, uint64_t n)
+{
+    if (!s || (n && (!ids || !off))) return BDG_E_ARG;
+    if (!n) return BDG_OK;
+    const uint64_t lo = off[0], bytes = off[n] - lo, base = s->text.size();
+    s->text.insert(s->text.end(), ids + lo, ids + lo + bytes);
+    s->off.reserve(s->off.size() + n);
+    for (uint64_t i = 1; i <= n; ++i) s->off.push_back(base + (off[i] - lo));
+    return BDG_OK;
+}
+
+int bdg_idstore_get(const bdg_idstore* s, uint64_t i, const char** p, uint32_t* len)
+{
+    if (!s || !p || !len || i + 1 >= s->off.size()) return BDG_E_ARG;
+    *p = s->text.data() + s->off[i]; *len = (uint32_t)(s->off[i + 1] - s->off[i]);
+    return BDG_OK;
+}
+
+int bdg_stage1_collect(bdg_ctx* ctx, const char* in_path, const bdg_stage1_opts* o, bdg_idstore* ids, bdg_stage1_result* res)
+{
+    if (!ctx || !in_path || !o || !ids || !res) return BDG_E_ARG;
+    memset(res, 0, sizeof(*res));
+    res->first_polyt = res->first_r1 = res->bad_read = ~0ull;
+    if (o->umi_len == 0 || o->umi_len > 64) return bdg_fail(ctx, BDG_E_ARG, "umi_len out of range");
+    const double t_start = now_s();
+    bdg_ingest_opts io;
+    memset(&io, 0, sizeof(io));
+    io.chunk_reads = o->chunk_reads ? o->chunk_reads : 100000u;
+    io.ring_chunks = 4; io.pinned = 1; io.threads = o->threads; io.segment_bytes = o->segment_bytes; io.skip_secondary = o->skip_secondary;
+    bdg_ingest* ing = nullptr;
+    int rc = bdg_ingest_open_ex(in_path, &io, &ing);
+    if (rc) return bdg_fail(ctx, rc, std::string("cannot read ") + in_path + " (unknown extension or unreadable file)");
+    struct Fly { bdg_ingest_chunk ch; uint32_t slot; uint64_t g0; };
+    std::deque<Fly> inflight;
+    std::vector<bdg_extract_rec> recs;
+    std::string err; uint64_t bad_read = ~0ull, k = 0, g0 = 0;
+    auto collect = [&](const Fly& f) -> int {
+        recs.resize(f.ch.n);
+        const double t0 = now_s();
+        int r = bdg_extract_collect(ctx, f.slot, recs.data());
+        res->seconds_wait_gpu += now_s() - t0;
+        if (r) {
+            err = bdg_last_error(ctx);
+            if (r == BDG_E_BADBASE) { uint64_t b = ~0ull, w = 0; (void)bdg_extract_status(ctx, &b, &w); if (b != ~0ull) bad_read = f.g0 + b; }
+        }
+        bdg_ingest_release(ing, f.ch.id);
+        return r;
+    };
+    while (rc == BDG_OK) {
+        bdg_ingest_chunk ch;
+        const double t0 = now_s();
+        rc = bdg_ingest_next(ing, &ch);
+        res->seconds_wait_parse += now_s() - t0;
+        if (rc) { err = bdg_ingest_error(ing); break; }
+        if (ch.n == 0) break;
+        if (inflight.size() >= 2) { const Fly f = inflight.front(); inflight.pop_front(); if ((rc = collect(f))) { bdg_ingest_release(ing, ch.id); break; } }
+        const double t1 = now_s();
+        (void)bdg_idstore_append(ids, ch.ids, ch.id_off, ch.n);
+        const uint32_t slot = (uint32_t)(k % 2);
+        rc = bdg_extract_submit(ctx, slot, ch.bases, ch.off, ch.n, o->umi_len);
+        res->seconds_submit += now_s() - t1;
+        if (rc) { err = bdg_last_error(ctx); bdg_ingest_release(ing, ch.id); break; }
+        inflight.push_back(Fly{ ch, slot, g0 });
+        g0 += ch.n; ++k;
+    }
+    while (!inflight.empty()) {
+        const Fly f = inflight.front(); inflight.pop_front();
+        const int r = collect(f);                              // (after a failure: still wait for the GPU before the pinned buffers go)
+        if (rc == BDG_OK) rc = r;
+    }
+    bdg_ingest_close(ing);
+    res->reads = g0; res->chunks = k; res->bad_read = bad_read; res->seconds_total = now_s() - t_start;
+    if (rc) return bdg_fail(ctx, rc, err);
+    return BDG_OK;
+}
+
+int bdg_write_assignments(const bdg_idstore* ids, const uint32_t* rank, const uint8_t* has, uint64_t n, const char* path)
+{
+    if (!ids || !path || (n && (!rank || !has)) || n != bdg_idstore_count(ids)) return BDG_E_ARG;
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return BDG_E_ARG;
+    bool ok = write_all(fd, "readID\tbarcode\n", 15);
+    std::vector<char> buf;
+    buf.reserve(size_t(8) << 20);
+    for (uint64_t i = 0; i < n && ok; ++i) {
+        const size_t idl = (size_t)(ids->off[i + 1] - ids->off[i]);
+        const size_t at = buf.size();
+        buf.resize(at + idl + 19);
+        char* o = buf.data() + at;
+        memcpy(o, ids->text.data() + ids->off[i], idl); o += idl;
+        *o++ = '\t';
+        if (has[i]) { const uint32_t r = rank[i]; for (int b = 0; b < 16; ++b) *o++ = "ACGT"[(r >> (2 * b)) & 3u]; }   // unrank, common.py:27-38
+        else *o++ = '*';
+        *o++ = '\n';
+        buf.resize((size_t)(o - buf.data()));
+        if (buf.size() > (size_t(8) << 20) - 4096) { ok = write_all(fd, buf.data(), buf.size()); buf.clear(); }
+    }
+    if (ok && !buf.empty()) ok = write_all(fd, buf.data(), buf.size());
+    if (::close(fd) != 0) ok = false;
+    return ok ? BDG_OK : BDG_E_ARG;
 }
 
 }  // extern "C"

@@ -52,6 +52,16 @@ def all_max(value, device=None):
     return float(t[0])
 
 
+def all_sum(value, device=None):
+    """sum over ranks of a python number"""
+    if not dist.is_initialized():
+        return float(value)
+    on_gpu = device is not None and device.type == "cuda" and dist.get_backend() == "nccl"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t[0])
+
+
 def timed(step, steps, device=None):
     """K calls of step() bracketed by barrier + synchronize; returns max-over-ranks seconds."""
     barrier(device)
@@ -93,6 +103,12 @@ def graph_row_blocks(n, world, balance="rows"):
     for g in range(1, world + 1):
         cuts[g] = max(cuts[g], cuts[g - 1])
     return [(cuts[g], cuts[g + 1]) for g in range(world)]
+
+
+def graph_balance(thr):
+    """how graph rows are cut into per-GPU blocks: thr 1 runs the neighbourhood probes, the same 176 look-ups for every
+    row ("rows"); thr >= 2 runs the q-gram join, where row i walks its bucket tails BEHIND i, i.e. work ~ n - i ("pairs")"""
+    return "rows" if thr <= 1 else "pairs"
 
 
 def graph_edges_sharded(edges_fn, ranks_sorted, thr, qgram_T, balance="rows"):

@@ -127,10 +127,12 @@ class Stage2:
         ctx.rows_of_dev(d_uniq, nu, d_edges, tot, 3, d_rows.data_ptr(), 0)
         ctx.rows_of_dev(d_uniq, nu, d_edges, tot, 3, d_rows.data_ptr() + 4 * max(tot, 1), 1)
         rows = d_rows.to_host()
-        for d in (d_edges, d_rows, d_tot) + (() if on_device else (d_uniq,)):
+        for d in (d_edges, d_tot):
             d.free()
         self.ea = rows[0, :tot].astype(np.intp)
         self.eb = rows[1, :tot].astype(np.intp)
+        # the positions and the distinct barcodes stay on the device: the clustering levels and the per-read assignment run there
+        self._dev = {"ctx": ctx, "rows": d_rows, "m": tot, "uniq": d_uniq}
 
     # ------------------------------------------------------------------ centres
     def get_cluster_centers(self, true_barcodes, bc_len, barcode_list, n_cells, interval):
@@ -172,6 +174,19 @@ class Stage2:
         present = ((pos < nu) & (self.uniq[np.minimum(pos, nu - 1)] == cr)) if nu else np.zeros(len(cr), bool)
         cidx = pos[present]                                               # centres that were observed (the others have no edges)
         owner[cidx] = cidx
+        dev = getattr(self, "_dev", None)
+        if dev is not None and dev["m"] == len(self.ea):
+            # the edges are on the device: both levels there (bdg_cluster_dev), the same rule as the array code below
+            print(1)
+            print(2)                                                      # the reference prints the level numbers (:289)
+            ctx = dev["ctx"]
+            own32 = owner.astype(np.int32)
+            d_owner = _native.DeviceArray.from_host(ctx, own32)
+            m = dev["m"]
+            ctx.cluster_dev(dev["rows"].data_ptr(), dev["rows"].data_ptr() + 4 * max(m, 1), m, nu, d_owner)
+            self.owner = d_owner.to_host(nu).astype(np.int64) if nu else owner
+            d_owner.free()
+            return
         u = np.concatenate([self.ea, self.eb])
         v = np.concatenate([self.eb, self.ea])                            # every edge in both directions: u expands, v is reached
         for level in (1, 2):
@@ -214,11 +229,12 @@ class Stage2:
         return nu - (int(key.sum()) + int((~present).sum()))
 
     # ------------------------------------------------------------------ assignment and output
-    def assigned_rank(self, high_sens=False):
-        """per distinct barcode: rank of the barcode it is corrected to, NONE if unassigned"""
-        out = np.full(len(self.uniq), NONE, dtype=np.uint32)
+    def assigned(self, high_sens=False):
+        """per distinct barcode: (rank of the barcode it is corrected to, whether it has one)"""
+        out = np.zeros(len(self.uniq), dtype=np.uint32)
         ok = self.owner >= 0
         out[ok] = self.uniq[self.owner[ok]]
+        has = ok.copy()
         if high_sens:
             centers = np.unique(out[ok])                                  # the centres in use, ascending: ties -> lowest rank
             todo = np.nonzero(~ok)[0]
@@ -226,21 +242,55 @@ class Stage2:
                 idx, ed, _ = self._ctx().nearest16(self.uniq[todo], centers, 2)
                 near = ed < 3
                 out[todo[near]] = centers[idx[near]]
+                has[todo[near]] = True
+        return out, has
+
+    def assigned_rank(self, high_sens=False):
+        """per distinct barcode: rank of the barcode it is corrected to, NONE if unassigned"""
+        out, has = self.assigned(high_sens)
+        out = out.copy()
+        out[~has] = NONE
         return out
 
-    def output_file(self, read_ids, obs_rank, usable, out, high_sens):
-        """<out>_output_file.tsv with columns readID, barcode (reference :388-410)"""
-        assigned = self.assigned_rank(high_sens)
-        per_read = np.full(len(read_ids), NONE, dtype=np.uint32)
+    def per_read(self, obs_rank, usable, high_sens):
+        """per read: (rank of the corrected barcode, whether there is one), on the host"""
+        assigned, has = self.assigned(high_sens)
+        n = len(obs_rank)
+        rank, got = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint8)
         if usable.any():
             pos = np.searchsorted(self.uniq, obs_rank[usable])
-            per_read[usable] = assigned[pos]
-        got = per_read != NONE
-        names = np.empty(len(read_ids), dtype=object)
-        names[:] = "*"
-        if got.any():
-            distinct, inv = np.unique(per_read[got], return_inverse=True)
-            names[got] = np.array(unrank_many(distinct), dtype=object)[inv]
-        with open(out + "_output_file.tsv", "w") as f:
-            f.write("readID\tbarcode\n")
-            f.write("".join("%s\t%s\n" % (rid, bc) for rid, bc in zip(read_ids, names)))
+            rank[usable] = assigned[pos]
+            got[usable] = has[pos]
+        return rank, got
+
+    def output_file(self, read_ids, obs_rank, usable, out, high_sens):
+        """<out>_output_file.tsv with columns readID, barcode (reference :388-410), written natively (bdg_write_assignments).
+        read_ids: a list of str or an _native.IdStore."""
+        rank, got = self.per_read(obs_rank, usable, high_sens)
+        ids = read_ids if isinstance(read_ids, _native.IdStore) else _native.IdStore(read_ids)
+        _native.write_assignments(ids, rank, got, out + "_output_file.tsv")
+
+    def output_file_from_device(self, ids, ctx, out, high_sens):
+        """the same straight from the extraction records the context kept: per read, the position of its barcode among the
+        distinct ones and what that was corrected to, on the device (bdg_assign_reads_dev); the host only writes the file"""
+        assigned, has = self.assigned(high_sens)
+        ptr, n = ctx.kept_records()
+        dev = self._dev
+        d_assigned = _native.DeviceArray.from_host(ctx, assigned)
+        d_has = _native.DeviceArray.from_host(ctx, has.astype(np.uint8))
+        d_rank = _native.DeviceArray(ctx, max(n, 1), np.uint32)
+        d_got = _native.DeviceArray(ctx, max(n, 1), np.uint8)
+        if n:
+            ctx.assign_reads_dev(ptr, n, dev["uniq"], len(self.uniq), d_assigned, d_has, d_rank, d_got)
+        rank, got = d_rank.to_host(n), d_got.to_host(n)
+        for d in (d_assigned, d_has, d_rank, d_got):
+            d.free()
+        _native.write_assignments(ids, rank, got, out + "_output_file.tsv")
+
+    def release_device(self):
+        dev = getattr(self, "_dev", None)
+        if dev is not None:
+            dev["rows"].free()
+            if dev["uniq"] is not getattr(self, "_d_uniq", None):
+                dev["uniq"].free()
+            self._dev = None

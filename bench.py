@@ -99,12 +99,12 @@ def profile_counters(kernel):
     """HBM bytes / vector instructions per launch of `kernel` from the committed rocprofv3 PMC passes
     (tools/pmc_profile.sh -> tools/summarize_profile.py), only if they were taken from this very build of the
     library; otherwise None (a stale profile must not be printed beside live timings)."""
-    out = {"traffic": None, "valu": None, "source": None}
+    out = {"traffic": None, "valu": None, "lds": None, "source": None}
     try:
         lib_version = _native.load().bdg_version().decode()
     except Exception:
         return out
-    for name, key in (("traffic.json", "traffic"), ("valu.json", "valu")):
+    for name, key in (("traffic.json", "traffic"), ("valu.json", "valu"), ("lds.json", "lds")):
         f = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(f):
             continue
@@ -209,7 +209,8 @@ def bench_graph(args, rank, world, dev, local_dev):
     wl = synth.make_whitelist(args.whitelist)
     ranks = observed_barcodes(n, wl)
     T = orc.qgram_threshold(thr)
-    lo, hi = bdist.graph_row_blocks(n, world, "rows")[rank]
+    # thr 1: a row's work is its 176 probes (equal rows); thr >= 2: its bucket tails behind it, i.e. ~ (n - i) (equal pair counts)
+    lo, hi = bdist.graph_row_blocks(n, world, bdist.graph_balance(thr))[rank]
     d_ranks = torch.from_numpy(ranks.view(np.int32)).to(dev)
     cap = 32 * n
     d_edges = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
@@ -256,6 +257,16 @@ def bench_graph(args, rank, world, dev, local_dev):
         alg = 4 * n + 9 * ne                           # 4n in + 9E out (rank's own edges)
         achieved = alg / (per_launch_ms[dom] * 1e-3) / 1e9
         pc = profile_counters(dom)
+        # HBM is not what binds these kernels (L2-resident gathers, LDS counters, integer issue): say how close they are to the
+        # ceilings that could - vector-instruction issue (1024 SIMDs, one wave64 instruction per 4 clocks) and the LDS arrays
+        # (one cycle per lane group and CU, MI355X_MICROARCH.md "LDS") - from the committed counter passes of this build
+        t_dom = per_launch_ms[dom] * 1e-3
+        issue_peak, lds_peak = 1024 * 2.4e9 / 4.0, 256 * 2.4e9
+        int_issue = None if pc["valu"] is None else {"valu_insts_per_launch": pc["valu"], "achieved": pc["valu"] / t_dom, "peak": issue_peak,
+                                                     "unit": "wave-instr/s", "frac": pc["valu"] / t_dom / issue_peak}
+        lds_use = None if pc["lds"] is None else {"lds_cycles_per_launch": pc["lds"]["cycles"], "bank_conflict_cycles": pc["lds"]["conflict_cycles"],
+                                                  "achieved": pc["lds"]["cycles"] / t_dom, "peak": lds_peak, "unit": "LDS-array cycles/s (256 CUs)",
+                                                  "frac": pc["lds"]["cycles"] / t_dom / lds_peak}
         line = {
             "metric": "graph rows/sec, threshold=%d, %d distinct barcodes" % (thr, n), "value": n / (elapsed / args.steps),
             "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -264,11 +275,12 @@ def bench_graph(args, rank, world, dev, local_dev):
             "config": {"workload": "BASELINE config %d: barcode_graph edges, threshold %d, %d distinct observed barcodes (%s)"
                                    % (args.config, thr, n, "neighbourhood probes" if thr == 1 else "q-gram join"),
                        "rows": n, "edges_rank0": ne, "qgram_T": T,
-                       "parallelism": "row blocks per GPU, no collectives",
+                       "parallelism": "row blocks per GPU (%s), no collectives" % ("equal rows" if thr == 1 else "equal pair counts"),
+                       "rows_this_rank": [int(lo), int(hi)],
                        "clock_ramp": "%d untimed steps (%.2f s) before the %d warm-up steps" % (ramp_steps, RAMP_S, args.warmup)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pc["traffic"], "traffic_source": pc["source"],
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": per_launch_ms[dom]},
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": per_launch_ms[dom], "int_issue": int_issue, "lds": lds_use},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(per_launch_ms.items())},
             "parity_sample": "ok",
         }
@@ -301,6 +313,9 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="batch pipelining: K2 of batch i on a second stream beside K1 of batch i+1 (bdg_set_overlap; about +7 %% calls/s, "
                          "but the kernels then share the chip and their own durations - the roofline block - grow)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="the multi-rank plumbing without GPUs (self-launch, rendezvous, row / read split, barrier, max-over-ranks clock, "
+                         "rank 0's line) with a stub in place of the step; prints a line marked \"rehearsal\": true - never a measurement")
     args = ap.parse_args()
 
     rank, local_rank, world = bdist.env_rank()
@@ -308,6 +323,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(spawn_ranks(args.gpus))           # before anything here touches a GPU
         args.gpus = world
+    if args.rehearse:
+        return rehearse(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     ndev = torch.cuda.device_count()
@@ -323,6 +340,34 @@ def main():
             bench_graph(args, rank, world, dev, local_dev)
         else:
             bench_calls(args, rank, world, dev, local_dev)
+    finally:
+        if world > 1 and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+
+
+def rehearse(args, rank, world):
+    """Everything of a --gpus N run except the GPU: the ranks rendezvous over gloo, take their share of the work exactly as the
+    real run cuts it (reads: N x --reads, weak; graph rows: row blocks, equal rows at thr 1, equal pair counts at thr 2), time
+    a stub step between the barriers with the max-over-ranks clock, and rank 0 prints the line from the totals over ranks.
+    The SCALE leg of the driver is then not the first time this code runs."""
+    bdist.init(backend="gloo")
+    try:
+        if args.config in (3, 5):
+            thr = 1 if args.config == 3 else 2
+            lo, hi = bdist.graph_row_blocks(args.rows, world, bdist.graph_balance(thr))[rank]
+            units, unit, scaling = hi - lo, "rows/s", "strong"
+            share = {"rows_this_rank": [int(lo), int(hi)], "balance": bdist.graph_balance(thr)}
+        else:
+            units, unit, scaling = args.reads, "calls/s", "weak"
+            share = {"reads_per_gpu": args.reads, "seed_this_rank": 1 + rank}
+        elapsed = bdist.timed(lambda: time.sleep(0.002 * (1 + rank)), args.steps, None)
+        total = bdist.all_sum(units)
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "metric": "stub step, no GPU work", "value": total / (elapsed / args.steps), "unit": unit,
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "data": "none",
+                              "config": dict(share, workload="rehearsal of BASELINE config %d" % args.config, units_all_ranks=int(total))}))
+        bdist.barrier(None)
     finally:
         if world > 1 and torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()

@@ -247,7 +247,7 @@ int64_t bdg_format_rows(const bdg_ingest_chunk* chunk, const bdg_extract_rec* re
 typedef struct bdg_stage1_opts {
     uint32_t umi_len;             /* 10 (tenX_v2) or 12 (tenX_v3) */
     uint32_t threads;             /* reader threads (bdg_ingest_opts.threads) */
-    uint32_t format_threads;      /* 0 = 3 */
+    uint32_t format_threads;      /* 0 = 4 */
     uint32_t header_every;        /* 0: the header once, on top (the reference's single-thread file shape); N: in front of every N
                                      reads and once more when the input ends on a multiple of N - the reference's parallel shape,
                                      one header per READ_CHUNK_SIZE chunk including the trailing empty one (:131-150,243-246) */
@@ -291,6 +291,10 @@ int  bdg_nearest16_recs_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_
 /* algorithm: 0 = automatic, 1 = force the exhaustive Myers scan, 2 = force the
  * neighbourhood-probe path (max_ed <= 2 only). Results are identical. */
 int  bdg_nearest16_set_algo(bdg_ctx* ctx, int algo);
+/* Device memory held by the neighbourhood-probe index of the loaded whitelist, in bytes: 0 until a call takes the probe path
+ * (automatic mode takes the exhaustive scan while nw * nq stays small, e.g. stage 2's --high_sens pass against ~5,000 centres:
+ * no index is ever built then); the deletion-variant part is added by the first probe call with max_ed = 2. */
+uint64_t bdg_nearest16_index_bytes(bdg_ctx* ctx);
 
 /* ---- B-G: edit-distance graph ----------------------------------------- */
 /* ranks: distinct rank-packed 16-mers, any order.  Writes up to cap edges (a<b)
@@ -328,6 +332,35 @@ int  bdg_distinct_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
  * barcode arrays of bdg_distinct_dev, which is what clustering on arrays needs (offset 0: a, offset 1: b). */
 int  bdg_rows_of_dev(bdg_ctx* ctx, const uint32_t* d_sorted, uint32_t n, const uint32_t* d_values, uint64_t m,
                      uint32_t stride_words, uint32_t* d_rows);
+
+/* The two clustering levels of BarcodeGraph.cluster (barcode_graph.py:279-301) on the device.  d_ea / d_eb: the m edges
+ * as positions in the distinct-barcode array of nu entries (bdg_rows_of_dev).  d_owner [nu], in: c at every centre's own
+ * position c, -2 elsewhere; out: the position of the centre a barcode belongs to, -1 where two centres met on one level
+ * (the reference's (-1, -1)), -2 unclustered.  Asynchronous. */
+int  bdg_cluster_dev(bdg_ctx* ctx, const uint32_t* d_ea, const uint32_t* d_eb, uint64_t m, uint32_t nu, int32_t* d_owner);
+/* Per read of d_recs: the barcode its observed barcode was corrected to (assign_by_cluster + the loop of output_file,
+ * barcode_graph.py:322-329,388-410): d_uniq [nu] ascending distinct barcodes, d_assigned [nu] / d_has [nu] what each was
+ * assigned to (has = 0: nothing, the row prints '*').  Asynchronous. */
+int  bdg_assign_reads_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint64_t n, const uint32_t* d_uniq, uint32_t nu,
+                          const uint32_t* d_assigned, const uint8_t* d_has, uint32_t* d_out_rank, uint8_t* d_out_has);
+
+/* ---- stage 2's read-side plumbing on the host (badger.py:112-121,129; barcode_graph.py:388-410) -------------- */
+/* Read ids of a run, kept natively (12 bytes per read instead of a Python string each). */
+typedef struct bdg_idstore bdg_idstore;
+bdg_idstore* bdg_idstore_new(void);
+void     bdg_idstore_free(bdg_idstore* s);
+uint64_t bdg_idstore_count(const bdg_idstore* s);
+/* n ids as one concatenated buffer + n + 1 offsets (off[0] need not be 0) */
+int      bdg_idstore_append(bdg_idstore* s, const char* ids, const uint64_t* off, uint64_t n);
+/* id i: pointer into the store (valid until the next append) and its length */
+int      bdg_idstore_get(const bdg_idstore* s, uint64_t i, const char** p, uint32_t* len);
+/* Stage 1 without the TSV: every read of in_path through the context (its records stay on the device if the context keeps
+ * them, bdg_extract_keep_records), the read ids into `ids`.  What badger.py does with read input (:112-117).  opts as for
+ * bdg_stage1_run (header_every / format_threads unused); res->reads = reads seen. */
+int  bdg_stage1_collect(bdg_ctx* ctx, const char* in_path, const bdg_stage1_opts* opts, bdg_idstore* ids, bdg_stage1_result* res);
+/* "<readID>\t<barcode>\n" per read under the header "readID\tbarcode" (output_file, barcode_graph.py:406-410): rank[i]
+ * spelled out (common.py:27-38) where has[i] != 0, '*' elsewhere.  n must equal the store's count. */
+int  bdg_write_assignments(const bdg_idstore* ids, const uint32_t* rank, const uint8_t* has, uint64_t n, const char* path);
 
 #ifdef __cplusplus
 }

@@ -75,3 +75,30 @@ def test_clock_ramp_runs_whole_groups_of_steps_for_the_stated_time(monkeypatch):
     dt = time.perf_counter() - t0
     assert k == calls["steps"] and k % 8 == 0 and k >= 8 and calls["syncs"] == k // 8
     assert 0.05 <= dt < 0.5
+
+
+def test_multi_rank_rehearsal_over_gloo():
+    """`python bench.py --gpus 2 --config 5 --rehearse` as the driver's SCALE leg starts it, minus the GPUs: the parent
+    launches torch.distributed.run as a child, two ranks rendezvous on 127.0.0.1 over gloo, cut the rows into blocks of
+    equal pair counts, time a stub step with the max-over-ranks clock, and rank 0 prints ONE line whose totals are sums
+    over the ranks.  Same for the headline config (reads per GPU, weak scaling)."""
+    import subprocess
+    from badger_amd import dist as bdist
+    env = dict(os.environ, BADGER_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "5", "--steps", "3", "--warmup", "1",
+                        "--rows", "500000", "--rehearse"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["rehearsal"] is True and d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["units_all_ranks"] == 500000 and d["config"]["balance"] == "pairs"
+    assert d["config"]["rows_this_rank"] == list(bdist.graph_row_blocks(500000, 2, "pairs")[0])
+    assert d["ms_per_step"] >= 3.9                      # max over ranks: rank 1's stub sleeps 4 ms a step
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--reads", "1000", "--rehearse"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["units_all_ranks"] == 2000

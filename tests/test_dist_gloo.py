@@ -82,3 +82,30 @@ def test_world2_gloo_sharded_extract_and_clock():
         assert p.exitcode == 0
     assert same and n == 301
     assert t >= 0.19          # max over ranks: rank 1 sleeps 2 x 0.1 s
+
+
+def test_pair_balanced_blocks_balance_the_joins_work():
+    """thr >= 2: the q-gram join's work for row i is the number of candidate entries behind it in its 11 buckets
+    (index.py:77-93 walks exactly those).  Blocks of equal pair counts must give every GPU the same share of that within
+    5 %; equal rows would give the first of 8 GPUs almost twice its share."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n = 60000
+    ranks = bench.observed_barcodes(n, synth.make_whitelist(20000))
+    assert bdist.graph_balance(1) == "rows" and bdist.graph_balance(2) == "pairs" and bdist.graph_balance(3) == "pairs"
+    # entries behind row i: for each of its 11 six-mers, the rows > i holding that six-mer (with multiplicity)
+    r = ranks.astype(np.uint64)
+    keys = np.stack([(r >> np.uint64(2 * p)) & np.uint64(0xFFF) for p in range(11)], axis=1).astype(np.int64)       # [n, 11]
+    flat = keys.ravel()
+    order = np.argsort(flat, kind="stable")                       # sorted by six-mer, rows ascending inside a bucket
+    pos = np.empty(len(flat), dtype=np.int64)
+    pos[order] = np.arange(len(flat))
+    ends = np.searchsorted(flat[order], np.arange(4097))          # bucket k ends at ends[k + 1]
+    behind = (ends[flat + 1] - pos - 1).reshape(n, 11).sum(axis=1)
+    total = behind.sum()
+    for world in (2, 4, 8):
+        share = [behind[lo:hi].sum() / total for lo, hi in bdist.graph_row_blocks(n, world, "pairs")]
+        assert max(share) * world < 1.05 and min(share) * world > 0.95, (world, share)
+        rows = [behind[lo:hi].sum() / total for lo, hi in bdist.graph_row_blocks(n, world, "rows")]
+        assert max(rows) * world > 1.4

@@ -262,7 +262,7 @@ def test_config5_visium_scale_whitelist_and_thr2_graph(world):
     d_out = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
     d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     parts = []
-    for lo, hi in bdist.graph_row_blocks(n, 8, "rows"):
+    for lo, hi in bdist.graph_row_blocks(n, 8, bdist.graph_balance(2)):        # thr 2: blocks of equal pair counts, as bench.py cuts them
         ctx.graph_edges_rows_dev(d_ranks, n, lo, hi, 2, T, d_out, cap, d_cnt)
         torch.cuda.synchronize()
         parts.append(d_out[:int(d_cnt[0])].cpu().numpy().view(np.uint32).copy())

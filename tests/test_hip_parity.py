@@ -372,6 +372,33 @@ def test_nearest16_scan_large_max_ed(ctx, orc):
     assert (ge == we).all() and (gi == wi).all() and (gt == wt).all()
 
 
+def test_nearest16_picks_the_algorithm_by_size(orc):
+    """automatic mode: a small job (stage 2's --high_sens pass: some thousand centres) takes the exhaustive scan and builds no
+    index at all; a whitelist-sized list takes the probe path, whose deletion-variant part only appears with max_ed = 2.
+    Results equal the oracle's either way."""
+    c = _native.Context(0)
+    rng = np.random.default_rng(23)
+    wl = synth.make_whitelist(5000)
+    q = _near_queries(wl, rng, 4000)
+    gi, ge, gt = c.nearest16(q, wl, 2)
+    assert c.nearest16_index_bytes() == 0
+    wi, we, wt = orc.nearest16(q, wl, 2, threads=8)
+    assert (gi == wi).all() and (ge == we).all() and (gt == wt).all()
+    wl = synth.make_whitelist(737280)
+    q = _near_queries(wl, rng, 6000)
+    gi, ge, gt = c.nearest16(q, wl, 1)
+    pairs_only = c.nearest16_index_bytes()
+    assert 0 < pairs_only < 150 << 20
+    wi, we, wt = orc.nearest16(q, wl, 1, threads=8, probe=True)
+    assert (gi == wi).all() and (ge == we).all() and (gt == wt).all()
+    gi, ge, gt = c.nearest16(q, wl, 2)
+    assert c.nearest16_index_bytes() > pairs_only
+    wi, we, wt = orc.nearest16(q, wl, 2, threads=8, probe=True)
+    assert (gi == wi).all() and (ge == we).all() and (gt == wt).all()
+    c.nearest16(q[:10], wl, 2)                               # the index exists: a small job uses it too
+    c.close()
+
+
 def test_nearest16_edge_cases(ctx):
     wl = synth.make_whitelist(10)
     gi, ge, gt = ctx.nearest16(np.zeros(0, np.uint32), wl, 2)

@@ -114,3 +114,64 @@ def test_arrays_reproduce_the_references_stage2_fixture(tmp_path, golden_dir):
     st2.output_file([r for r, _ in ra], obs_rank, usable, prefix, False)
     assert open(prefix + "_output_file.tsv").read() == open(os.path.join(golden_dir, "c1_stage2_output_file.tsv")).read()
     assert str(st2.disconnected()) == open(os.path.join(golden_dir, "c1_stage2_stdout_tail.txt")).read().strip()
+
+
+def test_idstore_and_native_output_writer(tmp_path):
+    from badger_amd import _native
+    ids = ["r%d/x" % i for i in range(1000)] + ["", "a b"]
+    st = _native.IdStore(ids[:400])
+    st.extend(ids[400:])
+    assert len(st) == len(ids) and st.to_list() == ids and st[401] == ids[401]
+    rng = np.random.default_rng(3)
+    rank = rng.integers(0, 1 << 32, len(ids), dtype=np.uint64).astype(np.uint32)
+    rank[5] = 0xFFFFFFFF                                   # sixteen T: a barcode like any other
+    has = (rng.random(len(ids)) < 0.7).astype(np.uint8)
+    has[5] = 1
+    p = str(tmp_path / "w.tsv")
+    _native.write_assignments(st, rank, has, p)
+    want = "readID\tbarcode\n" + "".join("%s\t%s\n" % (i, synth.rank_to_str(r) if h else "*") for i, r, h in zip(ids, rank, has))
+    assert open(p).read() == want and "\tTTTTTTTTTTTTTTTT\n" in want
+    with pytest.raises(_native.BadgerHipError):
+        _native.write_assignments(st, rank[:-1], has[:-1], p)             # one id per read, or it is an error
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,thr,n_cells", [(1, 1, 40), (2, 2, 25), (4, 2, 60), (5, 1, 8), (6, 2, 300)])
+def test_device_clustering_and_assignment_equal_the_array_code(seed, thr, n_cells):
+    """bdg_cluster_dev (both levels with min / max atomics over the edge array) and bdg_assign_reads_dev against the numpy
+    code, which the CPU tier checks against the dictionary mirror of the reference: graphs with conflicts on both levels"""
+    from badger_amd import _native
+    ids, bcs = _reads(n_cells, 20000 if n_cells > 100 else 6000, seed)
+    obs_rank, usable = observed_from_strings(bcs)
+    ref = Stage2(thr)
+    ref.count_host(obs_rank, usable)
+    _edges_from_oracle(ref, thr)
+    with redirect_stdout(io.StringIO()):
+        ref.cluster(None, None, max(4, n_cells // 2), 16, 25)
+    ctx = _native.default_context(0)
+    dev = Stage2(thr)
+    dev.count_host(obs_rank, usable)
+    dev.ea, dev.eb = ref.ea, ref.eb
+    m = len(ref.ea)
+    d_rows = _native.DeviceArray.from_host(ctx, np.stack([ref.ea, ref.eb]).astype(np.uint32) if m else np.zeros((2, 1), np.uint32))
+    dev._dev = {"ctx": ctx, "rows": d_rows, "m": m, "uniq": _native.DeviceArray.from_host(ctx, dev.uniq)}
+    with redirect_stdout(io.StringIO()) as o:
+        dev.cluster(None, None, max(4, n_cells // 2), 16, 25)
+    assert o.getvalue() == "1\n2\n"
+    assert (dev.owner == ref.owner).all() and (ref.owner == -1).sum() > 0 and (ref.owner >= 0).sum() > n_cells // 2
+    # per read, from extraction records on the device
+    recs = np.zeros(len(obs_rank), dtype=_native.REC_DTYPE)
+    recs["valid"] = 1
+    recs["bc_rank"] = obs_rank
+    recs["flags"] = np.where(usable, _native.FLAG_RANK_OK | _native.FLAG_BC16, 0)
+    recs["valid"][::17] = 0                                   # reads without a barcode
+    usable2 = usable & (recs["valid"] == 1)
+    want_rank, want_has = ref.per_read(obs_rank, usable2, False)
+    assigned, has = dev.assigned(False)
+    d_recs = _native.DeviceArray.from_host(ctx, recs.view(np.uint8).reshape(-1, 32))
+    d_a, d_h = _native.DeviceArray.from_host(ctx, assigned), _native.DeviceArray.from_host(ctx, has.astype(np.uint8))
+    d_r, d_g = _native.DeviceArray(ctx, len(recs), np.uint32), _native.DeviceArray(ctx, len(recs), np.uint8)
+    ctx.assign_reads_dev(d_recs, len(recs), dev._dev["uniq"], len(dev.uniq), d_a, d_h, d_r, d_g)
+    got_rank, got_has = d_r.to_host(), d_g.to_host()
+    assert (got_has == want_has).all() and (got_rank[want_has == 1] == want_rank[want_has == 1]).all() and want_has.sum() > 1000
+    dev.release_device()

@@ -28,7 +28,8 @@ SLAB = 1000000
 
 
 def helper(tmp):
-    so = os.path.join(tmp, "libfastx_tools.so")
+    import tempfile
+    so = os.path.join(tempfile.mkdtemp(dir="/tmp"), "libfastx_tools.so")        # (not under TMPDIR: /dev/shm is mounted noexec)
     subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", so,
                            os.path.join(ROOT, "tools", "native", "fastx_tools.c"), "-lz"])
     L = C.CDLL(so)
@@ -76,12 +77,13 @@ def main():
     done = 0
     while done < n:
         k = min(SLAB, n - done)
-        bases, off = synth.make_reads(k, wl, seed=1 + done // SLAB, device="cuda")
-        bases, off = bases.cpu().numpy(), off.cpu().numpy().astype(np.uint64)
+        tb, to = synth.make_reads(k, wl, seed=1 + done // SLAB, device="cuda")
+        tb, to = tb.cpu(), to.cpu()
+        bases, off = tb.numpy(), to.numpy().astype(np.uint64)
         if done == 0:
             k0 = min(k, 200000)
-            recs = orc.extract_batch(bases[:int(off[k0])], off[:k0 + 1], 12, threads=len(os.sched_getaffinity(0)))
-            seqs = synth.reads_to_list(bases[:int(off[k0])], off[:k0 + 1])
+            recs = orc.extract_batch(bases[:int(off[k0])], off[:k0 + 1], 12, threads=16)
+            seqs = synth.reads_to_list(tb[:int(off[k0])], to[:k0 + 1])
             first_rows = "".join(record_to_row("read_%d" % i, s, r) + "\n" for i, (s, r) in enumerate(zip(seqs, recs))).encode()
             gz1 = os.path.join(tmp, "cli_reads_1m.fastq")
             if os.path.exists(gz1):

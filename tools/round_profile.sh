@@ -15,13 +15,13 @@ case $mode in
 gpu)
     rm -rf gpurun_out/${tag} gpurun_out/${tag}_c3 gpurun_out/${tag}_c5 gpurun_out/${tag}_ops
     $GPURUN --timeout 1200 -- "timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/${tag}_tests.txt 2>&1 && bash tools/pmc_profile.sh ${tag} && bash tools/pmc_profile.sh ${tag}_c5 --config 5 && bash tools/pmc_profile.sh ${tag}_c3 --config 3 && bash tools/ops_profile.sh ${tag}_ops; tail -1 gpurun_out/${tag}_tests.txt"
-    python3 tools/summarize_profile.py gpurun_out/${tag} ${tag}          # writes profiles/traffic.json for this build BEFORE the bench lines
+    python3 tools/summarize_profile.py gpurun_out/${tag} ${tag} gpurun_out/${tag}_c5 gpurun_out/${tag}_c3   # writes profiles/traffic.json (+ valu, lds) for this build BEFORE the bench lines
     $GPURUN --timeout 1200 -- "python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err && python bench.py --config 3 > gpurun_out/${tag}_bench_c3.json 2>> gpurun_out/${tag}_bench.err && python bench.py --config 5 > gpurun_out/${tag}_bench_c5.json 2>> gpurun_out/${tag}_bench.err && python bench.py --overlap > gpurun_out/${tag}_bench_ov.json 2>> gpurun_out/${tag}_bench.err && python tools/stress_parity.py --cases 2 > gpurun_out/${tag}_stress.txt 2>&1; tail -n 1 gpurun_out/${tag}_stress.txt"
     ;;
 collect)
     old=${3:-}
     if [ -n "$old" ]; then git rm -q --cached profiles/${old}_* 2>/dev/null || true; rm -f profiles/${old}_*; fi
-    python3 tools/summarize_profile.py gpurun_out/${tag} ${tag}
+    python3 tools/summarize_profile.py gpurun_out/${tag} ${tag} gpurun_out/${tag}_c5 gpurun_out/${tag}_c3
     for t in c5 c3 ops; do cp "$(find gpurun_out/${tag}_$t/stats -name '*_kernel_stats.csv' | head -1)" profiles/${tag}_${t}_kernel_stats.csv; done
     cp "$(find gpurun_out/${tag}/stats -name '*_kernel_stats.csv' | head -1)" profiles/${tag}_kernel_stats.csv
     cp gpurun_out/${tag}_ops/ops.jsonl profiles/${tag}_ops.jsonl

@@ -15,6 +15,7 @@ import os
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
+more = sys.argv[3:]              # further pass directories (--config 3 / 5 runs): their kernels join traffic.json / valu.json / lds.json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -24,32 +25,43 @@ def kname(full):
 
 
 summary = collections.defaultdict(dict)
-for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
-    for r in csv.DictReader(open(f)):
-        k = kname(r["Name"])
-        summary[k]["calls"] = int(r["Calls"])
-        summary[k]["avg_ns"] = float(r["AverageNs"])
-        summary[k]["min_ns"] = float(r["MinNs"])
-        summary[k]["max_ns"] = float(r["MaxNs"])
-for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
-    if not os.path.isdir(d):
-        continue
-    files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
-    if len(files) != 1:          # (one process per pass; more means leftovers of an earlier run in the same directory)
-        sys.exit("%s holds %d counter files, expected 1" % (d, len(files)))
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in files:
+
+
+def take_dir(one, sub):
+    """one pmc_profile.sh output directory; a kernel that an earlier directory named keeps that directory's figures"""
+    for f in glob.glob(os.path.join(one, "stats", "*", "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
-            agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    # the pass as committed: per kernel and counter, launches and mean per launch
-    with open(os.path.join(ROOT, "profiles", "%s_%s.csv" % (tag, os.path.basename(d))), "w") as out:
-        out.write("kernel,counter,launches,mean_per_launch\n")
-        for k in sorted(agg):
-            for c in sorted(agg[k]):
-                out.write("%s,%s,%d,%.1f\n" % (k, c, len(agg[k][c]), sum(agg[k][c]) / len(agg[k][c])))
-    for k, cs in agg.items():
-        for c, v in cs.items():
-            summary[k][c] = sum(v) / len(v)
+            k = kname(r["Name"])
+            if "calls" in summary[k]:
+                continue
+            summary[k]["calls"] = int(r["Calls"])
+            summary[k]["avg_ns"] = float(r["AverageNs"])
+            summary[k]["min_ns"] = float(r["MinNs"])
+            summary[k]["max_ns"] = float(r["MaxNs"])
+    for d in sorted(glob.glob(os.path.join(one, "pmc*"))):
+        if not os.path.isdir(d):
+            continue
+        files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+        if len(files) != 1:          # (one process per pass; more means leftovers of an earlier run in the same directory)
+            sys.exit("%s holds %d counter files, expected 1" % (d, len(files)))
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for f in files:
+            for r in csv.DictReader(open(f)):
+                agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # the pass as committed: per kernel and counter, launches and mean per launch
+        with open(os.path.join(ROOT, "profiles", "%s%s_%s.csv" % (tag, sub, os.path.basename(d))), "w") as out:
+            out.write("kernel,counter,launches,mean_per_launch\n")
+            for k in sorted(agg):
+                for c in sorted(agg[k]):
+                    out.write("%s,%s,%d,%.1f\n" % (k, c, len(agg[k][c]), sum(agg[k][c]) / len(agg[k][c])))
+        for k, cs in agg.items():
+            for c, v in cs.items():
+                summary[k].setdefault(c, sum(v) / len(v))
+
+
+take_dir(src, "")
+for one in more:
+    take_dir(one, "_" + os.path.basename(one.rstrip("/")).split("_")[-1])
 STREAMING = {"k_scan_reads"}
 traffic = {}
 for k, s in summary.items():
@@ -68,6 +80,10 @@ json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), in
 valu = {k: s["SQ_INSTS_VALU"] for k, s in summary.items() if "SQ_INSTS_VALU" in s}
 valu["_meta"] = meta
 json.dump(valu, open(os.path.join(ROOT, "profiles", "valu.json"), "w"), indent=1, sort_keys=True)
+# LDS-array cycles per launch (SQ_LDS_IDX_ACTIVE: all cycles, SQ_LDS_BANK_CONFLICT: the extra ones), MI355X_MICROARCH.md "LDS"
+lds = {k: {"cycles": s["SQ_LDS_IDX_ACTIVE"], "conflict_cycles": s.get("SQ_LDS_BANK_CONFLICT")} for k, s in summary.items() if "SQ_LDS_IDX_ACTIVE" in s}
+lds["_meta"] = meta
+json.dump(lds, open(os.path.join(ROOT, "profiles", "lds.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(summary):
     s = summary[k]
     print("%-26s avg %8.1f us  VALU %6.1fM  hbm %s" % (k, s.get("avg_ns", 0) / 1e3, s.get("SQ_INSTS_VALU", 0) / 1e6,
