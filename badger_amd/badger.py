@@ -9,6 +9,7 @@ is outside the accelerated path; the flags are accepted and rejected with a mess
 """
 import argparse
 import logging
+import os
 import sys
 from io import StringIO
 from traceback import print_exc
@@ -88,6 +89,12 @@ def load_true_barcodes(path):
 
 
 def main(args):
+    import time
+    t_marks = [("start", time.perf_counter())]
+
+    def mark(name):
+        t_marks.append((name, time.perf_counter()))
+
     args = parse_args(args)
     set_logger(logger)
     if args.data_type and args.data_type.startswith("tenX"):
@@ -130,16 +137,20 @@ def main(args):
         except BaseException:
             ctx.extract_keep_records(False)
             raise
+        mark("extract")
         logger.info("Finished barcode extraction")
         logger.info("Initializing Graph")
         st2.count_device(ctx)
+        mark("count")
         st2.build_edges(ctx, on_device=True)
         from_device = ctx
     else:
         logger.error("Unknown file format " + args.reads)
         sys.exit(-1)
+    mark("reads_and_graph")
     logger.info("Graph construction done")
     st2.cluster(true_barcodes, barcode_list, args.n_cells, bc_len, args.interval)
+    mark("cluster")
     logger.info("Clustering done")
     if from_device is not None:
         st2.output_file_from_device(read_ids, from_device, args.output, args.high_sens)
@@ -147,13 +158,23 @@ def main(args):
     else:
         st2.output_file(read_ids, obs_rank, usable, args.output, args.high_sens)
     st2.release_device()
+    mark("output")
     print(st2.disconnected())          # "disconnected" count (reference :131-132)
+    timing = os.environ.get("BADGER_AMD_STAGE2_TIMING")
+    if timing:                                   # where the run's time went (tools/stage2_throughput.py reads it)
+        import json
+        with open(timing, "a") as f:
+            f.write(json.dumps({b[0]: round(b[1] - a[1], 4) for a, b in zip(t_marks, t_marks[1:])}) + "\n")
 
 
 if __name__ == "__main__":
     _native.PRELOAD_TORCH = False            # this command line allocates through the library (bdg_mem_alloc): no torch start-up
     try:
         main(sys.argv[1:])
+        logging.shutdown()                   # (files are closed: skip the interpreter's and the HIP runtime's tear-down)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     except (SystemExit, KeyboardInterrupt):
         raise
     except:  # noqa: E722  (same catch-all as the reference :177-196)

@@ -5,6 +5,7 @@
 #include <cstddef>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 
 // launchers in the kernel translation units
@@ -371,8 +372,13 @@ static int slot_enqueue(bdg_ctx* ctx, bdg_ctx::Slot& sl)
     return BDG_OK;
 }
 
+// where bdg_extract_submit's time goes (BADGER_AMD_INGEST_DEBUG; printed by bdg_stage1_run)
+double g_submit_t[6] = { 0, 0, 0, 0, 0, 0 };
+static inline double submit_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int bdg_extract_submit(bdg_ctx* ctx, uint32_t slot, const uint8_t* bases, const uint64_t* off, uint32_t n, uint32_t umi_len)
 {
+    const double T0 = submit_now();
     if (!ctx || slot >= BDG_SLOTS) return BDG_E_ARG;
     bdg_ctx::Slot& sl = ctx->slots[slot];
     if (sl.busy) return bdg_fail(ctx, BDG_E_ARG, "slot still in flight: collect it first");
@@ -399,24 +405,20 @@ int bdg_extract_submit(bdg_ctx* ctx, uint32_t slot, const uint8_t* bases, const 
         }
     }
     if (!sl.done) BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    const double T1 = submit_now();
     uint64_t* rel = static_cast<uint64_t*>(sl.h_off);
     for (uint32_t i = 0; i <= n; ++i) rel[i] = off[i] - lo;
     hipStream_t st = ctx->stream;
-    if (total > (16ull << 20)) {
-        // one copy = one DMA engine (about 21 GB/s from pinned memory on this part): a large chunk goes as two halves on
-        // two streams; the slot's buffer is free (its last chunk was collected), so the second stream may start at once
-        if (!ctx->copy_stream) BDG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-        if (!ctx->ev_copy) BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));
-        const uint64_t half = (total / 2) & ~uint64_t(255);
-        char* d = static_cast<char*>(sl.d_bases.p);
-        BDG_HIP_TRY(ctx, hipMemcpyAsync(d + half, bases + lo + half, total - half, hipMemcpyHostToDevice, ctx->copy_stream));
-        BDG_HIP_TRY(ctx, hipEventRecord(ctx->ev_copy, ctx->copy_stream));
-        BDG_HIP_TRY(ctx, hipMemcpyAsync(d, bases + lo, half, hipMemcpyHostToDevice, st));
-        BDG_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_copy, 0));
-    } else if (total) BDG_HIP_TRY(ctx, hipMemcpyAsync(sl.d_bases.p, bases + lo, total, hipMemcpyHostToDevice, st));
+    const double T2 = submit_now();
+    // (one copy on one stream runs at the link's rate here: 56.6 GB/s for 32 MB from pinned memory, tools/hip_first_calls.py; two
+    // halves on two streams, which gained 10 % in round 2, gain nothing any more)
+    if (total) BDG_HIP_TRY(ctx, hipMemcpyAsync(sl.d_bases.p, bases + lo, total, hipMemcpyHostToDevice, st));
     BDG_HIP_TRY(ctx, hipMemcpyAsync(sl.d_off.p, rel, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, st));
+    const double T3 = submit_now();
     if ((rc = slot_enqueue(ctx, sl))) return rc;
     sl.busy = true;
+    const double T4 = submit_now();
+    g_submit_t[0] += T1 - T0; g_submit_t[1] += T2 - T1; g_submit_t[2] += T3 - T2; g_submit_t[3] += T4 - T3; g_submit_t[4] += 1;
     return BDG_OK;
 }
 

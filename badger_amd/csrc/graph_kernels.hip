@@ -860,9 +860,10 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             BDG_HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
             int per_cu = 0, per_cu_w = 0;
             BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_graph_qjoin<QJ_W>, 256, 0));
-            ctx->g_qjw_variant = 0;
-            if (const char* e = getenv("BADGER_AMD_QJ_VARIANT")) ctx->g_qjw_variant = atoi(e);      // (for measurements: slice size per wave)
-            if (ctx->g_qjw_variant < 0 || ctx->g_qjw_variant > 3) ctx->g_qjw_variant = 0;
+            // slice size per wave, measured at 500 K rows / thr 2: 16 K rows x 2 waves per block 11.1 ms, 8 K x 4 12.2, 32 K x 1 15.8, 4 K x 4 18.8
+            ctx->g_qjw_variant = 1;
+            if (const char* e = getenv("BADGER_AMD_QJ_VARIANT")) ctx->g_qjw_variant = atoi(e);      // (for measurements)
+            if (ctx->g_qjw_variant < 0 || ctx->g_qjw_variant > 3) ctx->g_qjw_variant = 1;
             switch (ctx->g_qjw_variant) {
             case 1:  BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<16384, 2, true>, 128, 0)); break;
             case 2:  BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<32768, 1, true>, 64, 0)); break;

@@ -225,7 +225,8 @@ int bdg_stage1_run(bdg_ctx* const* ctxs, uint32_t n_ctx, const char* in_path, co
     const double t_start = now_s();
     uint32_t fthreads = o->format_threads ? std::min(o->format_threads, 32u) : 4u;
     if (!o->format_threads) if (const char* e = getenv("BADGER_AMD_FORMAT_THREADS")) { const long v = atol(e); if (v > 0 && v <= 32) fthreads = (uint32_t)v; }
-    const uint32_t per_ctx = 2;                                  // chunks in flight per context (BDG_SLOTS >= 2)
+    uint32_t per_ctx = 2;                                        // chunks in flight per context (BDG_SLOTS >= 2)
+    if (const char* e = getenv("BADGER_AMD_INFLIGHT")) { const long v = atol(e); if (v >= 1 && v <= BDG_SLOTS) per_ctx = (uint32_t)v; }
     bdg_ingest_opts io;
     memset(&io, 0, sizeof(io));
     io.chunk_reads = o->chunk_reads ? o->chunk_reads : 100000u;
@@ -302,7 +303,11 @@ int bdg_stage1_run(bdg_ctx* const* ctxs, uint32_t n_ctx, const char* in_path, co
     if (::close(P.fd) != 0) ok_io = false;
     const double t_close0 = now_s();
     bdg_ingest_close(P.ing);
-    if (getenv("BADGER_AMD_INGEST_DEBUG")) fprintf(stderr, "stage1: reader closed in %.3f s\n", now_s() - t_close0);
+    if (getenv("BADGER_AMD_INGEST_DEBUG")) {
+        extern double g_submit_t[6];
+        fprintf(stderr, "stage1: reader closed in %.3f s; %d submits: reserve %.3f s, offsets %.3f s, copies %.3f s, launches + D2H %.3f s\n", now_s() - t_close0,
+                (int)g_submit_t[4], g_submit_t[0], g_submit_t[1], g_submit_t[2], g_submit_t[3]);
+    }
     res->reads = P.total.reads; res->barcodes = P.total.bc; res->polyt = P.total.pt; res->r1 = P.total.r1;
     res->first_polyt = P.total.first_pt; res->first_r1 = P.total.first_r1; res->bad_read = bad_read;
     res->chunks = k; res->out_bytes = P.out_bytes;

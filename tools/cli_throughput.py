@@ -91,15 +91,25 @@ def main():
             assert L.fq_append(gz1.encode(), bases.ctypes.data, off.ctypes.data, k, 0, b"read_") > 0
         assert L.fq_append(fq.encode(), bases.ctypes.data, off.ctypes.data, k, done, b"read_") > 0
         done += k
+    forms = "plain,bgzf,gz"
+    for a in sys.argv[1:]:
+        if a.startswith("--forms="):
+            forms = a.split("=", 1)[1]
+    forms = forms.split(",")
     bgz = os.path.join(tmp, "cli_reads_bgzf.fastq.gz")
-    assert L.bgzf_compress_file(fq.encode(), bgz.encode(), 1) > 0
-    subprocess.check_call("gzip -1 -k -f %s" % gz1, shell=True)
-    sizes = {"fastq": os.path.getsize(fq), "bgzf.fastq.gz": os.path.getsize(bgz), "1m.fastq.gz": os.path.getsize(gz1 + ".gz")}
+    sizes = {"fastq": os.path.getsize(fq)}
+    if "bgzf" in forms:
+        assert L.bgzf_compress_file(fq.encode(), bgz.encode(), 1) > 0
+        sizes["bgzf.fastq.gz"] = os.path.getsize(bgz)
+    if "gz" in forms:
+        subprocess.check_call("gzip -1 -k -f %s" % gz1, shell=True)
+        sizes["1m.fastq.gz"] = os.path.getsize(gz1 + ".gz")
     print(json.dumps({"prepared_s": round(time.perf_counter() - t0, 1), "reads": n, "bytes": sizes,
                       "cores": len(os.sched_getaffinity(0)), "cpu_count": os.cpu_count()}), flush=True)
     timing = os.path.join(tmp, "cli_timing.jsonl")
     digests = {}
-    for path, nreads in ((fq, n), (bgz, n), (gz1 + ".gz", min(n, SLAB))):
+    inputs = [(fq, n)] * ("plain" in forms) + [(bgz, n)] * ("bgzf" in forms) + [(gz1 + ".gz", min(n, SLAB))] * ("gz" in forms)
+    for path, nreads in inputs:
         for threads in (0, 1) if path != fq else (0, 1, 4, 8, 16):
             # the readers alone (pageable buffers: no GPU, no pinning)
             t0 = time.perf_counter()

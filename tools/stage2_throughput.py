@@ -10,6 +10,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 from badger_amd import synth  # noqa: E402
 
 
@@ -17,12 +18,17 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
     tmp = os.environ.get("TMPDIR", "/tmp")
     wl = synth.make_whitelist(737280)
-    bases, off = synth.make_reads(n, wl, seed=1, device="cuda")
-    seqs = synth.reads_to_list(bases.cpu(), off.cpu())
+    import numpy as np
+    from cli_throughput import helper
+    L = helper(tmp)
     fq = os.path.join(tmp, "s2_reads.fastq")
-    with open(fq, "w") as f:
-        for a in range(0, n, 50000):
-            f.write("".join("@read_%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in zip(range(a, a + 50000), seqs[a:a + 50000])))
+    if os.path.exists(fq):
+        os.remove(fq)
+    for k in range(0, n, 1000000):                 # slabs of 1 M reads, seeds 1, 2, ... (as tools/cli_throughput.py makes them)
+        m = min(1000000, n - k)
+        tb, to = synth.make_reads(m, wl, seed=1 + k // 1000000, device="cuda")
+        b, o = tb.cpu().numpy(), to.cpu().numpy().astype(np.uint64)
+        assert L.fq_append(fq.encode(), b.ctypes.data, o.ctypes.data, m, k, b"read_") > 0
     wlf = os.path.join(tmp, "s2_wl.txt")
     with open(wlf, "w") as f:
         f.write("\n".join(synth.rank_to_str(r) for r in wl) + "\n")
@@ -42,14 +48,23 @@ def main():
     for thr in ("1", "2"):
         for label, reads in (("tsv", tsv), ("fastq", fq)):
             prefix = os.path.join(tmp, "s2_out_%s_%s" % (label, thr))
-            t0 = time.perf_counter()
-            subprocess.check_call([sys.executable, "-m", "badger_amd.badger", "-r", reads, "-d", "tenX_v3", "-l", wlf, "-c", "5000",
-                                   "-t", thr, "-o", prefix], cwd=ROOT, stdout=subprocess.DEVNULL)
-            wall = time.perf_counter() - t0
+            timing = os.path.join(tmp, "s2_timing.jsonl")
+            best = None
+            for rep in range(2):
+                if os.path.exists(timing):
+                    os.remove(timing)
+                t0 = time.perf_counter()
+                subprocess.check_call([sys.executable, "-m", "badger_amd.badger", "-r", reads, "-d", "tenX_v3", "-l", wlf, "-c", "5000",
+                                       "-t", thr, "-tr", "16", "-o", prefix], cwd=ROOT, stdout=subprocess.DEVNULL,
+                                      env=dict(os.environ, BADGER_AMD_STAGE2_TIMING=timing))
+                wall = time.perf_counter() - t0
+                if best is None or wall < best[0]:
+                    best = (wall, json.loads(open(timing).read().strip().split("\n")[-1]))
+            wall, phases = best
             outs[(label, thr)] = open(prefix + "_output_file.tsv").read()
             assigned = sum(1 for l in outs[(label, thr)].split("\n")[1:] if l and not l.endswith("*"))
             print(json.dumps({"stage": 2, "input": label, "threshold": int(thr), "reads": n, "wall_s": round(wall, 2),
-                              "reads_per_s": round(n / wall), "assigned": assigned}), flush=True)
+                              "reads_per_s": round(n / wall), "assigned": assigned, "phases_s": phases}), flush=True)
         print(json.dumps({"threshold": int(thr), "tsv_route_equals_device_route": outs[("tsv", thr)] == outs[("fastq", thr)]}), flush=True)
 
 
