@@ -40,7 +40,7 @@ EXPORTS = [
     "bdg_ingest_open", "bdg_ingest_open_mt", "bdg_ingest_open_ex", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error",
     "bdg_ingest_reads", "bdg_ingest_close", "bdg_format_rows", "bdg_stage1_run",
     "bdg_cluster_dev", "bdg_assign_reads_dev", "bdg_idstore_new", "bdg_idstore_free", "bdg_idstore_count", "bdg_idstore_append",
-    "bdg_idstore_get", "bdg_stage1_collect", "bdg_write_assignments",
+    "bdg_idstore_get", "bdg_stage1_collect", "bdg_write_assignments", "bdg_import_stage1_tsv", "bdg_host_free",
 ]
 
 
@@ -161,6 +161,9 @@ def load():
     L.bdg_idstore_get.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(u32)]
     L.bdg_stage1_collect.argtypes = [vp, C.c_char_p, C.POINTER(Stage1Opts), vp, C.POINTER(Stage1Result)]
     L.bdg_write_assignments.argtypes = [vp, vp, vp, u64, C.c_char_p]
+    L.bdg_import_stage1_tsv.argtypes = [C.c_char_p, u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+    L.bdg_host_free.argtypes = [vp]
+    L.bdg_host_free.restype = None
     L.bdg_ingest_next.argtypes = [vp, C.POINTER(IngestChunk)]
     L.bdg_ingest_release.argtypes = [vp, u32]
     L.bdg_ingest_error.argtypes = [vp]
@@ -563,6 +566,26 @@ def stage1_collect(ctx, in_path, umi_len, ids, threads=0, skip_secondary=False, 
             raise TypeError(msg)
         raise BadgerHipError(rc, msg)
     return res
+
+
+def import_stage1_tsv(path, bc_len=16):
+    """a stage-1 TSV the way badger.py:91-111 reads it -> (IdStore of the read ids, rank uint32[n], usable bool[n])"""
+    L = load()
+    ids = IdStore()
+    pr, pu, n, bad = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+    rc = L.bdg_import_stage1_tsv(os.fsencode(path), bc_len, ids.h, C.byref(pr), C.byref(pu), C.byref(n), C.byref(bad))
+    if rc == E_BADBASE:
+        raise KeyError("the barcode in line %d of %s holds a letter outside ACGT" % (bad.value, path))
+    if rc == E_FORMAT:
+        raise ValueError("%s has no '#read_id' / 'barcode' column" % path)
+    if rc != 0:
+        raise BadgerHipError(rc, "cannot read %s" % path)
+    k = int(n.value)
+    rank = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_uint32)), shape=(max(k, 1),))[:k].copy()
+    usable = np.ctypeslib.as_array(C.cast(pu, C.POINTER(C.c_uint8)), shape=(max(k, 1),))[:k].astype(bool)
+    L.bdg_host_free(pr)
+    L.bdg_host_free(pu)
+    return ids, rank, usable
 
 
 def write_assignments(ids, rank, has, path):

@@ -105,20 +105,28 @@ def main(args):
     if args.stats or args.ground_truth is not None:
         logger.error("--stats / --ground_truth run the reference's offline evaluation module, which this build does not carry")
         sys.exit(-4)
+    # the device context comes up (0.15 - 0.3 s of runtime start) while this thread reads the barcode lists
+    import threading
+    def _warm():
+        try:
+            _native.default_context(args.device)
+        except Exception:
+            pass                                  # (it shows again, as the exception it is, at the first real use)
+    warm = threading.Thread(target=_warm, daemon=True)
+    warm.start()
     true_barcodes = load_true_barcodes(args.true_barcodes) if args.true_barcodes else None
     barcode_list = None
     if args.barcode_list:
-        with open(args.barcode_list) as f:
-            barcode_list = set(f.read().split("\n"))
+        from .common import BarcodeRanks
+        barcode_list = BarcodeRanks.from_file(args.barcode_list, bc_len)      # (the reference keeps a set of the lines, :82-88)
 
     from .stage2 import Stage2, observed_from_strings
+    warm.join()
     st2 = Stage2(args.threshold, device=args.device)
     from_device = None
     if args.reads.endswith("tsv"):
-        read_assignment, _ = import_tsv(args.reads, bc_len)
+        read_ids, obs_rank, usable = _native.import_stage1_tsv(args.reads, bc_len)      # (import_tsv below, natively)
         logger.info("Imported barcodes from file")
-        read_ids = [ra[0] for ra in read_assignment]
-        obs_rank, usable = observed_from_strings([ra[1] for ra in read_assignment], bc_len)
         logger.info("Initializing Graph")
         st2.count_host(obs_rank, usable)
         st2.build_edges()

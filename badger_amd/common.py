@@ -54,3 +54,33 @@ def rank_valid_many(seqs, length=16):
     codes = _LUT[raw.reshape(-1, length)]
     codes = codes[(codes != 255).all(axis=1)]
     return _pack(codes, length)
+
+
+class BarcodeRanks:
+    """The --barcode_list file (reference badger.py:82-88: a set of the file's lines) as the ranks of those lines that are
+    `length` letters of ACGT - the only lines an unrank() output can equal (barcode_graph.py:264).  Truthy whatever it
+    holds, like the reference's set, which always contains at least the empty string."""
+
+    def __init__(self, ranks):
+        self.ranks = np.asarray(ranks, dtype=np.uint32)
+
+    def __bool__(self):
+        return True
+
+    def __len__(self):
+        return len(self.ranks)
+
+    @classmethod
+    def from_file(cls, path, length=16):
+        buf = np.fromfile(path, dtype=np.uint8)
+        if (buf == 13).any():                                     # '\r': Python's text mode translates it; take the plain route
+            with open(path) as f:
+                return cls(rank_valid_many(set(f.read().split("\n")), length))
+        nl = np.flatnonzero(buf == 10)
+        starts = np.concatenate([np.zeros(1, dtype=np.int64), nl + 1])
+        ends = np.concatenate([nl, np.array([len(buf)], dtype=np.int64)])
+        starts = starts[ends - starts == length]
+        if not len(starts):
+            return cls(np.zeros(0, dtype=np.uint32))
+        codes = _LUT[buf[starts[:, None] + np.arange(length)]]
+        return cls(np.unique(_pack(codes[(codes != 255).all(axis=1)], length)))

@@ -743,7 +743,10 @@ struct bdg_ingest : ChunkSink {
                 s->head_len = first; s->tail_off = s->len;
                 if (first < s->len) {
                     const size_t span = s->len - first;
-                    const bool ok = chunk_prepare(c, span / 512 + 1024, format == F_FASTQ ? span / 2 + 4096 : span + 4096, span / 32 + 4096);
+                    // (sized by the segment size, not by this segment's span: the same request every time, so a buffer that served one
+                    // segment serves them all - spans differ by a few bytes and each larger one would re-pin the buffer)
+                    const size_t room = std::max(span, std::min(src.seg_bytes, src.compressed ? src.seg_bytes : src.size));
+                    const bool ok = chunk_prepare(c, room / 512 + 1024, format == F_FASTQ ? room / 2 + 65536 : room + 65536, room / 32 + 4096);
                     wp.c = c; wp.st = 0; wp.partial.clear(); wp.failed = false; wp.nomem = false; wp.noseq = false; wp.err.clear(); wp.line_no = 0;
                     if (!ok || !wp.feed(s->data + first, span)) s->bad = true;            // the assembler parses it again, in sequence, and reports
                     else {

@@ -408,6 +408,95 @@ int bdg_stage1_collect(bdg_ctx* ctx, const char* in_path, const bdg_stage1_opts*
     return BDG_OK;
 }
 
+// Stage-1 TSV -> read ids + observed barcodes, the way badger.py:91-111 takes it in through pandas: the columns "#read_id" and
+// "barcode" by the first line's names, repeated header rows skipped (:104,107), an empty / NA barcode is '*', a barcode of
+// bc_len + 1 letters loses its last one (:108-109).  usable[i] = the read has a barcode of bc_len letters; its rank
+// (common.py:21-25) or BDG_E_BADBASE for a letter outside ACGT (the reference's rank() raises KeyError).
+int bdg_import_stage1_tsv(const char* path, uint32_t bc_len, bdg_idstore* ids, uint32_t** rank_out, uint8_t** usable_out, uint64_t* n_out, uint64_t* bad_line)
+{
+    if (!path || !ids || !rank_out || !usable_out || !n_out || bc_len == 0 || bc_len > 16) return BDG_E_ARG;
+    *rank_out = nullptr; *usable_out = nullptr; *n_out = 0;
+    if (bad_line) *bad_line = 0;
+    FILE* f = fopen(path, "rb");
+    if (!f) return BDG_E_ARG;
+    std::vector<char> buf;
+    {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        buf.resize(sz > 0 ? (size_t)sz : 0);
+        if (sz > 0 && fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return BDG_E_ARG; }
+        fclose(f);
+    }
+    std::vector<uint32_t> ranks; std::vector<uint8_t> usable;
+    const char* p = buf.data(); const char* const end = p + buf.size();
+    int ci = -1, cb = -1; uint64_t line_no = 0;
+    auto is_na = [](const char* s, size_t l) {
+        static const char* const na[] = { "", "NA", "NaN", "nan", "N/A", "NULL", "null", "None" };      // what pandas reads as missing
+        for (const char* t : na) if (strlen(t) == l && memcmp(t, s, l) == 0) return true;
+        return false;
+    };
+    while (p < end) {
+        const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+        const char* le = nl ? nl : end;
+        const char* next = nl ? nl + 1 : end;
+        if (le > p && le[-1] == '\r') --le;
+        ++line_no;
+        // fields ci and cb of the line
+        const char* fs[2] = { nullptr, nullptr }; size_t fl[2] = { 0, 0 };
+        int col = 0; const char* q = p;
+        if (line_no == 1) {
+            for (;;) {
+                const char* t = static_cast<const char*>(memchr(q, '\t', (size_t)(le - q)));
+                const size_t l = (size_t)((t ? t : le) - q);
+                if (l == 8 && memcmp(q, "#read_id", 8) == 0 && ci < 0) ci = col;
+                if (l == 7 && memcmp(q, "barcode", 7) == 0 && cb < 0) cb = col;
+                if (!t) break;
+                q = t + 1; ++col;
+            }
+            if (ci < 0 || cb < 0) return BDG_E_FORMAT;
+            p = next;
+            continue;
+        }
+        for (;;) {
+            const char* t = static_cast<const char*>(memchr(q, '\t', (size_t)(le - q)));
+            const size_t l = (size_t)((t ? t : le) - q);
+            if (col == ci) { fs[0] = q; fl[0] = l; }
+            if (col == cb) { fs[1] = q; fl[1] = l; }
+            if (!t) break;
+            q = t + 1; ++col;
+        }
+        p = next;
+        if (!fs[0] || !fs[1]) continue;                                        // fewer fields than the columns need
+        if ((fl[0] == 8 && memcmp(fs[0], "#read_id", 8) == 0) || (fl[1] == 7 && memcmp(fs[1], "barcode", 7) == 0)) continue;
+        size_t L = fl[1];
+        const bool none = is_na(fs[1], L) || (L == 1 && fs[1][0] == '*');
+        if (!none && L == (size_t)bc_len + 1) L = bc_len;
+        uint32_t r = 0; uint8_t ok = 0;
+        if (!none && L == bc_len) {
+            ok = 1;
+            for (uint32_t i = 0; i < bc_len; ++i) {
+                uint32_t c;
+                switch (fs[1][i]) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break;
+                                    default: if (bad_line) *bad_line = line_no; return BDG_E_BADBASE; }
+                r |= c << (2 * i);
+            }
+        }
+        const uint64_t off2[2] = { 0, fl[0] };
+        (void)bdg_idstore_append(ids, fs[0], off2, 1);
+        ranks.push_back(r); usable.push_back(ok);
+    }
+    const size_t n = ranks.size();
+    *rank_out = static_cast<uint32_t*>(malloc(sizeof(uint32_t) * (n ? n : 1)));
+    *usable_out = static_cast<uint8_t*>(malloc(n ? n : 1));
+    if (!*rank_out || !*usable_out) { free(*rank_out); free(*usable_out); *rank_out = nullptr; *usable_out = nullptr; return BDG_E_NOMEM; }
+    if (n) { memcpy(*rank_out, ranks.data(), sizeof(uint32_t) * n); memcpy(*usable_out, usable.data(), n); }
+    *n_out = n;
+    return BDG_OK;
+}
+
+void bdg_host_free(void* p) { free(p); }
+
 int bdg_write_assignments(const bdg_idstore* ids, const uint32_t* rank, const uint8_t* has, uint64_t n, const char* path)
 {
     if (!ids || !path || (n && (!rank || !has)) || n != bdg_idstore_count(ids)) return BDG_E_ARG;

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _native
 from .barcode_graph import qgram_threshold
-from .common import RANK, rank, rank_many, rank_valid_many
+from .common import RANK, BarcodeRanks, rank, rank_many, rank_valid_many
 
 logger = logging.getLogger("BarcodeGraph")
 NONE = np.uint32(0xFFFFFFFF)
@@ -147,7 +147,8 @@ class Stage2:
         if true_barcodes:
             tbcs = [rank(bc, bc_len) for bc in true_barcodes]
         elif barcode_list:
-            listed = np.isin(self.uniq, rank_valid_many(barcode_list, bc_len).astype(np.uint32))
+            wl_ranks = barcode_list.ranks if isinstance(barcode_list, BarcodeRanks) else rank_valid_many(barcode_list, bc_len).astype(np.uint32)
+            listed = np.isin(self.uniq, wl_ranks)
             while i < len(by_count) and cnt[by_count[i]] > cutoff and n <= hi:
                 if listed[by_count[i]]:
                     tbcs.append(int(self.uniq[by_count[i]]))

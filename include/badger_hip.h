@@ -358,6 +358,12 @@ int      bdg_idstore_get(const bdg_idstore* s, uint64_t i, const char** p, uint3
  * them, bdg_extract_keep_records), the read ids into `ids`.  What badger.py does with read input (:112-117).  opts as for
  * bdg_stage1_run (header_every / format_threads unused); res->reads = reads seen. */
 int  bdg_stage1_collect(bdg_ctx* ctx, const char* in_path, const bdg_stage1_opts* opts, bdg_idstore* ids, bdg_stage1_result* res);
+/* A stage-1 TSV as badger.py reads it (:91-111): the read ids into `ids`; per read the rank of its observed barcode (a
+ * barcode of bc_len + 1 letters loses the last) and whether it has one of bc_len letters.  *rank / *usable are malloc'd
+ * arrays of *n entries: release with bdg_host_free.  BDG_E_FORMAT: no "#read_id" / "barcode" column; BDG_E_BADBASE: a
+ * usable barcode holds a letter outside ACGT (reference: KeyError from rank()), *bad_line = its line. */
+int  bdg_import_stage1_tsv(const char* path, uint32_t bc_len, bdg_idstore* ids, uint32_t** rank, uint8_t** usable, uint64_t* n, uint64_t* bad_line);
+void bdg_host_free(void* p);
 /* "<readID>\t<barcode>\n" per read under the header "readID\tbarcode" (output_file, barcode_graph.py:406-410): rank[i]
  * spelled out (common.py:27-38) where has[i] != 0, '*' elsewhere.  n must equal the store's count. */
 int  bdg_write_assignments(const bdg_idstore* ids, const uint32_t* rank, const uint8_t* has, uint64_t n, const char* path);

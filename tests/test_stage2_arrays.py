@@ -175,3 +175,59 @@ def test_device_clustering_and_assignment_equal_the_array_code(seed, thr, n_cell
     got_rank, got_has = d_r.to_host(), d_g.to_host()
     assert (got_has == want_has).all() and (got_rank[want_has == 1] == want_rank[want_has == 1]).all() and want_has.sum() > 1000
     dev.release_device()
+
+
+def test_barcode_list_file_as_ranks(tmp_path):
+    """BarcodeRanks.from_file = the ranks of exactly those lines of the file that the reference's set of lines could match
+    (16 letters of ACGT), whatever else the file holds; truthy even when empty, like the reference's set"""
+    from badger_amd.common import BarcodeRanks, rank_valid_many
+    rng = np.random.default_rng(4)
+    good = unrank_many(rng.integers(0, 1 << 32, 500, dtype=np.uint64).astype(np.uint32))
+    lines = good + ["", "ACGT", "ACGTACGTACGTACGTA", "ACGTACGTACGTACGN", "acgtacgtacgtacgt", good[3], "AAAAAAAAAAAAAAAA-1"]
+    rng.shuffle(lines)
+    for text in ("\n".join(lines) + "\n", "\n".join(lines), "\r\n".join(lines) + "\r\n", ""):
+        p = tmp_path / "wl.txt"
+        with open(p, "w", newline="") as f:
+            f.write(text)
+        with open(p) as f:
+            ref = set(f.read().split("\n"))
+        got = BarcodeRanks.from_file(str(p))
+        assert bool(got) and sorted(got.ranks.tolist()) == sorted(set(rank_valid_many(ref).astype(np.uint32).tolist()))
+    assert len(BarcodeRanks.from_file(str(p))) == 0
+
+
+def test_native_tsv_import_equals_the_python_one(tmp_path, golden_dir):
+    """bdg_import_stage1_tsv against badger.import_tsv + observed_from_strings (the restatement of badger.py:91-111): the
+    reference's own stage-1 TSV, and a file with repeated headers, short rows, NA barcodes, 17-letter barcodes, CRLF"""
+    from badger_amd import _native
+    cases = [os.path.join(golden_dir, "c1_expected.tsv")]
+    p = tmp_path / "odd.tsv"
+    head = "#read_id\tbarcode\tUMI\tBC_score\tvalid_UMI\tstrand\tpolyT_start\tR1_end"
+    rows = [head, "r1\tACGTACGTACGTACGT\tAAAA\t0\tFalse\t+\t5\t3", "r2\t*\t*\t-1\tFalse\t.\t-1\t-1", head, "r3\tACGTACGTACGTACGTA\tAAAA\t0\tFalse\t+\t5\t3",
+            "r4\tACG\tAAAA\t0\tFalse\t+\t5\t3", "r5", "r6\t\tx", "r7\tNA\tx", "r8\tTTTTTTTTTTTTTTTT\tx\t0"]
+    p.write_text("\n".join(rows) + "\n")
+    cases.append(str(p))
+    q = tmp_path / "crlf.tsv"
+    q.write_bytes(("\r\n".join(rows[:5]) + "\r\n").encode())
+    cases.append(str(q))
+    w = tmp_path / "swapped.tsv"
+    w.write_text("barcode\tx\t#read_id\nACGTACGTACGTACGT\t1\tq1\n*\t2\tq2\nbarcode\t3\t#read_id\n")
+    cases.append(str(w))
+    for path in cases:
+        ra, _ = badger.import_tsv(path, 16)
+        want_rank, want_usable = observed_from_strings([b for _, b in ra])
+        ids, rank, usable = _native.import_stage1_tsv(path, 16)
+        assert ids.to_list() == [r for r, _ in ra] and (usable == want_usable).all() and (rank[usable] == want_rank[usable]).all(), path
+    assert len(ids) == 2
+    bad = tmp_path / "bad.tsv"
+    bad.write_text(head + "\nr1\tACGTACGTACGTACGN\tAAAA\t0\tFalse\t+\t5\t3\n")
+    with pytest.raises(KeyError):
+        _native.import_stage1_tsv(str(bad), 16)
+    with pytest.raises(KeyError):
+        observed_from_strings([b for _, b in badger.import_tsv(str(bad), 16)[0]])
+    nohead = tmp_path / "nohead.tsv"
+    nohead.write_text("a\tb\nr1\tACGTACGTACGTACGT\n")
+    with pytest.raises(ValueError):
+        _native.import_stage1_tsv(str(nohead), 16)
+    with pytest.raises(ValueError):
+        badger.import_tsv(str(nohead), 16)
