@@ -35,8 +35,6 @@ struct bdg_ctx {
     hipEvent_t ev_main = nullptr, ev_aux[2] = { nullptr, nullptr };
     uint64_t aux_count = 0;                 // matches queued on aux_stream so far
     bool overlap = false, aux_pending = false;
-    hipStream_t copy_stream = nullptr;      // bdg_extract_submit: second half of a large host-to-device copy (a second DMA engine)
-    hipEvent_t ev_copy = nullptr;
     hipStream_t launch_stream = nullptr;    // where kernels (and their timing events) currently go: stream, or aux_stream
     std::string err;
     bool profiling = false;

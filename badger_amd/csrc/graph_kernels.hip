@@ -879,7 +879,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             hipLaunchKernelGGL(k_graph_qjoin<QJ_W>, dim3(grid), dim3(256), 0, st, d_ranks, n, row_begin, row_end, v_out, pos_of, split, G,
                                thr, qgram_T, 1, d_out, cap, reinterpret_cast<unsigned long long*>(d_n_edges));
         } else {
-            ScopedKernelTimer tm(ctx, "k_graph_qjoin");
+            ScopedKernelTimer tm(ctx, "k_graph_qjoin_w");
             const int var = ctx->g_qjw_variant;
             const uint32_t waves = qgram_T < 2 ? 4u : (var == 1 ? 2u : (var == 2 ? 1u : 4u));
             uint32_t grid = (uint32_t)ctx->g_qjw_per_cu * (uint32_t)ctx->g_cus;         // resident grid, one row per wave at a time, rows interleaved

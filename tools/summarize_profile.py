@@ -21,7 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def kname(full):
     i = full.find("k_")
-    return full[i:full.find("(", i)]
+    name = full[i:full.find("(", i)]
+    return name.split("<", 1)[0]              # (template arguments of a kernel are not part of its name here)
 
 
 summary = collections.defaultdict(dict)
