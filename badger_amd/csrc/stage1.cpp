@@ -338,7 +338,7 @@ int bdg_idstore_append(bdg_idstore* s, const char* ids, const uint64_t* off, uin
     if (!n) return BDG_OK;
     const uint64_t lo = off[0], bytes = off[n] - lo, base = s->text.size();
     s->text.insert(s->text.end(), ids + lo, ids + lo + bytes);
-    s->off.reserve(s->off.size() + n);
+    if (s->off.capacity() < s->off.size() + n) s->off.reserve(std::max<size_t>(s->off.size() + n, 2 * s->off.capacity()));   // (never to the exact size: appends come one id at a time, too)
     for (uint64_t i = 1; i <= n; ++i) s->off.push_back(base + (off[i] - lo));
     return BDG_OK;
 }

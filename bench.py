@@ -117,7 +117,7 @@ def profile_counters(kernel):
             out["source"] = "profiles/%s is from build %r, this is %r: not reported" % (name, meta.get("lib"), lib_version)
             continue
         out[key] = d.get(kernel)
-        out["source"] = "profiles/%s@%s (rocprofv3 --pmc, %s)" % (name, meta.get("tag"), lib_version)
+        out["source"] = "profiles/{traffic,valu,lds}.json@%s (rocprofv3 --pmc, %s)" % (meta.get("tag"), lib_version)
     return out
 
 
