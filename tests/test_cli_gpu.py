@@ -366,3 +366,21 @@ def test_stage1_iupac_codes_in_bam_raise_keyerror(tmp_path):
     open(p, "wb").write(bamio.bgzf(bamio.bam_raw([("a", 4, "ACGTNACGTACGTACGTTTTTT"), ("b", 4, "")])))
     with pytest.raises(TypeError):
         erb.main(["--mode", "tenX_v3", "-i", p, "-o", str(tmp_path / "o.tsv"), "-t", "1"])
+
+
+def test_stage1_gpus_flag_over_contexts_of_one_device(tmp_path, monkeypatch):
+    """--gpus 3 as the command line drives it (chunk k on context k mod 3, two in flight each, rows in input order), rehearsed
+    on one device with three independent contexts: the TSV and .stats are those of the one-context run, in both file shapes"""
+    path, rows, recs = _fastq_of(tmp_path, 40000, 31)
+    header = "#read_id\tbarcode\tUMI\tBC_score\tvalid_UMI\tstrand\tpolyT_start\tR1_end"
+    monkeypatch.setenv("BADGER_AMD_CONTEXTS_ON_ONE_DEVICE", "1")
+    monkeypatch.setenv("BADGER_AMD_SEGMENT_MB", "1")                      # 80 parse segments: many chunks per context
+    outs = {}
+    for gpus in ("1", "3"):
+        for t in ("1", "5"):
+            out = str(tmp_path / ("g%s_t%s.tsv" % (gpus, t)))
+            erb.main(["--mode", "tenX_v3", "-i", path, "-o", out, "-t", t, "--gpus", gpus])
+            outs[(gpus, t)] = (open(out).read(), open(out + ".stats").read())
+    assert outs[("1", "1")] == outs[("3", "1")] and outs[("1", "5")] == outs[("3", "5")]
+    assert outs[("3", "1")][0] == "\n".join([header] + rows) + "\n"
+    assert outs[("3", "5")][0] == "\n".join([header] + rows) + "\n"       # 40,000 reads: one chunk of the reference's 100,000, one header
