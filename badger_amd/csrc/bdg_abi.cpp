@@ -100,10 +100,13 @@ static int collect_timers(bdg_ctx* ctx)
 
 extern "C" {
 
-#ifndef BDG_SRC_HASH
-#define BDG_SRC_HASH "unhashed"
+#ifndef BDG_KERNEL_HASH
+#define BDG_KERNEL_HASH "unhashed"
 #endif
-const char* bdg_version(void) { return "badger_hip 0.2 (gfx950) src " BDG_SRC_HASH; }
+#ifndef BDG_HOST_HASH
+#define BDG_HOST_HASH "unhashed"
+#endif
+const char* bdg_version(void) { return "badger_hip 0.3 (gfx950) kernels " BDG_KERNEL_HASH " host " BDG_HOST_HASH; }
 
 int bdg_device_count(void)
 {

@@ -701,7 +701,8 @@ struct bdg_ingest : ChunkSink {
         emit(full);
         IngestChunk* c = pool_get();
         if (c && !chunk_prepare(c, chunk_reads, (size_t)chunk_reads * 64, (size_t)chunk_reads * 16)) { seqp.oom(); }
-        return c ? c : full;                                         // (stopping: the parse is abandoned anyway)
+        if (!c) seqp.fail("reader stopped");                         // (closing: the parse is abandoned)
+        return c ? c : full;
     }
 
     void worker_loop()
@@ -822,6 +823,16 @@ struct bdg_ingest : ChunkSink {
                 ok = seqp.feed(s->data, s->len);
                 // (text before a damaged spot is still parsed: a sequential reader would have delivered it)
                 if (ok && s->failed) { seqp.fail("read error: " + s->err); ok = false; }
+                // A segment no reader could start in (a record longer than a segment, wrapped FASTQ lines, ...) went into the
+                // chunk in front of it; where that happens segment after segment the chunk must not grow without bound.
+                if (ok && !seq_mode && seqp.c->n >= chunk_reads) {
+                    IngestChunk* old = seqp.c;
+                    IngestChunk* nc = fresh();
+                    if (!nc) ok = false;
+                    else if (seqp.record_open()) { if (!seqp.move_open_record(nc)) { pool_put(nc); ok = false; } }
+                    else seqp.c = nc;
+                    if (ok) emit(old);
+                }
             } else {
                 ok = seqp.feed(s->data, s->head_len);
                 if (ok && s->head_len < s->len) {

@@ -95,6 +95,12 @@ def cpu_baseline(bases_dev, off_dev, wl):
             "value_1core": 1.0 / (1.0 / ext_one + 1.0 / near_one)}
 
 
+def kernels_hash(lib_version):
+    """the device-side source hash inside bdg_version() ("... kernels <hash> host <hash>")"""
+    parts = lib_version.split()
+    return parts[parts.index("kernels") + 1] if "kernels" in parts[:-1] else lib_version
+
+
 def profile_counters(kernel):
     """HBM bytes / vector instructions per launch of `kernel` from the committed rocprofv3 PMC passes
     (tools/pmc_profile.sh -> tools/summarize_profile.py), only if they were taken from this very build of the
@@ -104,6 +110,7 @@ def profile_counters(kernel):
         lib_version = _native.load().bdg_version().decode()
     except Exception:
         return out
+    kernels = kernels_hash(lib_version)
     for name, key in (("traffic.json", "traffic"), ("valu.json", "valu"), ("lds.json", "lds")):
         f = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(f):
@@ -113,8 +120,8 @@ def profile_counters(kernel):
         except Exception:
             continue
         meta = d.get("_meta", {})
-        if meta.get("lib") != lib_version:
-            out["source"] = "profiles/%s is from build %r, this is %r: not reported" % (name, meta.get("lib"), lib_version)
+        if meta.get("kernels") != kernels:              # (per-launch counters belong to the device code: the host side may differ)
+            out["source"] = "profiles/%s is from kernels %r, these are %r: not reported" % (name, meta.get("kernels"), kernels)
             continue
         out[key] = d.get(kernel)
         out["source"] = "profiles/{traffic,valu,lds}.json@%s (rocprofv3 --pmc, %s)" % (meta.get("tag"), lib_version)

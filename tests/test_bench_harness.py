@@ -51,11 +51,13 @@ def test_profile_counters_only_for_the_measured_build(monkeypatch, tmp_path):
     prof = tmp_path / "profiles"
     prof.mkdir()
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    json.dump({"k_scan_reads": 123.0, "_meta": {"lib": "some other build", "tag": "old"}}, open(prof / "traffic.json", "w"))
-    json.dump({"k_scan_reads": 9.0, "_meta": {"lib": lib, "tag": "new"}}, open(prof / "valu.json", "w"))
+    kh = bench.kernels_hash(lib)
+    assert kh != lib and kh in lib                       # "... kernels <hash> host <hash>": counters follow the device code only
+    json.dump({"k_scan_reads": 123.0, "_meta": {"lib": "some other build", "kernels": "0123456789ab", "tag": "old"}}, open(prof / "traffic.json", "w"))
+    json.dump({"k_scan_reads": 9.0, "_meta": {"lib": "a build with another host side", "kernels": kh, "tag": "new"}}, open(prof / "valu.json", "w"))
     pc = bench.profile_counters("k_scan_reads")
     assert pc["traffic"] is None and pc["valu"] == 9.0
-    json.dump({"k_scan_reads": 123.0, "_meta": {"lib": lib, "tag": "new"}}, open(prof / "traffic.json", "w"))
+    json.dump({"k_scan_reads": 123.0, "_meta": {"lib": lib, "kernels": kh, "tag": "new"}}, open(prof / "traffic.json", "w"))
     pc = bench.profile_counters("k_scan_reads")
     assert pc["traffic"] == 123.0 and "new" in pc["source"]
 

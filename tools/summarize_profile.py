@@ -73,7 +73,10 @@ for k, s in summary.items():
         traffic[k] = s["hbm_bytes_fetch_x2"] if k in STREAMING else s["hbm_bytes_fetch_x1"]
 sys.path.insert(0, ROOT)
 from badger_amd import _native  # noqa: E402  (dlopen only: which build of the library the counters belong to)
-meta = {"lib": _native.load().bdg_version().decode(), "tag": tag}
+lib = _native.load().bdg_version().decode()
+parts = lib.split()
+# (the counters belong to the device code; "summarised_with" only says which build of the library ran this script)
+meta = {"kernels": parts[parts.index("kernels") + 1] if "kernels" in parts[:-1] else lib, "tag": tag, "summarised_with": lib}
 traffic["_meta"] = meta
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(summary, open(os.path.join(ROOT, "profiles", tag + "_summary.json"), "w"), indent=1, sort_keys=True)
@@ -89,4 +92,4 @@ for k in sorted(summary):
     s = summary[k]
     print("%-26s avg %8.1f us  VALU %6.1fM  hbm %s" % (k, s.get("avg_ns", 0) / 1e3, s.get("SQ_INSTS_VALU", 0) / 1e6,
                                                      ("%.3f GB" % (traffic[k] / 1e9)) if k in traffic else "-"))
-print("library:", meta["lib"])
+print("library:", meta["summarised_with"])
