@@ -36,7 +36,7 @@ EXPORTS = [
     "bdg_extract_set_strand_rule",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo", "bdg_nearest16_index_bytes",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev", "bdg_rows_of_dev",
-    "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host",
+    "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host", "bdg_keep_observed",
     "bdg_ingest_open", "bdg_ingest_open_mt", "bdg_ingest_open_ex", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error",
     "bdg_ingest_reads", "bdg_ingest_close", "bdg_format_rows", "bdg_stage1_run",
     "bdg_cluster_dev", "bdg_assign_reads_dev", "bdg_idstore_new", "bdg_idstore_free", "bdg_idstore_count", "bdg_idstore_append",
@@ -144,6 +144,7 @@ def load():
     L.bdg_extract_keep_records.argtypes = [vp, C.c_int]
     L.bdg_kept_records.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.bdg_kept_records_to_host.argtypes = [vp, vp, u64]
+    L.bdg_keep_observed.argtypes = [vp, vp, vp, u64]
     L.bdg_ingest_open.argtypes = [C.c_char_p, u32, u32, C.c_int, C.POINTER(vp)]
     L.bdg_ingest_open_mt.argtypes = [C.c_char_p, u32, u32, C.c_int, u32, C.POINTER(vp)]
     L.bdg_ingest_open_ex.argtypes = [C.c_char_p, C.POINTER(IngestOpts), C.POINTER(vp)]
@@ -264,6 +265,14 @@ class Context:
     def extract_keep_records(self, on=True):
         """keep (a copy of) every collected chunk's records on the device, in order, for the stage-2 hand-off"""
         self._check(self.lib.bdg_extract_keep_records(self.h, 1 if on else 0))
+
+    def keep_observed(self, rank, usable):
+        """the observed barcodes of a stage-1 TSV (rank uint32[n], usable bool[n]) as the kept records"""
+        rank = np.ascontiguousarray(rank, dtype=np.uint32)
+        usable = np.ascontiguousarray(usable, dtype=np.uint8)
+        if len(rank) != len(usable):
+            raise ValueError("rank and usable differ in length")
+        self._check(self.lib.bdg_keep_observed(self.h, rank.ctypes.data, usable.ctypes.data, len(rank)))
 
     def kept_records(self):
         """-> (device pointer, count) of the records kept since extract_keep_records(True)"""

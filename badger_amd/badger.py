@@ -123,13 +123,19 @@ def main(args):
     from .stage2 import Stage2, observed_from_strings
     warm.join()
     st2 = Stage2(args.threshold, device=args.device)
-    from_device = None
     if args.reads.endswith("tsv"):
         read_ids, obs_rank, usable = _native.import_stage1_tsv(args.reads, bc_len)      # (import_tsv below, natively)
         logger.info("Imported barcodes from file")
         logger.info("Initializing Graph")
-        st2.count_host(obs_rank, usable)
-        st2.build_edges()
+        # the observed barcodes go to the device as records (bdg_keep_observed): from here on the TSV route is the route of
+        # read input - counting, edges, clustering and the per-read assignment run there
+        ctx = _native.default_context(args.device)
+        ctx.keep_observed(obs_rank, usable)
+        mark("import")
+        st2.count_device(ctx)
+        mark("count")
+        st2.build_edges(ctx, on_device=True)
+        from_device = ctx
     elif is_native_input(args.reads):
         # FASTA / FASTQ / SAM / BAM: the records of every chunk stay on the device (stage 1 -> stage 2 hand-off without host
         # strings): counting and the edge build run there, the host only gets the per-read ranks for the output file.
@@ -160,11 +166,8 @@ def main(args):
     st2.cluster(true_barcodes, barcode_list, args.n_cells, bc_len, args.interval)
     mark("cluster")
     logger.info("Clustering done")
-    if from_device is not None:
-        st2.output_file_from_device(read_ids, from_device, args.output, args.high_sens)
-        from_device.extract_keep_records(False)
-    else:
-        st2.output_file(read_ids, obs_rank, usable, args.output, args.high_sens)
+    st2.output_file_from_device(read_ids, from_device, args.output, args.high_sens)
+    from_device.extract_keep_records(False)
     st2.release_device()
     mark("output")
     print(st2.disconnected())          # "disconnected" count (reference :131-132)

@@ -18,6 +18,7 @@ int bdg_whitelist_load_impl(bdg_ctx*, const uint32_t*, uint32_t);
 int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, int, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
 int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*);
 int bdg_distinct_launch(bdg_ctx*, const bdg_extract_rec*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+int bdg_records_of_observed_launch(bdg_ctx*, const uint32_t*, const uint8_t*, uint64_t, bdg_extract_rec*);
 int bdg_rows_of_launch(bdg_ctx*, const uint32_t*, uint32_t, const uint32_t*, uint64_t, uint32_t, uint32_t*);
 int bdg_cluster_launch(bdg_ctx*, const uint32_t*, const uint32_t*, uint64_t, uint32_t, int32_t*);
 int bdg_assign_reads_launch(bdg_ctx*, const bdg_extract_rec*, uint64_t, const uint32_t*, uint32_t, const uint32_t*, const uint8_t*, uint32_t*, uint8_t*);
@@ -473,6 +474,27 @@ int bdg_extract_keep_records(bdg_ctx* ctx, int on)
         (void)hipFree(ctx->x_allrecs.p);
         ctx->x_allrecs = DevBuf();
     }
+    return BDG_OK;
+}
+
+int bdg_keep_observed(bdg_ctx* ctx, const uint32_t* rank, const uint8_t* usable, uint64_t n)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (n && (!rank || !usable)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    if (n >= (1ull << 32)) return bdg_fail(ctx, BDG_E_ARG, "more than 2^32 - 1 reads");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = bdg_extract_keep_records(ctx, 1);                       // (an empty array; what was kept before is dropped)
+    if (rc || n == 0) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->x_allrecs, sizeof(bdg_extract_rec) * n))) return rc;
+    // the two host arrays through the scratch buffer (pageable memory: the copies return when the data has left it)
+    if ((rc = bdg_reserve(ctx, ctx->g_tmp1, 5 * n + 16))) return rc;
+    uint32_t* const d_rank = static_cast<uint32_t*>(ctx->g_tmp1.p);
+    uint8_t* const d_usable = reinterpret_cast<uint8_t*>(d_rank + n);
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(d_rank, rank, 4 * n, hipMemcpyHostToDevice, ctx->stream));
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(d_usable, usable, n, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = bdg_records_of_observed_launch(ctx, d_rank, d_usable, n, static_cast<bdg_extract_rec*>(ctx->x_allrecs.p)))) return rc;
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));             // (the scratch buffer is free for the next user)
+    ctx->x_allrecs_n = n;
     return BDG_OK;
 }
 

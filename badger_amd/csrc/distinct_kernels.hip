@@ -41,6 +41,25 @@ void k_distinct_finish(const unsigned long long* __restrict__ ukeys, const uint3
     first[j] = sorted_vals[uoffsets[j]];
 }
 
+// Observed barcodes that come from a stage-1 TSV (badger.py:91-111) instead of from an extraction: the records the
+// rest of stage 2 reads (bc_rank, valid, flags) for them, so that counting and assignment run the same device code.
+__global__ __launch_bounds__(256)
+void k_records_of_observed(const uint32_t* __restrict__ rank, const uint8_t* __restrict__ usable, uint64_t n,
+                           bdg_extract_rec* __restrict__ recs)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256ull + threadIdx.x;
+    if (i >= n) return;
+    const bool ok = usable[i] != 0;
+    bdg_extract_rec r;
+    r.polyT = -1; r.r1_end = -1; r.bc_start = 0; r.umi_start = 0; r.umi_end = 0;
+    r.bc_rank = ok ? rank[i] : 0u;
+    r.r1_score = 0; r.strand = 0;
+    r.valid = ok ? 1 : 0;
+    r.flags = ok ? (uint8_t)(BDG_FLAG_RANK_OK | BDG_FLAG_BC16) : (uint8_t)0;
+    r.reserved = 0;
+    recs[i] = r;
+}
+
 // rows[i] = position of values[i * stride] in the ascending array sorted[0..n), NONE when absent: what turns an edge's
 // two ranks (the reference keys its edges dict by rank, barcode_graph.py:245-247) into indices of the distinct-barcode
 // arrays the stage-2 array code works on.
@@ -60,6 +79,15 @@ void k_rows_of(const uint32_t* __restrict__ sorted, uint32_t n, const uint32_t* 
 }
 
 }  // namespace
+
+int bdg_records_of_observed_launch(bdg_ctx* ctx, const uint32_t* d_rank, const uint8_t* d_usable, uint64_t n, bdg_extract_rec* d_recs)
+{
+    if (n == 0) return BDG_OK;
+    ScopedKernelTimer tm(ctx, "k_records_of_observed");
+    hipLaunchKernelGGL(k_records_of_observed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_rank, d_usable, n, d_recs);
+    BDG_HIP_TRY(ctx, hipGetLastError());
+    return BDG_OK;
+}
 
 int bdg_rows_of_launch(bdg_ctx* ctx, const uint32_t* d_sorted, uint32_t n, const uint32_t* d_values, uint64_t m,
                        uint32_t stride, uint32_t* d_rows)

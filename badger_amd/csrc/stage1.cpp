@@ -12,6 +12,8 @@
 #include "bdg_common.hpp"
 
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -417,80 +419,130 @@ int bdg_import_stage1_tsv(const char* path, uint32_t bc_len, bdg_idstore* ids, u
     if (!path || !ids || !rank_out || !usable_out || !n_out || bc_len == 0 || bc_len > 16) return BDG_E_ARG;
     *rank_out = nullptr; *usable_out = nullptr; *n_out = 0;
     if (bad_line) *bad_line = 0;
-    FILE* f = fopen(path, "rb");
-    if (!f) return BDG_E_ARG;
-    std::vector<char> buf;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return BDG_E_ARG;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { ::close(fd); return BDG_E_ARG; }
+    const size_t size = (size_t)sb.st_size;
+    if (size == 0) { ::close(fd); return BDG_OK; }
+    void* const map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (map == MAP_FAILED) return BDG_E_ARG;
+    const char* const begin = static_cast<const char*>(map);
+    const char* const end = begin + size;
+
+    // the first line names the columns
+    int ci = -1, cb = -1;
+    const char* body;
     {
-        fseek(f, 0, SEEK_END);
-        const long sz = ftell(f);
-        fseek(f, 0, SEEK_SET);
-        buf.resize(sz > 0 ? (size_t)sz : 0);
-        if (sz > 0 && fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return BDG_E_ARG; }
-        fclose(f);
-    }
-    std::vector<uint32_t> ranks; std::vector<uint8_t> usable;
-    const char* p = buf.data(); const char* const end = p + buf.size();
-    int ci = -1, cb = -1; uint64_t line_no = 0;
-    auto is_na = [](const char* s, size_t l) {
-        static const char* const na[] = { "", "NA", "NaN", "nan", "N/A", "NULL", "null", "None" };      // what pandas reads as missing
-        for (const char* t : na) if (strlen(t) == l && memcmp(t, s, l) == 0) return true;
-        return false;
-    };
-    while (p < end) {
-        const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+        const char* nl = static_cast<const char*>(memchr(begin, '\n', size));
         const char* le = nl ? nl : end;
-        const char* next = nl ? nl + 1 : end;
-        if (le > p && le[-1] == '\r') --le;
-        ++line_no;
-        // fields ci and cb of the line
-        const char* fs[2] = { nullptr, nullptr }; size_t fl[2] = { 0, 0 };
-        int col = 0; const char* q = p;
-        if (line_no == 1) {
-            for (;;) {
-                const char* t = static_cast<const char*>(memchr(q, '\t', (size_t)(le - q)));
-                const size_t l = (size_t)((t ? t : le) - q);
-                if (l == 8 && memcmp(q, "#read_id", 8) == 0 && ci < 0) ci = col;
-                if (l == 7 && memcmp(q, "barcode", 7) == 0 && cb < 0) cb = col;
-                if (!t) break;
-                q = t + 1; ++col;
-            }
-            if (ci < 0 || cb < 0) return BDG_E_FORMAT;
-            p = next;
-            continue;
-        }
-        for (;;) {
+        body = nl ? nl + 1 : end;
+        if (le > begin && le[-1] == '\r') --le;
+        int col = 0;
+        for (const char* q = begin;; ++col) {
             const char* t = static_cast<const char*>(memchr(q, '\t', (size_t)(le - q)));
             const size_t l = (size_t)((t ? t : le) - q);
-            if (col == ci) { fs[0] = q; fl[0] = l; }
-            if (col == cb) { fs[1] = q; fl[1] = l; }
+            if (l == 8 && memcmp(q, "#read_id", 8) == 0 && ci < 0) ci = col;
+            if (l == 7 && memcmp(q, "barcode", 7) == 0 && cb < 0) cb = col;
             if (!t) break;
-            q = t + 1; ++col;
+            q = t + 1;
         }
-        p = next;
-        if (!fs[0] || !fs[1]) continue;                                        // fewer fields than the columns need
-        if ((fl[0] == 8 && memcmp(fs[0], "#read_id", 8) == 0) || (fl[1] == 7 && memcmp(fs[1], "barcode", 7) == 0)) continue;
-        size_t L = fl[1];
-        const bool none = is_na(fs[1], L) || (L == 1 && fs[1][0] == '*');
-        if (!none && L == (size_t)bc_len + 1) L = bc_len;
-        uint32_t r = 0; uint8_t ok = 0;
-        if (!none && L == bc_len) {
-            ok = 1;
-            for (uint32_t i = 0; i < bc_len; ++i) {
-                uint32_t c;
-                switch (fs[1][i]) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break;
-                                    default: if (bad_line) *bad_line = line_no; return BDG_E_BADBASE; }
-                r |= c << (2 * i);
-            }
-        }
-        const uint64_t off2[2] = { 0, fl[0] };
-        (void)bdg_idstore_append(ids, fs[0], off2, 1);
-        ranks.push_back(r); usable.push_back(ok);
+        if (ci < 0 || cb < 0) { munmap(map, size); return BDG_E_FORMAT; }
     }
-    const size_t n = ranks.size();
+
+    // the lines behind it, in ranges cut at line ends: one thread per range, results joined in file order
+    struct Part {
+        const char* lo; const char* hi;
+        std::vector<uint32_t> ranks; std::vector<uint8_t> usable; std::vector<char> text; std::vector<uint32_t> idlen;
+        uint64_t lines = 0, bad = 0;                     // lines seen; 1-based line (inside the range) of the first bad letter
+    };
+    const size_t body_bytes = (size_t)(end - body);
+    unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("BADGER_AMD_IMPORT_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+    nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, body_bytes >> 20));        // a megabyte per thread at least
+    std::vector<Part> parts(nt);
+    {
+        const char* at = body;
+        for (unsigned k = 0; k < nt; ++k) {
+            parts[k].lo = at;
+            const char* want = k + 1 == nt ? end : body + body_bytes / nt * (k + 1);
+            if (want < at) want = at;
+            if (want < end) { const char* nl = static_cast<const char*>(memchr(want, '\n', (size_t)(end - want))); want = nl ? nl + 1 : end; }
+            parts[k].hi = at = want;
+        }
+    }
+    auto parse = [&](Part& pt) {
+        static const char* const na[] = { "", "NA", "NaN", "nan", "N/A", "NULL", "null", "None" };      // what pandas reads as missing
+        const size_t bytes = (size_t)(pt.hi - pt.lo);
+        pt.ranks.reserve(bytes / 48); pt.usable.reserve(bytes / 48); pt.idlen.reserve(bytes / 48); pt.text.reserve(bytes / 3);
+        const char* p = pt.lo;
+        while (p < pt.hi) {
+            const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(pt.hi - p)));
+            const char* le = nl ? nl : pt.hi;
+            const char* next = nl ? nl + 1 : pt.hi;
+            if (le > p && le[-1] == '\r') --le;
+            ++pt.lines;
+            const char* fs[2] = { nullptr, nullptr }; size_t fl[2] = { 0, 0 };
+            int col = 0;
+            for (const char* q = p;; ++col) {
+                const char* t = static_cast<const char*>(memchr(q, '\t', (size_t)(le - q)));
+                const size_t l = (size_t)((t ? t : le) - q);
+                if (col == ci) { fs[0] = q; fl[0] = l; }
+                if (col == cb) { fs[1] = q; fl[1] = l; }
+                if (!t || (fs[0] && fs[1])) break;
+                q = t + 1;
+            }
+            p = next;
+            if (!fs[0] || !fs[1]) continue;                                        // fewer fields than the columns need
+            if ((fl[0] == 8 && memcmp(fs[0], "#read_id", 8) == 0) || (fl[1] == 7 && memcmp(fs[1], "barcode", 7) == 0)) continue;
+            size_t L = fl[1];
+            bool none = L == 1 && fs[1][0] == '*';
+            if (!none && L <= 4) for (const char* t : na) if (strlen(t) == L && memcmp(t, fs[1], L) == 0) { none = true; break; }
+            if (!none && L == (size_t)bc_len + 1) L = bc_len;
+            uint32_t r = 0; uint8_t ok = 0;
+            if (!none && L == bc_len) {
+                ok = 1;
+                for (uint32_t i = 0; i < bc_len; ++i) {
+                    uint32_t c;
+                    switch (fs[1][i]) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break;
+                                        default: pt.bad = pt.lines; return; }
+                    r |= c << (2 * i);
+                }
+            }
+            pt.text.insert(pt.text.end(), fs[0], fs[0] + fl[0]);
+            pt.idlen.push_back((uint32_t)fl[0]);
+            pt.ranks.push_back(r); pt.usable.push_back(ok);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; ++k) th.emplace_back([&, k] { parse(parts[k]); });
+        parse(parts[0]);
+        for (auto& t : th) t.join();
+    }
+    munmap(map, size);
+    uint64_t lines_before = 1;                                                     // (the header line)
+    size_t n = 0, text_bytes = 0;
+    for (const Part& pt : parts) {
+        if (pt.bad) { if (bad_line) *bad_line = lines_before + pt.bad; return BDG_E_BADBASE; }
+        lines_before += pt.lines; n += pt.ranks.size(); text_bytes += pt.text.size();
+    }
     *rank_out = static_cast<uint32_t*>(malloc(sizeof(uint32_t) * (n ? n : 1)));
     *usable_out = static_cast<uint8_t*>(malloc(n ? n : 1));
     if (!*rank_out || !*usable_out) { free(*rank_out); free(*usable_out); *rank_out = nullptr; *usable_out = nullptr; return BDG_E_NOMEM; }
-    if (n) { memcpy(*rank_out, ranks.data(), sizeof(uint32_t) * n); memcpy(*usable_out, usable.data(), n); }
+    ids->text.reserve(ids->text.size() + text_bytes);
+    ids->off.reserve(ids->off.size() + n);
+    size_t at = 0;
+    for (Part& pt : parts) {
+        const size_t m = pt.ranks.size();
+        if (m) { memcpy(*rank_out + at, pt.ranks.data(), sizeof(uint32_t) * m); memcpy(*usable_out + at, pt.usable.data(), m); }
+        at += m;
+        uint64_t o = ids->text.size();
+        ids->text.insert(ids->text.end(), pt.text.begin(), pt.text.end());
+        for (const uint32_t l : pt.idlen) { o += l; ids->off.push_back(o); }
+        pt = Part();                                                               // (its memory goes back before the next one is copied)
+    }
     *n_out = n;
     return BDG_OK;
 }

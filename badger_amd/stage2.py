@@ -76,10 +76,30 @@ class Stage2:
 
     # ------------------------------------------------------------------ counting
     def count_host(self, obs_rank, usable):
-        """distinct barcodes of the usable reads, in read order (counts in first-occurrence order = argsort(first))"""
+        """distinct barcodes of the usable reads, in read order (counts in first-occurrence order = argsort(first)).
+        One sort of (rank << 32 | position) gives the distinct ranks, their first positions, their counts and - kept for
+        per_read() - every usable read's place among the distinct ones."""
         r = obs_rank[usable]
-        self.uniq, self.first, self.count = np.unique(r, return_index=True, return_counts=True)
-        self.uniq = self.uniq.astype(np.uint32)
+        n = len(r)
+        if n == 0 or n >= 1 << 32:
+            self.uniq, self.first, self.count = np.unique(r, return_index=True, return_counts=True)
+            self.uniq = self.uniq.astype(np.uint32)
+            self._place = None
+            return
+        key = r.astype(np.uint64) << np.uint64(32) | np.arange(n, dtype=np.uint64)
+        key.sort()
+        rk = (key >> np.uint64(32)).astype(np.uint32)
+        idx = (key & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        new_run = np.empty(n, dtype=bool)
+        new_run[0] = True
+        np.not_equal(rk[1:], rk[:-1], out=new_run[1:])
+        start = np.flatnonzero(new_run)
+        self.uniq = rk[start]
+        self.first = idx[start]                               # (positions ascend inside a run: its first is the earliest read)
+        self.count = np.diff(np.append(start, n)).astype(np.int64)
+        place = np.empty(n, dtype=np.int64)
+        place[idx] = np.cumsum(new_run, dtype=np.int64) - 1
+        self._place = (obs_rank, usable, place)
 
     def count_device(self, ctx):
         """the same from the extraction records the context kept on the device (bdg_distinct_dev)"""
@@ -136,31 +156,47 @@ class Stage2:
 
     # ------------------------------------------------------------------ centres
     def get_cluster_centers(self, true_barcodes, bc_len, barcode_list, n_cells, interval):
-        """reference :252-277, on arrays.  Returns the centres as ranks, in the reference's order."""
-        order = np.argsort(self.first, kind="stable")                     # insertion order of the counts dict
-        cnt_ins = self.count[order]
-        by_count = order[np.argsort(-cnt_ins, kind="stable")]             # sorted(..., reverse=True) keeps ties in insertion order
-        cutoff = max(mean([int(x) for x in cnt_ins[:n_cells]]) / 5.0, 5)
+        """reference :252-277, on arrays.  Returns the centres as ranks, in the reference's order.  The reference sorts every
+        distinct barcode by count; its loops only ever walk the barcodes above the cutoff (a prefix of that order), so only
+        those are sorted here, and the rest of the order is produced if a loop really walks into it."""
+        nu = len(self.uniq)
+        cnt, first = self.count, self.first
+        # counts of the first n_cells barcodes in insertion order (the counts dict, :253-254)
+        if nu > n_cells:
+            head = np.argpartition(first, n_cells)[:n_cells]
+        else:
+            head = np.arange(nu)
+        cutoff = max(mean([int(x) for x in cnt[head]]) / 5.0, 5)      # (the mean of a set of integers: order does not matter)
         hi, lo = n_cells + n_cells * interval * 0.01, n_cells - n_cells * interval * 0.01
+        above = np.flatnonzero(cnt > cutoff)
+        # sorted(..., reverse=True) keeps ties in insertion order: by falling count, then by first occurrence
+        order = [above[np.lexsort((first[above], -cnt[above]))]]
+
+        def by_count(i):
+            if i >= len(order[0]) and len(order[0]) < nu:                # a loop walks past the barcodes above the cutoff
+                ins = np.argsort(first, kind="stable")
+                order[0] = ins[np.argsort(-cnt[ins], kind="stable")]
+            return int(order[0][i])
+
         tbcs, n, i = [], 0, 0
-        cnt = self.count
         if true_barcodes:
             tbcs = [rank(bc, bc_len) for bc in true_barcodes]
         elif barcode_list:
             wl_ranks = barcode_list.ranks if isinstance(barcode_list, BarcodeRanks) else rank_valid_many(barcode_list, bc_len).astype(np.uint32)
-            listed = np.isin(self.uniq, wl_ranks)
-            while i < len(by_count) and cnt[by_count[i]] > cutoff and n <= hi:
-                if listed[by_count[i]]:
-                    tbcs.append(int(self.uniq[by_count[i]]))
+            top = order[0]
+            listed = np.isin(self.uniq[top], wl_ranks)
+            while i < len(top) and n <= hi:                               # (every barcode of `top` is above the cutoff)
+                if listed[i]:
+                    tbcs.append(int(self.uniq[top[i]]))
                     n += 1
                 i += 1
         else:
-            while cnt[by_count[i]] > cutoff and n <= hi:
-                tbcs.append(int(self.uniq[by_count[i]]))
+            while cnt[by_count(i)] > cutoff and n <= hi:
+                tbcs.append(int(self.uniq[by_count(i)]))
                 i += 1
                 n += 1
         while n < lo:
-            tbcs.append(int(self.uniq[by_count[i]]))
+            tbcs.append(int(self.uniq[by_count(i)]))
             i += 1
             n += 1
         return tbcs
@@ -259,7 +295,11 @@ class Stage2:
         n = len(obs_rank)
         rank, got = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint8)
         if usable.any():
-            pos = np.searchsorted(self.uniq, obs_rank[usable])
+            kept = getattr(self, "_place", None)
+            if kept is not None and kept[0] is obs_rank and kept[1] is usable:
+                pos = kept[2]                                 # (count_host saw these very arrays)
+            else:
+                pos = np.searchsorted(self.uniq, obs_rank[usable])
             rank[usable] = assigned[pos]
             got[usable] = has[pos]
         return rank, got

@@ -47,7 +47,7 @@ def host_cores():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
-def cpu_baseline(bases_dev, off_dev, wl):
+def cpu_baseline(bases_dev, off_dev, wl, device_out=None):
     """The CPU oracle (a port of the reference algorithm) timed on this box's host cores, on a bounded sample of the
     same workload.  Only the checker is timed here; nothing the product path produces depends on it.
     Legs, each on all cores and on one core:
@@ -57,7 +57,9 @@ def cpu_baseline(bases_dev, off_dev, wl):
                path uses (a tuned CPU implementation).  `exhaustive`: Levenshtein against every entry, which is what the
                reference's postprocessing loop does against its ~5K centres (barcode_graph.py:376-384) - against 737K
                entries it is a lower bound nobody would run, reported for completeness only.
-    value = calls/s of extract + probe on all cores."""
+    value = calls/s of extract + probe on all cores.
+    device_out = (records, best_idx, best_ed, n_ties) of the last step: what the oracle computes for the timing is compared
+    with it record by record (the sample the CPU leg runs is the largest piece of oracle output this run has)."""
     from oracle import pyoracle as orc
     cores = host_cores()
     n_all, n_one = 100000, 3000
@@ -75,8 +77,19 @@ def cpu_baseline(bases_dev, off_dev, wl):
     q = recs["bc_rank"][(recs["flags"] & 2) != 0]
     orc.nearest16(q[:64], wl, 2, threads=cores, probe=True)                # warm (builds nothing persistent, pages the code in)
     t0 = time.perf_counter()
-    orc.nearest16(q, wl, 2, threads=cores, probe=True)
+    wi, we, wt = orc.nearest16(q, wl, 2, threads=cores, probe=True)
     near_all = len(q) / (time.perf_counter() - t0)
+    checked = None
+    if device_out is not None:
+        d_recs, d_idx, d_ed, d_ties = device_out
+        ok = (recs["flags"] & 2) != 0
+        got = d_recs[:n_all].cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+        gi = d_idx[:n_all].cpu().numpy().view(np.uint32)[ok]
+        ge = d_ed[:n_all].cpu().numpy()[ok]
+        gt = d_ties[:n_all].cpu().numpy().view(np.uint16)[ok]
+        if not ((got == recs).all() and (gi == wi).all() and (ge == we).all() and (gt == wt).all()):
+            raise SystemExit("parity failed: the first %d records / calls differ from the oracle's" % n_all)
+        checked = "the device's first %d records and %d calls equal the oracle's" % (n_all, len(q))
     q1 = q[:20000]
     t0 = time.perf_counter()
     orc.nearest16(q1, wl, 2, threads=1, probe=True)
@@ -92,7 +105,7 @@ def cpu_baseline(bases_dev, off_dev, wl):
             "extract_reads_per_s": ext_all, "extract_reads_per_s_1core": ext_one,
             "nearest_probe_calls_per_s": near_all, "nearest_probe_calls_per_s_1core": near_one,
             "nearest_exhaustive_calls_per_s": near_exh,
-            "value_1core": 1.0 / (1.0 / ext_one + 1.0 / near_one)}
+            "value_1core": 1.0 / (1.0 / ext_one + 1.0 / near_one), "checked": checked}
 
 
 def kernels_hash(lib_version):
@@ -292,16 +305,22 @@ def bench_graph(args, rank, world, dev, local_dev):
             "parity_sample": "ok",
         }
         if not args.no_cpu_baseline and world == 1:
+            # the whole job on the host cores: same rows, same index, and its edge list is the checker for the device's
             cores = host_cores()
-            m = min(n, 60000 if thr == 1 else 30000)
-            sub = np.sort(ranks[np.random.default_rng(1).permutation(n)[:m]])
             t0 = time.perf_counter()
-            orc.graph_edges(sub, thr, T, threads=cores)
+            want, t_index, t_rows = orc.graph_edges_sampled(ranks, thr, 1, T, threads=cores, cap=ne + 1)
             t_all = time.perf_counter() - t0
-            line["cpu_baseline"] = {"value": m / t_all, "unit": "rows/s", "cores": cores, "kind": "port",
+            got = e[np.lexsort((e[:, 1], e[:, 0]))]
+            same = len(want) == ne and np.array_equal(got[:, 0], want["a"]) and np.array_equal(got[:, 1], want["b"]) \
+                and np.array_equal(got[:, 2], want["dist"])
+            if not same:
+                raise SystemExit("parity failed: the device's edge list differs from the oracle's (%d against %d edges)" % (ne, len(want)))
+            line["parity_sample"] = "ok (all %d edges equal the oracle's)" % ne
+            line["cpu_baseline"] = {"value": n / (t_index + t_rows), "unit": "rows/s", "cores": cores, "kind": "port",
                                     "sample": "oracle graph_edges (QGramIndex buckets + 3 Levenshtein per candidate, "
-                                              "barcode_graph.py:207-249) on a %d-row subset, OpenMP over %d cores; the work per row "
-                                              "grows with the row count, so this rate is an upper bound for %d rows" % (m, cores, n)}
+                                              "barcode_graph.py:207-249) on the same %d rows, OpenMP over %d cores: index %.2f s, "
+                                              "rows %.2f s (sorting the edge list for the comparison, %.2f s more, is not counted)"
+                                              % (n, cores, t_index, t_rows, t_all - t_index - t_rows)}
         print(json.dumps(line))
 
 
@@ -494,7 +513,8 @@ def bench_calls(args, rank, world, dev, local_dev):
             "parity_sample": "ok",
         }
         if not args.no_cpu_baseline and world == 1:       # the CPU leg runs at N = 1 only (256 host threads would fight the other ranks)
-            line["cpu_baseline"] = cpu_baseline(bases, off_u, wl)
+            line["cpu_baseline"] = cpu_baseline(bases, off_u, wl, (recs, best_idx, best_ed, n_ties))
+            line["parity_sample"] = "ok (3 x 1000 records and calls after the timed region; " + line["cpu_baseline"].pop("checked") + ")"
         print(json.dumps(line))
     if world > 1:
         bdist.barrier(dev)

@@ -185,6 +185,11 @@ int  bdg_extract_collect(bdg_ctx* ctx, uint32_t slot, bdg_extract_rec* out);
  * an empty array; turning it off frees it. */
 int  bdg_extract_keep_records(bdg_ctx* ctx, int on);
 int  bdg_kept_records(bdg_ctx* ctx, const bdg_extract_rec** d_recs, uint64_t* n);
+/* The same hand-off for barcodes that come out of a stage-1 TSV (badger.py:91-111, bdg_import_stage1_tsv): n reads, rank[i]
+ * the rank of read i's barcode where usable[i] != 0 (host arrays).  They become the kept records (valid, bc_rank, flags; the
+ * other fields empty), replacing what was kept before, so that bdg_distinct_dev, the edge build, bdg_cluster_dev and
+ * bdg_assign_reads_dev serve the TSV route as they serve read input.  Synchronises. */
+int  bdg_keep_observed(bdg_ctx* ctx, const uint32_t* rank, const uint8_t* usable, uint64_t n);
 /* The kept records copied to host memory (the first min(n, cap) of them); synchronises.  output_file
  * (barcode_graph.py:388-410) needs every read's observed barcode once more, as a rank. */
 int  bdg_kept_records_to_host(bdg_ctx* ctx, bdg_extract_rec* out, uint64_t cap);

@@ -5,9 +5,11 @@
  * It restates WHAT the reference computes; it shares no code with it (the
  * reference is Python).  Citations are reference-relative file:line.
  */
+#define _POSIX_C_SOURCE 199309L                /* clock_gettime */
 #include "badger_oracle.h"
 
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -441,10 +443,23 @@ static void ev_push(edge_vec* e, uint32_t a, uint32_t b, uint32_t d)
     e->v[e->n].a = a; e->v[e->n].b = b; e->v[e->n].dist = d; e->n++;
 }
 
-uint64_t orc_graph_edges(const uint32_t* ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
-                         orc_edge* out, uint64_t cap, int threads)
+static double now_s(void)
 {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* The edges of every row_stride-th row of the sorted array (row i against all j > i of the WHOLE array), index over all
+ * n rows: the same work per row as the full job, on a bounded sample of rows.  t[0] = seconds spent building the index,
+ * t[1] = seconds in the row loop (NULL: not wanted). */
+uint64_t orc_graph_edges_sampled(const uint32_t* ranks, uint32_t n, uint32_t thr, int32_t qgram_T, uint32_t row_stride,
+                                 orc_edge* out, uint64_t cap, int threads, double* t)
+{
+    if (t) t[0] = t[1] = 0.0;
     if (n == 0) return 0;
+    if (row_stride < 1) row_stride = 1;
+    const double t_begin = now_s();
     if (threads < 1) threads = 1;
     uint32_t* r = (uint32_t*)malloc(sizeof(uint32_t) * n);
     memcpy(r, ranks, sizeof(uint32_t) * n);
@@ -463,6 +478,8 @@ uint64_t orc_graph_edges(const uint32_t* ranks, uint32_t n, uint32_t thr, int32_
     free(fill);
 
     edge_vec* per = (edge_vec*)calloc((size_t)threads, sizeof(edge_vec));
+    const double t_indexed = now_s();
+    const int64_t n_sampled = ((int64_t)n + row_stride - 1) / row_stride;
 #pragma omp parallel num_threads(threads)
     {
         int tid = 0;
@@ -472,8 +489,8 @@ uint64_t orc_graph_edges(const uint32_t* ranks, uint32_t n, uint32_t thr, int32_
         uint16_t* acc = (uint16_t*)calloc(n, sizeof(uint16_t));
         uint32_t* touched = (uint32_t*)malloc(sizeof(uint32_t) * n);
 #pragma omp for schedule(dynamic, 256)
-        for (int64_t ii = 0; ii < (int64_t)n; ++ii) {
-            uint32_t i = (uint32_t)ii, nt = 0;
+        for (int64_t ii = 0; ii < n_sampled; ++ii) {
+            uint32_t i = (uint32_t)(ii * row_stride), nt = 0;
             /* get_close (index.py:77-93): entries j > number */
             for (int p = 0; p < NQ; ++p) {
                 uint32_t g = (r[i] >> (2 * p)) & 0xFFFu;
@@ -495,18 +512,25 @@ uint64_t orc_graph_edges(const uint32_t* ranks, uint32_t n, uint32_t thr, int32_
         }
         free(acc); free(touched);
     }
+    if (t) { t[0] = t_indexed - t_begin; t[1] = now_s() - t_indexed; }
     uint64_t total = 0;
-    for (int t = 0; t < threads; ++t) total += per[t].n;
+    for (int w = 0; w < threads; ++w) total += per[w].n;
     orc_edge* all = (orc_edge*)malloc(sizeof(orc_edge) * (total ? total : 1));
     uint64_t k = 0;
-    for (int t = 0; t < threads; ++t) {
-        if (per[t].n) memcpy(all + k, per[t].v, per[t].n * sizeof(orc_edge));
-        k += per[t].n; free(per[t].v);
+    for (int w = 0; w < threads; ++w) {
+        if (per[w].n) memcpy(all + k, per[w].v, per[w].n * sizeof(orc_edge));
+        k += per[w].n; free(per[w].v);
     }
     qsort(all, total, sizeof(orc_edge), cmp_edge);
     for (uint64_t e = 0; e < total && e < cap; ++e) out[e] = all[e];
     free(all); free(per); free(bent); free(bstart); free(r);
     return total;
+}
+
+uint64_t orc_graph_edges(const uint32_t* ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
+                         orc_edge* out, uint64_t cap, int threads)
+{
+    return orc_graph_edges_sampled(ranks, n, thr, qgram_T, 1, out, cap, threads, NULL);
 }
 
 uint64_t orc_graph_edges_brute(const uint32_t* ranks, uint32_t n, uint32_t thr, int32_t qgram_T,

@@ -105,6 +105,11 @@ int  orc_qgram_threshold(int threshold, int bc_len, int q);
  * index.py:29-35,77-93.  Returns total edges found (may exceed cap). */
 uint64_t orc_graph_edges(const uint32_t* ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
                          orc_edge* out, uint64_t cap, int threads);
+/* The same for every row_stride-th row of the sorted array only (row i against every j > i of the whole array, index over
+ * all n rows): a bounded sample of the full-size job for bench.py's cpu_baseline and parity check.  t[0] / t[1] receive the
+ * seconds spent on the index / in the row loop (t may be NULL). */
+uint64_t orc_graph_edges_sampled(const uint32_t* ranks, uint32_t n, uint32_t thr, int32_t qgram_T, uint32_t row_stride,
+                                 orc_edge* out, uint64_t cap, int threads, double* t);
 /* Same edge set by brute force over all pairs (cross-check of the bucket method). */
 uint64_t orc_graph_edges_brute(const uint32_t* ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
                                orc_edge* out, uint64_t cap);

@@ -76,6 +76,9 @@ def lib():
     L.orc_qgram_threshold.restype = C.c_int
     L.orc_graph_edges.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint64, C.c_int]
     L.orc_graph_edges.restype = C.c_uint64
+    L.orc_graph_edges_sampled.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p, C.c_uint64,
+                                          C.c_int, C.c_void_p]
+    L.orc_graph_edges_sampled.restype = C.c_uint64
     L.orc_graph_edges_brute.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint64]
     L.orc_graph_edges_brute.restype = C.c_uint64
     L.orc_nearest16.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
@@ -196,6 +199,22 @@ def graph_edges(ranks, thr, qgram_T=None, threads=1, brute=False):
             tot = lib().orc_graph_edges(ranks.ctypes.data, len(ranks), thr, qgram_T, out.ctypes.data, cap, threads)
         if tot <= cap:
             return out[:tot]
+        cap = int(tot)
+
+
+def graph_edges_sampled(ranks, thr, row_stride, qgram_T=None, threads=1, cap=1 << 16):
+    """edges of every row_stride-th row of the sorted array against the whole array; returns (edges, seconds for the index,
+    seconds in the row loop)"""
+    ranks = np.ascontiguousarray(ranks, dtype=np.uint32)
+    if qgram_T is None:
+        qgram_T = qgram_threshold(thr)
+    t = np.zeros(2, dtype=np.float64)
+    while True:
+        out = np.zeros(cap, dtype=EDGE_DTYPE)
+        tot = lib().orc_graph_edges_sampled(ranks.ctypes.data, len(ranks), thr, qgram_T, row_stride, out.ctypes.data, cap,
+                                            threads, t.ctypes.data)
+        if tot <= cap:
+            return out[:tot], float(t[0]), float(t[1])
         cap = int(tot)
 
 

@@ -221,9 +221,11 @@ def test_distinct_dev_against_the_references_counts(golden_dir):
 
 def test_stage2_handoff_on_device_equals_the_tsv_route(tmp_path):
     """badger.py on a FASTQ (extraction records stay on the device -> bdg_distinct_dev -> bdg_graph_edges_dev) must write
-    what it writes from the stage-1 TSV of the same reads (host strings -> rank -> host counting -> bdg_graph_edges),
-    at both thresholds, and must really have taken the device route."""
-    from badger_amd import stage2
+    what it writes from the stage-1 TSV of the same reads (native import -> bdg_keep_observed -> the same device code), at
+    both thresholds; both must really have taken the device route, and both must equal what the host array code makes of
+    the TSV (numpy counting, searchsorted per read)."""
+    from badger_amd import stage2, _native
+    from badger_amd.common import BarcodeRanks
     path, rows, recs = _fastq_of(tmp_path, 30000, 23)
     tsv = str(tmp_path / "s1.tsv")
     erb.main(["--mode", "tenX_v3", "-i", path, "-o", tsv, "-t", "1"])
@@ -235,22 +237,37 @@ def test_stage2_handoff_on_device_equals_the_tsv_route(tmp_path):
         outs = []
         for k, reads in enumerate((tsv, path)):
             prefix = str(tmp_path / ("o%s_%d" % (thr, k)))
-            calls = []
-            orig = stage2.Stage2.count_device
+            calls, observed = [], []
+            orig, orig_keep = stage2.Stage2.count_device, _native.Context.keep_observed
 
             def spy(self, ctx, _orig=orig, _calls=calls):
                 _calls.append(1)
                 return _orig(self, ctx)
-            stage2.Stage2.count_device = spy
+
+            def spy_keep(self, rank, usable, _orig=orig_keep, _calls=observed):
+                _calls.append(len(rank))
+                return _orig(self, rank, usable)
+            stage2.Stage2.count_device, _native.Context.keep_observed = spy, spy_keep
             try:
                 with redirect_stdout(io.StringIO()):
                     badger.main(["-r", reads, "-d", "tenX_v3", "-l", wl, "-c", "300", "-t", thr, "-o", prefix] + (["-hs"] if thr == "2" else []))
             finally:
-                stage2.Stage2.count_device = orig
-            assert len(calls) == k                      # TSV: host route; FASTQ: device route
+                stage2.Stage2.count_device, _native.Context.keep_observed = orig, orig_keep
+            assert len(calls) == 1 and observed == ([30000] if k == 0 else [])      # both count on the device; the TSV's barcodes were sent there
             outs.append(open(prefix + "_output_file.tsv").read())
         assert outs[0] == outs[1] and outs[0].count("\n") == 30001
         assert sum(1 for l in outs[0].split("\n")[1:] if l and not l.endswith("*")) > 10000
+        # the host array code on the same TSV
+        ids, obs, usable = _native.import_stage1_tsv(tsv, 16)
+        st = stage2.Stage2(int(thr))
+        st.count_host(obs, usable)
+        st.build_edges()
+        with redirect_stdout(io.StringIO()):
+            st.cluster(None, BarcodeRanks.from_file(wl, 16), 300, 16, 25)
+        prefix = str(tmp_path / ("h%s" % thr))
+        st.output_file(ids, obs, usable, prefix, thr == "2")
+        st.release_device()
+        assert open(prefix + "_output_file.tsv").read() == outs[0]
 
 
 def test_stage2_from_fastx_input(tmp_path, golden_dir):

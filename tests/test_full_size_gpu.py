@@ -169,6 +169,9 @@ def test_config3_graph_probe_equals_scan_and_oracle_rows(world):
                 want.append((b, orc.dmin3(int(a), b)))
         mine = sorted((int(x["b"]), int(x["dist"])) for x in e_probe[e_probe["a"] == a])
         assert mine == sorted(want)
+    # and the whole list against the oracle's bucket method on the same 500,000 rows
+    want, _, _ = orc.graph_edges_sampled(ranks, 1, 1, 5, threads=16, cap=len(e_probe) + 1)
+    assert len(want) == len(e_probe) and (want == e_probe).all()
 
 
 def test_config2_distinct_on_device_matches_host_counting(world):
@@ -280,6 +283,9 @@ def test_config5_visium_scale_whitelist_and_thr2_graph(world):
                     want.append((int(b), d))
         lim = int(ranks[ranks > a][:40000][-1])
         assert sorted(want) == [m for m in mine if m[0] <= lim]
+    # the whole list against the oracle's bucket method on the same 500,000 rows (a few seconds of host time)
+    want, _, _ = orc.graph_edges_sampled(ranks, 2, 1, T, threads=16, cap=len(whole) + 1)
+    assert len(want) == len(whole) and (want == whole).all()
     # the edge condition depends on the pair only: the oracle's graph of a subset == the full graph restricted to it
     sub = np.sort(ranks[rng.permutation(n)[:6000]])
     want = orc.graph_edges(sub, 2, T, threads=8)

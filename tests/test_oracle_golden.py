@@ -174,6 +174,9 @@ def test_graph_edges(golden_dir):
         assert got == case["edges"], key
         eb = orc.graph_edges(uniq, thr, case["qgram_T"], brute=True)
         assert (eb == e).all()
+        # every third row of the sorted array against the whole array (bench.py's bounded form) = those rows of the list
+        es, t_index, t_rows = orc.graph_edges_sampled(uniq, thr, 3, case["qgram_T"], threads=2)
+        assert (es == e[np.isin(e["a"], np.sort(uniq)[::3])]).all() and t_index >= 0.0 and t_rows >= 0.0
     # the thr=2 filter is lossy: brute force without the S filter finds more
     case = g["cells60_thr2"]
     uniq = np.unique(np.array(_ranks_of(case["barcodes"]), dtype=np.uint32))

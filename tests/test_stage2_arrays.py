@@ -59,6 +59,39 @@ def test_unrank_many_and_observed():
         observed_from_strings(["ACGTACGTACGTACGN"])
 
 
+def test_centre_selection_walks_the_dictionary_mirrors_order():
+    """get_cluster_centers sorts only the barcodes above the cutoff and produces the rest of the order when a loop walks into
+    it: against the dictionary mirror of the reference's loops (barcode_graph.py:252-277) on random count tables - flat, wide
+    and heavy-tailed counts, with and without a barcode list, cell numbers around and beyond the number of barcodes."""
+    from badger_amd.barcode_graph import BarcodeGraph
+    from badger_amd.common import BarcodeRanks
+    rng = np.random.default_rng(11)
+    tails = 0
+    for it in range(400):
+        nu = int(rng.integers(1, 300))
+        st2 = Stage2(1)
+        st2.uniq = np.sort(rng.choice(1 << 20, nu, replace=False)).astype(np.uint32)
+        st2.first = rng.permutation(nu * 3)[:nu].astype(np.int64)
+        st2.count = [rng.integers(1, 4, nu), rng.integers(1, 60, nu), (rng.pareto(1.0, nu) * 3 + 1).astype(np.int64)][it % 3].astype(np.int64)
+        g = BarcodeGraph(1)
+        for i in np.argsort(st2.first):
+            g.counts[int(st2.uniq[i])] = int(st2.count[i])
+        n_cells, interval = int(rng.integers(1, nu + 30)), int(rng.integers(0, 60))
+        listed = np.unique(rng.choice(st2.uniq, max(1, nu // 2))) if it % 2 else None
+        wl_set = {synth.rank_to_str(int(r)) for r in listed} if listed is not None else None
+        wl_arr = BarcodeRanks(listed) if listed is not None else None
+
+        def run(f, wl):
+            try:
+                return f(None, 16, wl, n_cells, interval)
+            except IndexError:
+                return "IndexError"
+        want, got = run(g.get_cluster_centers, wl_set), run(st2.get_cluster_centers, wl_arr)
+        assert got == want, (it, nu, n_cells, interval)
+        tails += isinstance(want, list) and len(want) > int((st2.count > 5).sum())
+    assert tails > 20                                  # the walk past the cutoff happened
+
+
 @pytest.mark.parametrize("seed,thr,n_cells,hs_wl", [(1, 1, 40, "list"), (2, 2, 25, "list"), (3, 1, 30, "none"), (4, 2, 60, "true"), (5, 1, 8, "list")])
 def test_arrays_equal_dictionary_mirror(tmp_path, seed, thr, n_cells, hs_wl):
     ids, bcs = _reads(n_cells, 6000, seed)
@@ -231,3 +264,43 @@ def test_native_tsv_import_equals_the_python_one(tmp_path, golden_dir):
         _native.import_stage1_tsv(str(nohead), 16)
     with pytest.raises(ValueError):
         badger.import_tsv(str(nohead), 16)
+
+
+def test_native_tsv_import_in_ranges(tmp_path, monkeypatch):
+    """The importer parses the file in line-aligned byte ranges, one thread each, and joins them in file order: 1, 3 and 5
+    threads give the same ids / ranks / flags on a 5 MB file with odd rows sprinkled in (repeated headers, short rows, '*',
+    17-letter barcodes, no final newline), and a bad letter far into the file is reported with its line number."""
+    from badger_amd import _native
+    rng = np.random.default_rng(3)
+    head = "#read_id\tbarcode\tUMI\tBC_score\tvalid_UMI\tstrand\tpolyT_start\tR1_end"
+    ranks = rng.integers(0, 1 << 32, 110000, dtype=np.uint64).astype(np.uint32)
+    lines = [head]
+    for i, r in enumerate(ranks):
+        bc = synth.rank_to_str(int(r))
+        if i % 997 == 0:
+            lines.append(head)
+        if i % 13 == 0:
+            lines.append("read_%d\t*\t*\t-1\tFalse\t.\t-1\t-1" % i)
+        elif i % 101 == 0:
+            lines.append("read_%d" % i)
+        elif i % 37 == 0:
+            lines.append("read_%d\t%sA\tACGTACGTACGT\t0\tTrue\t+\t120\t60" % (i, bc))
+        else:
+            lines.append("read_%d\t%s\tACGTACGTACGT\t0\tTrue\t+\t120\t60" % (i, bc))
+    p = tmp_path / "big.tsv"
+    p.write_text("\n".join(lines))                          # (no newline behind the last row)
+    assert p.stat().st_size > 5 << 20
+    ra, _ = badger.import_tsv(str(p), 16)
+    want_rank, want_usable = observed_from_strings([b for _, b in ra])
+    for threads in ("1", "3", "5"):
+        monkeypatch.setenv("BADGER_AMD_IMPORT_THREADS", threads)
+        ids, rank, usable = _native.import_stage1_tsv(str(p), 16)
+        assert len(ids) == len(ra) and ids.to_list() == [r for r, _ in ra], threads
+        assert (usable == want_usable).all() and (rank[usable] == want_rank[usable]).all(), threads
+    bad_at = len(lines) - 5000
+    lines[bad_at] = "read_x\tACGTACGTACGTACGN\tAAAA\t0\tFalse\t+\t5\t3"
+    p.write_text("\n".join(lines) + "\n")
+    for threads in ("1", "4"):
+        monkeypatch.setenv("BADGER_AMD_IMPORT_THREADS", threads)
+        with pytest.raises(KeyError, match="line %d " % (bad_at + 1)):
+            _native.import_stage1_tsv(str(p), 16)
