@@ -35,7 +35,7 @@ EXPORTS = [
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_extract_set_strand_rule",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo", "bdg_nearest16_index_bytes",
-    "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_set_algo", "bdg_distinct_dev", "bdg_rows_of_dev",
+    "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_edges_part_dev", "bdg_graph_set_algo", "bdg_distinct_dev", "bdg_rows_of_dev",
     "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host", "bdg_keep_observed",
     "bdg_ingest_open", "bdg_ingest_open_mt", "bdg_ingest_open_ex", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error",
     "bdg_ingest_reads", "bdg_ingest_close", "bdg_format_rows", "bdg_stage1_run",
@@ -136,6 +136,7 @@ def load():
     L.bdg_graph_edges.argtypes = [vp, vp, u32, u32, i32, vp, u64, C.POINTER(u64)]
     L.bdg_graph_edges_dev.argtypes = [vp, vp, u32, u32, i32, vp, u64, vp]
     L.bdg_graph_edges_rows_dev.argtypes = [vp, vp, u32, u32, u32, u32, i32, vp, u64, vp]
+    L.bdg_graph_edges_part_dev.argtypes = [vp, vp, u32, u32, u32, u32, i32, vp, u64, vp]
     L.bdg_graph_set_algo.argtypes = [vp, C.c_int]
     L.bdg_distinct_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     L.bdg_rows_of_dev.argtypes = [vp, vp, u32, vp, u64, u32, vp]
@@ -361,6 +362,11 @@ class Context:
         """edges whose smaller rank is row row_begin <= i < row_end of the sorted array (one GPU's share)"""
         self._check(self.lib.bdg_graph_edges_rows_dev(self.h, d_ranks.data_ptr(), n, row_begin, row_end, thr, qgram_T,
                                                       d_out.data_ptr(), cap, d_n_edges.data_ptr()))
+
+    def graph_edges_part_dev(self, d_ranks, n, part, nparts, thr, qgram_T, d_out, cap, d_n_edges):
+        """one of nparts disjoint shares of the edge list, cut by the library so that the shares cost the same (one GPU's share)"""
+        self._check(self.lib.bdg_graph_edges_part_dev(self.h, _ptr(d_ranks), n, part, nparts, thr, qgram_T,
+                                                      _ptr(d_out), cap, _ptr(d_n_edges)))
 
     def graph_set_algo(self, algo):
         self._check(self.lib.bdg_graph_set_algo(self.h, algo))

@@ -5,6 +5,7 @@
 #include <cstddef>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <mutex>
 
@@ -16,7 +17,8 @@ int bdg_extract_judge_host(bdg_ctx*, const void*, uint64_t, uint64_t*, uint64_t*
 size_t bdg_extract_counter_bytes();
 int bdg_whitelist_load_impl(bdg_ctx*, const uint32_t*, uint32_t);
 int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, int, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
-int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*);
+int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*, uint32_t part = 0, uint32_t nparts = 1);
+int bdg_graph_plan(const bdg_ctx*, uint32_t, uint32_t);
 int bdg_distinct_launch(bdg_ctx*, const bdg_extract_rec*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 int bdg_records_of_observed_launch(bdg_ctx*, const uint32_t*, const uint8_t*, uint64_t, bdg_extract_rec*);
 int bdg_rows_of_launch(bdg_ctx*, const uint32_t*, uint32_t, const uint32_t*, uint64_t, uint32_t, uint32_t*);
@@ -130,6 +132,7 @@ int bdg_init(int device_id, bdg_ctx** out)
         delete ctx; g_err_noctx = "hipStreamCreate failed"; return BDG_E_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (const char* e2 = getenv("BADGER_AMD_D2_MIN_ROWS")) ctx->g_d2_min_rows = (uint32_t)strtoul(e2, nullptr, 10);      // (for measurements)
     *out = ctx;
     return BDG_OK;
 }
@@ -607,7 +610,7 @@ int bdg_nearest16(bdg_ctx* ctx, const uint32_t* q, uint32_t nq, const uint32_t* 
 // ---- graph --------------------------------------------------------------------
 int bdg_graph_set_algo(bdg_ctx* ctx, int algo)
 {
-    if (!ctx || algo < 0 || algo > 4) return BDG_E_ARG;
+    if (!ctx || algo < 0 || algo > 5) return BDG_E_ARG;
     ctx->graph_algo = algo;
     return BDG_OK;
 }
@@ -629,6 +632,28 @@ int bdg_graph_edges_rows_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, 
     if (row_begin > row_end || row_end > n) return bdg_fail(ctx, BDG_E_ARG, "row block outside [0, n]");
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return bdg_graph_launch(ctx, d_ranks, n, row_begin, row_end, thr, qgram_T, d_out, cap, d_n_edges);
+}
+
+int bdg_graph_edges_part_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t part, uint32_t nparts,
+                             uint32_t thr, int32_t qgram_T, bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (!d_n_edges || (n && !d_ranks) || (cap && !d_out)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    if (nparts == 0 || part >= nparts) return bdg_fail(ctx, BDG_E_ARG, "part outside [0, nparts)");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int plan = bdg_graph_plan(ctx, n, thr);
+    if (plan == 5) return bdg_graph_launch(ctx, d_ranks, n, 0u, n, thr, qgram_T, d_out, cap, d_n_edges, part, nparts);
+    // the other paths share by blocks of rows: equal rows where a row's work is constant (neighbourhood probes), equal numbers
+    // of (i, j > i) pairs where row i meets what lies behind it (q-gram join, sweep): cuts at n (1 - sqrt(1 - g / nparts))
+    auto cut = [&](uint32_t g) -> uint32_t {
+        if (g >= nparts) return n;
+        if (plan == 2) return (uint32_t)((unsigned long long)n * g / nparts);
+        const double c = (double)n * (1.0 - std::sqrt(1.0 - (double)g / (double)nparts));
+        return c <= 0.0 ? 0u : (c >= (double)n ? n : (uint32_t)(c + 0.5));
+    };
+    uint32_t lo = cut(part), hi = cut(part + 1);
+    if (hi < lo) hi = lo;
+    return bdg_graph_launch(ctx, d_ranks, n, lo, hi, thr, qgram_T, d_out, cap, d_n_edges);
 }
 
 int bdg_graph_edges(bdg_ctx* ctx, const uint32_t* ranks, uint32_t n, uint32_t thr, int32_t qgram_T,

@@ -108,9 +108,12 @@ void k_graph_sig(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t* __res
 // atomics on one address complete ~11 ns apart device-wide, so one per edge - or per wave step - would bound the kernel).
 constexpr uint32_t ECAP = 128;                   // staged edges per wave
 
-struct EdgeStage { uint32_t a[ECAP], b[ECAP]; uint8_t d[ECAP]; };
+template <uint32_t CAP>
+struct EdgeStageT { static constexpr uint32_t cap = CAP; uint32_t a[CAP], b[CAP]; uint8_t d[CAP]; };
+using EdgeStage = EdgeStageT<ECAP>;
 
-__device__ __forceinline__ void edge_copy_out(const EdgeStage& st, uint32_t n, unsigned long long base, int lane,
+template <class Stage>
+__device__ __forceinline__ void edge_copy_out(const Stage& st, uint32_t n, unsigned long long base, int lane,
                                               bdg_edge* __restrict__ out, uint64_t cap)
 {
     for (uint32_t i = (uint32_t)lane; i < n; i += 64u) {
@@ -119,13 +122,14 @@ __device__ __forceinline__ void edge_copy_out(const EdgeStage& st, uint32_t n, u
     }
 }
 // wave-wide: lanes with `want` append their edge; a full stage is written out with the wave's own reservation
-__device__ __forceinline__ void edge_push(bool want, uint32_t a, uint32_t b, uint32_t d, EdgeStage& st, uint32_t& n, int lane,
+template <class Stage>
+__device__ __forceinline__ void edge_push(bool want, uint32_t a, uint32_t b, uint32_t d, Stage& st, uint32_t& n, int lane,
                                           bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* n_edges)
 {
     const unsigned long long m = __ballot(want);
     if (!m) return;
     const uint32_t cnt = (uint32_t)__popcll(m);
-    if (n + cnt > ECAP) {
+    if (n + cnt > Stage::cap) {
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(n_edges, (unsigned long long)n);
         base = __shfl(base, 0);
@@ -140,8 +144,8 @@ __device__ __forceinline__ void edge_push(bool want, uint32_t a, uint32_t b, uin
     n += cnt;
 }
 // block-wide, every thread: one reservation for the waves' stages (NW waves per block)
-template <int NW = 4>
-__device__ __forceinline__ void edge_finish(EdgeStage* stages, uint32_t n, uint32_t* s_cnt, unsigned long long* s_base,
+template <int NW = 4, class Stage = EdgeStage>
+__device__ __forceinline__ void edge_finish(Stage* stages, uint32_t n, uint32_t* s_cnt, unsigned long long* s_base,
                                             bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* n_edges)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -813,23 +817,419 @@ void k_graph_qjoin_w(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t ro
     edge_finish<WAVES>(s_edges, ne, s_ecnt, &s_ebase, out, cap, n_edges);
 }
 
+
+// ---------------------------------------------------------------------------
+// Deletion-variant join (thr <= 2, large n).  The q-gram join above follows the reference's index literally: a row walks
+// the tails of its 11 six-mer buckets, which grow with n, so its work is quadratic (500 K rows: 11 ms; 9.5 M rows: 6.9 s).
+// The edge set itself does not need that walk:  dmin(a,b) <= 2  implies that a and b share a 14-mer that is left when two
+// letters are deleted from each (two substitutions: delete the two positions; one insertion + one deletion: delete the
+// odd letter of each, then any common letter; the forms through a[:-1] / b[:-1] delete the last letter and one or two
+// more - a[:-1] minus one letter is a minus two).  So: every row emits its <= 120 distinct two-deletion 14-mers as
+// (14-mer, row << 7 | which deletion pair), the entries are sorted by 14-mer, and only rows that meet in a group are
+// verified - by the same dmin and the same S (in closed form) as everywhere else, so the filter stays the reference's.
+// A pair shares several 14-mers; it is reported from exactly one group, named by a rule that looks at the two barcodes only
+// (k_d2_pairs).  A row's entries are made distinct when they are emitted (of equal 14-mers the first deletion pair stays),
+// so a group holds a row once and the rule names one pair of entries.
+// Work is linear in n (about 71 entries per row) plus the pairs that meet.
+// ---------------------------------------------------------------------------
+constexpr int D2_NPAIR = 120;                    // C(16, 2) deletion pairs
+
+// deletion pair t -> (p << 4 | q), p < q, in the order p = 0 (q = 1..15), p = 1 (q = 2..15), ...
+struct D2Table { uint8_t pq[D2_NPAIR]; };
+constexpr D2Table d2_make_table()
+{
+    D2Table t{};
+    int k = 0;
+    for (int p = 0; p < 16; ++p) for (int q = p + 1; q < 16; ++q) t.pq[k++] = (uint8_t)(p << 4 | q);
+    return t;
+}
+__constant__ D2Table d2_table = d2_make_table();
+
+// r without its bases p and q (p < q): a 14-mer in 28 bits
+__device__ __forceinline__ uint32_t d2_key(uint32_t r, uint32_t p, uint32_t q)
+{
+    const uint32_t lo = r & ((1u << (2u * p)) - 1u);
+    const uint32_t mid = (r >> (2u * p + 2u)) & ((1u << (2u * (q - p - 1u))) - 1u);
+    const uint32_t hi = (uint32_t)((unsigned long long)r >> (2u * q + 2u));          // (q = 15: nothing)
+    return lo | (mid << (2u * p)) | (hi << (2u * q - 2u));
+}
+
+// which of nparts shares of the 14-mers k belongs to (multiplicative hash: even whatever the barcodes look like)
+__device__ __forceinline__ uint32_t d2_part(uint32_t k, uint32_t nparts)
+{
+    return (uint32_t)(((unsigned long long)(k * 2654435761u) * nparts) >> 32);
+}
+
+// is the 14-mer k what is left of the 16-mer b when two of its letters are deleted?  (greedy: delete at the first mismatch)
+__device__ __forceinline__ bool d2_subseq(uint32_t k, uint32_t b)
+{
+    const uint32_t x1 = (k ^ b) | (1u << 28);
+    const uint32_t l1 = (uint32_t)__builtin_ctz(x1) >> 1;                              // common prefix, <= 14
+    const uint32_t k1 = k >> (2u * l1), m1 = 14u - l1;
+    const uint32_t b1 = (uint32_t)((unsigned long long)b >> (2u * l1 + 2u));           // b behind the deleted letter
+    const uint32_t x2 = ((k1 ^ b1) & ((1u << (2u * m1)) - 1u)) | (1u << (2u * m1));
+    const uint32_t l2 = (uint32_t)__builtin_ctz(x2) >> 1;                              // <= m1
+    const uint32_t k2 = k1 >> (2u * l2), m2 = m1 - l2;
+    const uint32_t b2 = (uint32_t)((unsigned long long)b1 >> (2u * l2 + 2u));
+    return ((k2 ^ b2) & ((1u << (2u * m2)) - 1u)) == 0u;
+}
+
+// One wave per row at a time (rows interleaved over the resident waves): lane l holds deletion pairs l and 64 + l.
+// A pair is dropped when an earlier one of the row gives the same 14-mer.  Letters inside a run are interchangeable, so only
+// the first letter of a run (or the first two, for two deletions in one run) need to be deleted: that alone removes most
+// repeats and, of equal 14-mers, keeps the earliest pair of the table (which is what k_d2_pairs' rule 3 counts on).  The rest
+// is settled exactly through a table of 1024 slots in LDS: a one-to-one mixing of the 28 key bits (multiply, shift-xor,
+// multiply, all mod 2^28) gives 10 bits that name the slot and 18 that are a fingerprint, and the slot takes the minimum of
+// (pair index << 18 | fingerprint).  A lane
+// that finds its own value won; one that finds its fingerprint under an earlier pair is a repeat; one that finds another
+// fingerprint lost the slot to a different 14-mer - so did every other holder of its own 14-mer, and those few lanes
+// (about three a row) compare among themselves.
+constexpr uint32_t D2_SLOTS = 1024;
+constexpr uint32_t D2_ECAP = 512;                // staged edges per wave in k_d2_pairs
+
+struct D2Row { uint32_t k0, k1; bool keep0, keep1; };
+
+__device__ __forceinline__ D2Row d2_row(uint32_t r, int lane, uint32_t pq0, uint32_t pq1, uint32_t* __restrict__ tab,
+                                        uint32_t part, uint32_t nparts)
+{
+    D2Row o;
+    const bool has1 = lane < D2_NPAIR - 64;
+    o.k0 = d2_key(r, pq0 >> 4, pq0 & 15u);
+    o.k1 = has1 ? d2_key(r, pq1 >> 4, pq1 & 15u) : 0xFFFFFFFFu;
+    const uint32_t diff = r ^ (r << 2);
+    const uint32_t first = ((diff | (diff >> 1)) & 0x55555554u) | 1u;                   // bit 2x: base x starts a run
+    auto canonical = [&](uint32_t pq) {
+        const uint32_t p = pq >> 4, q = pq & 15u;
+        const bool fq = (first >> (2u * q)) & 1u, fp = (first >> (2u * p)) & 1u;
+        return fp && (fq || p + 1u == q);                                                // (p + 1 == q and q not first: same run)
+    };
+    bool keep0 = canonical(pq0), keep1 = has1 && canonical(pq1);
+    uint4* const tab4 = reinterpret_cast<uint4*>(tab);
+#pragma unroll
+    for (uint32_t i = 0; i < D2_SLOTS / 4u / 64u; ++i) tab4[i * 64u + (uint32_t)lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    __builtin_amdgcn_wave_barrier();
+    // (a row's 14-mers agree in their low letters whenever both deletions lie behind them: the slot must come from all 28 bits)
+    auto mix = [](uint32_t k) { uint32_t x = (k * 0x9E3779B1u) & 0x0FFFFFFFu; x ^= x >> 15; return (x * 0x85EBCA6Bu) & 0x0FFFFFFFu; };
+    const uint32_t x0 = mix(o.k0), x1 = mix(o.k1);
+    const uint32_t mine0 = (uint32_t)lane << 18 | (x0 & 0x3FFFFu), mine1 = (uint32_t)(64 + lane) << 18 | (x1 & 0x3FFFFu);
+    if (keep0) atomicMin(&tab[x0 >> 18], mine0);
+    if (keep1) atomicMin(&tab[x1 >> 18], mine1);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t got0 = tab[x0 >> 18], got1 = tab[x1 >> 18];
+    const bool same0 = ((got0 ^ mine0) & 0x3FFFFu) == 0u, same1 = ((got1 ^ mine1) & 0x3FFFFu) == 0u;
+    const bool lost0 = keep0 && !same0, lost1 = keep1 && !same1;         // the slot went to another 14-mer
+    keep0 = keep0 && (got0 == mine0 || !same0);
+    keep1 = keep1 && (got1 == mine1 || !same1);
+    __builtin_amdgcn_wave_barrier();                                     // (the table is cleared again for the next row)
+    const unsigned long long u0 = __ballot(lost0), u1 = __ballot(lost1);
+    for (unsigned long long w = u0; w; w &= w - 1ull) {
+        const int src = __builtin_ctzll(w);
+        const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)o.k0, src);
+        if (lost0 && lane > src && o.k0 == ks) keep0 = false;
+        if (lost1 && o.k1 == ks) keep1 = false;
+    }
+    for (unsigned long long w = u1; w; w &= w - 1ull) {
+        const int src = __builtin_ctzll(w);
+        const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)o.k1, src);
+        if (lost1 && lane > src && o.k1 == ks) keep1 = false;
+    }
+    // a share of the work (one GPU of several): the 14-mers whose hash falls into this part - a group is whole or absent
+    if (nparts > 1u) {
+        keep0 = keep0 && d2_part(o.k0, nparts) == part;
+        keep1 = keep1 && d2_part(o.k1, nparts) == part;
+    }
+    o.keep0 = keep0; o.keep1 = keep1;
+    return o;
+}
+
+// pass 1: how many entries a row has (the exclusive sums of these are where pass 2 writes them)
+__global__ __launch_bounds__(256)
+void k_d2_count(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, uint32_t nparts, uint32_t* __restrict__ count)
+{
+    __shared__ uint32_t s_tab[4][D2_SLOTS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * 4u + (uint32_t)wv, nwaves = gridDim.x * 4u;
+    const uint32_t pq0 = d2_table.pq[lane], pq1 = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
+    for (uint32_t row = wave; row < n; row += nwaves) {
+        const D2Row o = d2_row(ranks[row], lane, pq0, pq1, s_tab[wv], part, nparts);
+        const uint32_t c = (uint32_t)__popcll(__ballot(o.keep0)) + (uint32_t)__popcll(__ballot(o.keep1));
+        if (lane == 0) count[row] = c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) count[n] = 0u;              // (its exclusive sum is the number of entries)
+}
+
+// pass 2: the entries, a row's side by side
+__global__ __launch_bounds__(256)
+void k_d2_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, uint32_t nparts, const uint32_t* __restrict__ offset,
+               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    __shared__ uint32_t s_tab[4][D2_SLOTS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * 4u + (uint32_t)wv, nwaves = gridDim.x * 4u;
+    const uint32_t pq0 = d2_table.pq[lane], pq1 = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
+    for (uint32_t row = wave; row < n; row += nwaves) {
+        const D2Row o = d2_row(ranks[row], lane, pq0, pq1, s_tab[wv], part, nparts);
+        const unsigned long long m0 = __ballot(o.keep0), m1 = __ballot(o.keep1);
+        const uint32_t base = offset[row];
+        if (o.keep0) { const uint32_t at = base + lanes_below_u64(m0, lane); keys[at] = o.k0; vals[at] = row << 7 | (uint32_t)lane; }
+        if (o.keep1) { const uint32_t at = base + (uint32_t)__popcll(m0) + lanes_below_u64(m1, lane); keys[at] = o.k1; vals[at] = row << 7 | (uint32_t)(64 + lane); }
+    }
+}
+
+// r without its base p: a 15-mer in 30 bits
+__device__ __forceinline__ uint32_t d1_key(uint32_t r, uint32_t p)
+{
+    const uint32_t lo = r & ((1u << (2u * p)) - 1u);
+    const uint32_t hi = (uint32_t)((unsigned long long)r >> (2u * p + 2u));
+    return lo | (hi << (2u * p));
+}
+
+// Which of the 14-mers a pair shares reports it.  A function of the two barcodes alone (a = the lower row), so that every
+// group the pair meets in decides alike, and always one of the shared 14-mers:
+//   1. at most two differing letters: the 14-mer without them (one differing letter: without it and letter 0, or 1);
+//   2. a without letter i == b without letter j for some i, j (one insertion + one deletion, which includes the forms through
+//      a[:-1] / b[:-1] alone): that 15-mer without its first letter.  With lcp / lcs the common prefix / suffix of a and b,
+//      i <= j needs i <= lcp, j >= 15 - lcs and a[x + 1] == b[x] for x in [i, j): the narrowest such interval decides;
+//      j < i likewise with the roles swapped;
+//   3. otherwise: the 14-mer of a's first deletion pair (table order) that is left in b as well - found by trying them.
+// Returns 1 / 0 for rules 1 and 2 (k is / is not that 14-mer), 2 when rule 3 has to decide.
+__device__ __forceinline__ int d2_reports(uint32_t a, uint32_t b, uint32_t k)
+{
+    const uint32_t x = a ^ b;                                          // (a != b)
+    const uint32_t nz = (x | (x >> 1)) & 0x55555555u;
+    const uint32_t h = (uint32_t)__popc(nz);
+    const uint32_t lcp = (uint32_t)__builtin_ctz(nz) >> 1, lcs = (uint32_t)__builtin_clz(nz) >> 1;
+    if (h <= 2u) {
+        const uint32_t s1 = lcp, s2 = h == 2u ? 15u - lcs : (s1 == 0u ? 1u : 0u);
+        const uint32_t p = s1 < s2 ? s1 : s2, q = s1 < s2 ? s2 : s1;
+        return d2_key(a, p, q) == k ? 1 : 0;
+    }
+    const uint32_t far = 15u - lcs;                                    // first position from which on the tails agree (lcs <= 13 here)
+    const uint32_t near = lcp < far ? lcp : far;
+    const uint32_t span = ((1u << (2u * far)) - 1u) & ~((1u << (2u * near)) - 1u);      // letters near .. far - 1
+    if ((((a >> 2) ^ b) & span) == 0u) return (d1_key(a, near) >> 2) == k ? 1 : 0;       // i = near <= j = far
+    if ((((b >> 2) ^ a) & span) == 0u) return (d1_key(a, far) >> 2) == k ? 1 : 0;        // j = near < i = far
+    return 2;
+}
+
+// One wave per 64 consecutive sorted entries.  Lane l's entry meets the L_l entries behind it in its group (same 14-mer);
+// the wave walks the sum of those meetings 64 at a time, whatever the group sizes are (a meeting's owner is found in the
+// running sums), so the verification always runs with full lanes.
+__global__ __launch_bounds__(256)
+void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, unsigned long long m,
+                const uint32_t* __restrict__ ranks, uint32_t row_begin, uint32_t row_end, uint32_t thr, int32_t T,
+                bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges)
+{
+    __shared__ EdgeStageT<D2_ECAP> stages[4];
+    __shared__ uint32_t s_cnt[4];
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_incl[4][64], s_val[4][64], s_rank[4][64], s_key[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t ne = 0;
+    // resident grid, the windows interleaved over its waves: a wave reserves output when its stage is full and once at the end
+    // (one reservation per window - returning atomics on one address complete ~11 ns apart - would cost more than the kernel)
+    const unsigned long long nwin = (m + 63ull) / 64ull;
+    for (unsigned long long win = (unsigned long long)blockIdx.x * 4ull + (unsigned long long)wv; win < nwin; win += (unsigned long long)gridDim.x * 4ull) {
+    const unsigned long long wave_base = win * 64ull;
+    const unsigned long long e = wave_base + (unsigned long long)lane;
+    const bool have = e < m;
+    const uint32_t k = have ? keys[e] : 0xFFFFFFFFu;
+    const uint32_t v = have ? vals[e] : 0u;
+    // entries behind this one with the same 14-mer.  Inside the wave's 64 entries that is the distance to the group's last
+    // lane (groups are contiguous); only a group that runs past lane 63 looks into memory for its end (a 14-mer has at most
+    // 120 * 16 = 1920 parents: fewer than 2048 entries)
+    const unsigned long long next_base = wave_base + 64ull;
+    const uint32_t k_after = next_base < m ? keys[next_base] : 0xFFFFFFFEu;           // (matches no key and no padding)
+    const uint32_t k_down = (uint32_t)__shfl_down((int)k, 1);
+    const uint32_t k_next = lane == 63 ? k_after : k_down;
+    const unsigned long long ends = __ballot(!have || k != k_next);                  // lanes that end a group
+    const unsigned long long rest = ends >> lane;
+    uint32_t L = rest ? (uint32_t)__builtin_ctzll(rest) : 63u - (uint32_t)lane;
+    if (__ballot(have && rest == 0ull)) {                                             // the last group continues behind the window
+        const uint32_t k63 = (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
+        uint32_t tail = 0;
+#pragma unroll
+        for (uint32_t s = 1024; s >= 1; s >>= 1) {
+            const unsigned long long j = wave_base + 63ull + tail + s;
+            if (j < m && keys[j] == k63) tail += s;
+        }
+        if (rest == 0ull) L += tail;
+    }
+    if (!have) L = 0;
+    uint32_t incl = L;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, s); if (lane >= s) incl += o; }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    s_incl[wv][lane] = incl; s_val[wv][lane] = v; s_key[wv][lane] = k;
+    s_rank[wv][lane] = have ? ranks[v >> 7] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t x0 = 0; x0 < total; x0 += 64u) {
+        const uint32_t x = x0 + (uint32_t)lane;
+        const bool act = x < total;
+        uint32_t o = 0;                                            // owner: the number of lanes whose running sum is <= x
+#pragma unroll
+        for (uint32_t s = 32; s >= 1; s >>= 1) if (s_incl[wv][o + s - 1u] <= x) o += s;
+        o = act ? o : 0u;
+        const uint32_t before = o ? s_incl[wv][o - 1u] : 0u;
+        const unsigned long long e2 = wave_base + o + (x - before) + 1ull;
+        uint32_t a = 0, b = 0, t_a = 0, kk = 0;
+        bool on = false;
+        if (act) {
+            const uint32_t v1 = s_val[wv][o], v2 = vals[e2];
+            const uint32_t row_i = v1 >> 7, row_j = v2 >> 7;
+            const uint32_t rank_i = s_rank[wv][o], rank_j = ranks[row_j];
+            const bool lower = row_i < row_j;                      // (a row has one entry per 14-mer: row_i != row_j)
+            a = lower ? rank_i : rank_j; b = lower ? rank_j : rank_i;
+            t_a = (lower ? v1 : v2) & 127u;
+            kk = s_key[wv][o];
+            const uint32_t row_a = lower ? row_i : row_j;
+            on = row_a >= row_begin && row_a < row_end;
+        }
+        const uint32_t d = on ? dmin3(a, b) : 99u;
+        bool edge = d <= thr;
+        if (__ballot(edge)) {
+            edge = edge && (int32_t)qgram_S(a, b) >= T;
+            const int rep = edge ? d2_reports(a, b, kk) : 0;
+            edge = edge && rep != 0;
+            // rule 3, one pair at a time with the deletion pairs spread over the lanes: reported from here iff none of a's
+            // deletion pairs before this entry's leaves a 14-mer that b has, too
+            for (unsigned long long w = __ballot(edge && rep == 2); w; w &= w - 1ull) {
+                const int src = __builtin_ctzll(w);
+                const uint32_t ja = (uint32_t)__builtin_amdgcn_readlane((int)a, src), jb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
+                const uint32_t jt = (uint32_t)__builtin_amdgcn_readlane((int)t_a, src);
+                bool found = false;
+                for (uint32_t t0 = 0; t0 < jt; t0 += 64u) {
+                    const uint32_t t = t0 + (uint32_t)lane;
+                    const uint32_t pq = d2_table.pq[t < D2_NPAIR ? t : 0];
+                    found = found || (t < jt && d2_subseq(d2_key(ja, pq >> 4, pq & 15u), jb));
+                }
+                if (__ballot(found) && lane == src) edge = false;
+            }
+        }
+        edge_push(edge, a, b, d, stages[wv], ne, lane, out, cap, n_edges);
+    }
+    __builtin_amdgcn_wave_barrier();                                 // (the window's LDS rows are rewritten next)
+    }
+    edge_finish<4>(stages, ne, s_cnt, &s_base, out, cap, n_edges);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
+static uint32_t d2_emit_blocks_per_cu()
+{
+    static const uint32_t v = [] { const char* e = getenv("BADGER_AMD_D2_EMIT_BLOCKS"); const int x = e ? atoi(e) : 8; return (uint32_t)(x < 1 ? 1 : (x > 8 ? 8 : x)); }();
+    return v;                                                          // (16 KB of LDS a block; measured 2 / 4 / 6 / 8: 0.53 / 0.34 / 0.28 / 0.25 ms at 500 K rows)
+}
+
+static uint32_t d2_pairs_blocks_per_cu()
+{
+    static const uint32_t v = [] { const char* e = getenv("BADGER_AMD_D2_PAIRS_BLOCKS"); const int x = e ? atoi(e) : 8; return (uint32_t)(x < 1 ? 1 : (x > 8 ? 8 : x)); }();
+    return v;                                                          // (22 KB of LDS a block; measured 2 / 4 / 6 / 8: 1.23 / 1.00 / 0.94 / 0.86 ms at 500 K rows)
+}
+
+// once per context: the device's compute units and how many blocks of the join kernels a unit holds (resident grids are sized from these)
+static int graph_props(bdg_ctx* ctx)
+{
+    if (!ctx->g_cus) {
+        hipDeviceProp_t prop;
+        BDG_HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        int per_cu = 0, per_cu_w = 0;
+        BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_graph_qjoin<QJ_W>, 256, 0));
+        // slice size per wave, measured at 500 K rows / thr 2: 16 K rows x 2 waves per block 11.1 ms, 8 K x 4 12.2, 32 K x 1 15.8, 4 K x 4 18.8
+        ctx->g_qjw_variant = 1;
+        if (const char* e = getenv("BADGER_AMD_QJ_VARIANT")) ctx->g_qjw_variant = atoi(e);      // (for measurements)
+        if (ctx->g_qjw_variant < 0 || ctx->g_qjw_variant > 3) ctx->g_qjw_variant = 1;
+        switch (ctx->g_qjw_variant) {
+        case 1:  BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<16384, 2, true>, 128, 0)); break;
+        case 2:  BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<32768, 1, true>, 64, 0)); break;
+        case 3:  BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<4096, 4, true>, 256, 0)); break;
+        default: BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<8192, 4, true>, 256, 0)); break;
+        }
+        ctx->g_cus = prop.multiProcessorCount; ctx->g_qj_per_cu = per_cu < 1 ? 1 : per_cu; ctx->g_qjw_per_cu = per_cu_w < 1 ? 1 : per_cu_w;
+    }
+    return BDG_OK;
+}
+
+// which path bdg_graph_launch takes: 1 all-pairs sweep, 2 neighbourhood probes, 3 / 4 q-gram join, 5 deletion-variant join
+int bdg_graph_plan(const bdg_ctx* ctx, uint32_t n, uint32_t thr)
+{
+    if (ctx->graph_algo) return ctx->graph_algo;
+    if (thr == 1) return 2;
+    if (thr >= 2 && n < (1u << 25)) return (thr == 2 && n >= ctx->g_d2_min_rows) ? 5 : 3;
+    return 1;
+}
+
+// part / nparts: only the deletion-variant join looks at them (its share of the 14-mer groups); the other paths share by rows
 int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t row_begin, uint32_t row_end,
-                     uint32_t thr, int32_t qgram_T, bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges)
+                     uint32_t thr, int32_t qgram_T, bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges, uint32_t part, uint32_t nparts)
 {
     hipStream_t st = ctx->stream;
     BDG_HIP_TRY(ctx, hipMemsetAsync(d_n_edges, 0, 8, st));
     if (n < 2 || row_begin >= row_end) return BDG_OK;
     if (thr > 16) return bdg_fail(ctx, BDG_E_ARG, "thr must be <= 16");
     if (qgram_T < 1) return bdg_fail(ctx, BDG_E_ARG, "qgram_T must be >= 1 (index.py:22-24 never yields less)");
-    const bool probe = ctx->graph_algo == 2 || (ctx->graph_algo == 0 && thr == 1);
+    const int plan = bdg_graph_plan(ctx, n, thr);
+    const bool probe = plan == 2;
     if (ctx->graph_algo == 2 && thr != 1) return bdg_fail(ctx, BDG_E_ARG, "probe path needs thr == 1");
-    // q-gram join: any thr; the automatic choice for thr >= 2 (row << 4 | position and (j + 1) << 7 | count must fit 32 bits)
-    const bool qjoin = ctx->graph_algo == 3 || ctx->graph_algo == 4 || (ctx->graph_algo == 0 && thr >= 2 && n < (1u << 25));
+    // q-gram join: any thr; the automatic choice for thr >= 3 (row << 4 | position and (j + 1) << 7 | count must fit 32 bits)
+    const bool qjoin = plan == 3 || plan == 4;
     if ((ctx->graph_algo == 3 || ctx->graph_algo == 4) && n >= (1u << 25)) return bdg_fail(ctx, BDG_E_ARG, "q-gram join needs n < 2^25");
     int rc;
+    // deletion-variant join: thr <= 2 only (what makes it complete); the automatic choice for thr 2
+    const bool d2join = plan == 5;
+    if (ctx->graph_algo == 5 && (thr > 2 || n >= (1u << 25))) return bdg_fail(ctx, BDG_E_ARG, "deletion-variant join needs thr <= 2 and n < 2^25");
+    if (nparts == 0 || part >= nparts) return bdg_fail(ctx, BDG_E_ARG, "part outside [0, nparts)");
+    if (d2join) {
+        // entries: about 71 per row on random barcodes, 120 at most.  Counted first (pass 1), so that every row knows where
+        // its entries go and the buffers are sized exactly
+        auto* cnt = reinterpret_cast<unsigned long long*>(d_n_edges);
+        {
+            if ((rc = graph_props(ctx))) return rc;
+            size_t t_scan = 0;
+            uint32_t* nul = nullptr;
+            BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, t_scan, nul, nul, (int)(n + 1), st));
+            if ((rc = bdg_reserve(ctx, ctx->g_sig, sizeof(uint32_t) * 2ull * ((size_t)n + 1) + t_scan + 512))) return rc;   // (the sweep's signature buffer is free here)
+            auto* count = static_cast<uint32_t*>(ctx->g_sig.p);
+            auto* offset = count + n + 1;
+            void* scan_temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(offset + n + 1) + 255) & ~uintptr_t(255));
+            uint32_t grid = (uint32_t)ctx->g_cus * d2_emit_blocks_per_cu();
+            if (grid > (n + 3u) / 4u) grid = (n + 3u) / 4u;
+            uint32_t m32 = 0;
+            {
+                ScopedKernelTimer tm(ctx, "k_d2_count");
+                hipLaunchKernelGGL(k_d2_count, dim3(grid), dim3(256), 0, st, d_ranks, n, part, nparts, count);
+                BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(scan_temp, t_scan, count, offset, (int)(n + 1), st));
+            }
+            BDG_HIP_TRY(ctx, hipMemcpyAsync(&m32, offset + n, 4, hipMemcpyDeviceToHost, st));
+            BDG_HIP_TRY(ctx, hipStreamSynchronize(st));                           // (the sort needs the entry count on the host)
+            const unsigned long long m = m32;
+            size_t t_sort = 0;
+            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, nul, nul, nul, nul, (long long)(m ? m : 1), 0, 28, st));
+            if ((rc = bdg_reserve(ctx, ctx->g_qj, sizeof(uint32_t) * 4ull * (m + 64) + t_sort + 512))) return rc;
+            auto* k_in = static_cast<uint32_t*>(ctx->g_qj.p);
+            auto* k_out = k_in + m + 16;
+            auto* v_in = k_out + m + 16;
+            auto* v_out = v_in + m + 16;
+            void* temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(v_out + m + 16) + 255) & ~uintptr_t(255));
+            {
+                ScopedKernelTimer tm(ctx, "k_d2_emit");
+                hipLaunchKernelGGL(k_d2_emit, dim3(grid), dim3(256), 0, st, d_ranks, n, part, nparts, offset, k_in, v_in);
+            }
+            if (m) {
+                ScopedKernelTimer tm(ctx, "d2_sort");
+                size_t t = t_sort;
+                BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(temp, t, k_in, k_out, v_in, v_out, (long long)m, 0, 28, st));
+            }
+            ScopedKernelTimer tm(ctx, "k_d2_pairs");
+            unsigned long long pgrid = (unsigned long long)ctx->g_cus * d2_pairs_blocks_per_cu();
+            if (pgrid > (m + 255) / 256) pgrid = (m + 255) / 256;
+            if (m) hipLaunchKernelGGL(k_d2_pairs, dim3((uint32_t)pgrid), dim3(256), 0, st, k_out, v_out, m, d_ranks, row_begin, row_end,
+                                      thr, qgram_T, d_out, cap, cnt);
+            BDG_HIP_TRY(ctx, hipGetLastError());
+        }
+        return BDG_OK;
+    }
     if (qjoin) {
         const size_t m = (size_t)n * QJ_NQ;
         const uint32_t W = QJ_W;
@@ -855,23 +1255,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             hipLaunchKernelGGL(k_qj_index, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, k_out, v_out, (uint32_t)m, pos_of, bucket_off);
             if (closed_form) hipLaunchKernelGGL(k_qj_split, dim3((4096u * (G + 1) + 255) / 256), dim3(256), 0, st, v_out, bucket_off, G, W, split);
         }
-        if (!ctx->g_cus) {                                           // once per context: resident grids are sized from these
-            hipDeviceProp_t prop;
-            BDG_HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
-            int per_cu = 0, per_cu_w = 0;
-            BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_graph_qjoin<QJ_W>, 256, 0));
-            // slice size per wave, measured at 500 K rows / thr 2: 16 K rows x 2 waves per block 11.1 ms, 8 K x 4 12.2, 32 K x 1 15.8, 4 K x 4 18.8
-            ctx->g_qjw_variant = 1;
-            if (const char* e = getenv("BADGER_AMD_QJ_VARIANT")) ctx->g_qjw_variant = atoi(e);      // (for measurements)
-            if (ctx->g_qjw_variant < 0 || ctx->g_qjw_variant > 3) ctx->g_qjw_variant = 1;
-            switch (ctx->g_qjw_variant) {
-            case 1:  BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<16384, 2, true>, 128, 0)); break;
-            case 2:  BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<32768, 1, true>, 64, 0)); break;
-            case 3:  BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<4096, 4, true>, 256, 0)); break;
-            default: BDG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_graph_qjoin_w<8192, 4, true>, 256, 0)); break;
-            }
-            ctx->g_cus = prop.multiProcessorCount; ctx->g_qj_per_cu = per_cu < 1 ? 1 : per_cu; ctx->g_qjw_per_cu = per_cu_w < 1 ? 1 : per_cu_w;
-        }
+        if ((rc = graph_props(ctx))) return rc;
         if (closed_form) {
             ScopedKernelTimer tm(ctx, "k_graph_qjoin");
             uint32_t grid = (uint32_t)ctx->g_qj_per_cu * (uint32_t)ctx->g_cus;          // resident grid, rows interleaved

@@ -1,7 +1,8 @@
 """One process per GPU.  Reads partition independently, so the data path needs no
 collective: each rank takes a contiguous range of reads, the whitelist is replicated, and
 results are concatenated in rank order.  Graph rows shard the same way (every rank holds the whole
-sorted rank array and emits the edges whose smaller rank lies in its block of rows).  torch.distributed (RCCL on the GPU box, gloo on CPU)
+sorted rank array and emits its share of the edges: those whose smaller rank lies in its block of rows, or - the
+deletion-variant join - those reported from its share of the 14-mer groups; bdg_graph_edges_part_dev cuts the shares).  torch.distributed (RCCL on the GPU box, gloo on CPU)
 is used only for the barrier, the max-over-ranks clock and the final gather of records."""
 import os
 import time
@@ -109,6 +110,22 @@ def graph_balance(thr):
     """how graph rows are cut into per-GPU blocks: thr 1 runs the neighbourhood probes, the same 176 look-ups for every
     row ("rows"); thr >= 2 runs the q-gram join, where row i walks its bucket tails BEHIND i, i.e. work ~ n - i ("pairs")"""
     return "rows" if thr <= 1 else "pairs"
+
+
+def graph_parts_sharded(part_fn, ranks_sorted, thr, qgram_T):
+    """Run part_fn(ranks_sorted, part, nparts, thr, qgram_T) -> structured edge array (bdg_graph_edges_part_dev: one of
+    nparts disjoint shares of the edge list, cut by the library) with part = this rank, and return, on rank 0, all edges
+    sorted by (a, b) (None elsewhere).  No collective on the data path: the gather of the edge lists is the only exchange."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    mine = part_fn(ranks_sorted, rank, world, thr, qgram_T)
+    if world > 1:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine.tobytes(), gathered, dst=0)
+        if rank != 0:
+            return None
+        mine = np.concatenate([np.frombuffer(b, dtype=mine.dtype) for b in gathered])
+    return mine[np.lexsort((mine["b"], mine["a"]))]
 
 
 def graph_edges_sharded(edges_fn, ranks_sorted, thr, qgram_T, balance="rows"):

@@ -182,11 +182,11 @@ def spawn_ranks(ngpus):
     return subprocess.call(cmd)
 
 
-def observed_barcodes(n_distinct, wl, seed=3):
+def observed_barcodes(n_distinct, wl, seed=3, n_cells=5000):
     """n distinct 16-mers as extraction would see them: cell barcodes with substitutions and a
     deletion, numpy.default_rng(seed)."""
     rng = np.random.default_rng(seed)
-    cells = wl[rng.permutation(len(wl))[:5000]].astype(np.uint64)
+    cells = wl[rng.permutation(len(wl))[:n_cells]].astype(np.uint64)
     out = np.zeros(0, dtype=np.uint32)
     while len(out) < n_distinct:
         m = 2 * n_distinct
@@ -222,24 +222,26 @@ def clock_ramp(step, dev, seconds=RAMP_S):
 
 def bench_graph(args, rank, world, dev, local_dev):
     """BASELINE configs 3 / 5 (graph part): K3 over 500K distinct barcodes, thr 1 (neighbourhood probes) or thr 2
-    (q-gram join).  Rows shard over ranks in row blocks (every rank holds the whole sorted array), no collective."""
+    (deletion-variant join).  Every rank holds the whole sorted array and builds its share of the edge list, no collective."""
     from oracle import pyoracle as orc
     thr = 1 if args.config == 3 else 2
     n = args.rows
     wl = synth.make_whitelist(args.whitelist)
     ranks = observed_barcodes(n, wl)
     T = orc.qgram_threshold(thr)
-    # thr 1: a row's work is its 176 probes (equal rows); thr >= 2: its bucket tails behind it, i.e. ~ (n - i) (equal pair counts)
-    lo, hi = bdist.graph_row_blocks(n, world, bdist.graph_balance(thr))[rank]
+    # one of `world` shares of the edge list per rank, cut by the library (bdg_graph_edges_part_dev): thr 1 - blocks of equal
+    # rows (a row's work is its 176 probes); thr 2 - shares of the 14-mer groups of the deletion-variant join; the q-gram join
+    # (thr >= 3, or --graph-algo 3) - blocks of equal pair counts (a row walks its bucket tails behind it, ~ n - i)
     d_ranks = torch.from_numpy(ranks.view(np.int32)).to(dev)
     cap = 32 * n
     d_edges = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
     d_n = torch.zeros(1, dtype=torch.int64, device=dev)
     ctx = _native.Context(local_dev)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.graph_set_algo(args.graph_algo)
 
     def step():
-        ctx.graph_edges_rows_dev(d_ranks, n, lo, hi, thr, T, d_edges, cap, d_n)
+        ctx.graph_edges_part_dev(d_ranks, n, rank, world, thr, T, d_edges, cap, d_n)
 
     ramp_steps = clock_ramp(step, dev) if not args.no_ramp else 0
     for _ in range(max(1, args.warmup)):
@@ -252,28 +254,29 @@ def bench_graph(args, rank, world, dev, local_dev):
     ne = int(d_n[0])
     if ne > cap:
         raise SystemExit("edge capacity too small: %d > %d" % (ne, cap))
-    # check: every edge of 64 sampled rows of this rank's block against the oracle's S and dmin, both directions
+    # check (every rank, its own share): no edge twice, and 3,000 sampled edges are edges by the oracle's S and dmin with the
+    # distance they carry; the whole list is compared with the oracle's below (one GPU) or by its length (several)
     e = d_edges[:ne].cpu().numpy().view(np.uint32)
     rng = np.random.default_rng(7 + rank)
     status = "ok"
-    for a in (ranks[lo:hi][rng.integers(0, hi - lo, 64)] if hi > lo else []):
-        mine = sorted((int(x[1]), int(x[2])) for x in e[e[:, 0] == a])
-        cand = ranks[ranks > a][:20000]
-        want = []
-        for b in cand:
-            if orc.qgram_S(int(a), int(b)) >= T:
-                d = orc.dmin3(int(a), int(b))
-                if d <= thr:
-                    want.append((int(b), d))
-        limit = int(cand[-1]) if len(cand) else 0
-        if sorted(want) != [m_ for m_ in mine if m_[0] <= limit]:
-            status = "row of rank %d differs from the oracle" % int(a)
+    key = e[:, 0].astype(np.uint64) << np.uint64(32) | e[:, 1].astype(np.uint64)
+    if len(np.unique(key)) != ne or not (e[:, 0] < e[:, 1]).all():
+        status = "an edge is listed twice or not as (a < b)"
+    for a, b, d in (e[rng.integers(0, ne, 3000)] if ne else []):
+        if orc.qgram_S(int(a), int(b)) < T or orc.dmin3(int(a), int(b)) != int(d) or int(d) > thr:
+            status = "edge (%d, %d, %d) is not an edge by the oracle" % (int(a), int(b), int(d))
+    ne_all = int(bdist.all_sum(ne, dev))
     fails = bdist.all_max(0.0 if status == "ok" else 1.0, dev)
     if rank == 0:
         if fails:
             raise SystemExit("parity sample failed: " + status)
         per_launch_ms = {k: v[1] / max(1, v[0]) for k, v in prof.items() if v[0]}
         dom = max(per_launch_ms, key=per_launch_ms.get)
+        path, share = {"k_graph_probe": ("neighbourhood probes", "blocks of equal rows"),
+                       "k_graph_qjoin_w": ("q-gram join", "row blocks of equal pair counts"),
+                       "k_graph_qjoin": ("q-gram join, closed form", "row blocks of equal pair counts"),
+                       "k_graph_scan": ("all-pairs sweep", "row blocks of equal pair counts")}.get(
+                           dom, ("deletion-variant join", "shares of the 14-mer groups"))
         alg = 4 * n + 9 * ne                           # 4n in + 9E out (rank's own edges)
         achieved = alg / (per_launch_ms[dom] * 1e-3) / 1e9
         pc = profile_counters(dom)
@@ -293,10 +296,9 @@ def bench_graph(args, rank, world, dev, local_dev):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BASELINE config %d: barcode_graph edges, threshold %d, %d distinct observed barcodes (%s)"
-                                   % (args.config, thr, n, "neighbourhood probes" if thr == 1 else "q-gram join"),
-                       "rows": n, "edges_rank0": ne, "qgram_T": T,
-                       "parallelism": "row blocks per GPU (%s), no collectives" % ("equal rows" if thr == 1 else "equal pair counts"),
-                       "rows_this_rank": [int(lo), int(hi)],
+                                   % (args.config, thr, n, path),
+                       "rows": n, "edges_rank0": ne, "edges_all_ranks": ne_all, "qgram_T": T,
+                       "parallelism": "one share of the edge list per GPU (bdg_graph_edges_part_dev: %s), no collectives" % share,
                        "clock_ramp": "%d untimed steps (%.2f s) before the %d warm-up steps" % (ramp_steps, RAMP_S, args.warmup)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pc["traffic"], "traffic_source": pc["source"],
@@ -316,6 +318,12 @@ def bench_graph(args, rank, world, dev, local_dev):
             if not same:
                 raise SystemExit("parity failed: the device's edge list differs from the oracle's (%d against %d edges)" % (ne, len(want)))
             line["parity_sample"] = "ok (all %d edges equal the oracle's)" % ne
+        elif not args.no_cpu_baseline:
+            # several GPUs: the shares must add up to the oracle's list (each rank checked its own for repeats and soundness)
+            want, _, _ = orc.graph_edges_sampled(ranks, thr, 1, T, threads=host_cores(), cap=ne_all + 1)
+            if len(want) != ne_all:
+                raise SystemExit("parity failed: the ranks' shares hold %d edges, the oracle's list %d" % (ne_all, len(want)))
+            line["parity_sample"] = "ok (the %d shares hold the oracle's %d edges; every rank: no repeats, 3000 sampled edges sound)" % (world, ne_all)
             line["cpu_baseline"] = {"value": n / (t_index + t_rows), "unit": "rows/s", "cores": cores, "kind": "port",
                                     "sample": "oracle graph_edges (QGramIndex buckets + 3 Levenshtein per candidate, "
                                               "barcode_graph.py:207-249) on the same %d rows, OpenMP over %d cores: index %.2f s, "
@@ -336,6 +344,7 @@ def main():
                     help="BASELINE.json config: 2 = the headline (K1 + K2), 3 = graph thr 1, 5 = graph thr 2")
     ap.add_argument("--rows", type=int, default=500000, help="distinct barcodes for --config 3 / 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph-algo", type=int, default=0, help="--config 3 / 5: bdg_graph_set_algo (0: the library's choice)")
     ap.add_argument("--overlap", action="store_true",
                     help="batch pipelining: K2 of batch i on a second stream beside K1 of batch i+1 (bdg_set_overlap; about +7 %% calls/s, "
                          "but the kernels then share the chip and their own durations - the roofline block - grow)")
@@ -373,16 +382,17 @@ def main():
 
 def rehearse(args, rank, world):
     """Everything of a --gpus N run except the GPU: the ranks rendezvous over gloo, take their share of the work exactly as the
-    real run cuts it (reads: N x --reads, weak; graph rows: row blocks, equal rows at thr 1, equal pair counts at thr 2), time
+    real run cuts it (reads: N x --reads, weak; graph: part `rank` of `world` of the edge list, cut by the library), time
     a stub step between the barriers with the max-over-ranks clock, and rank 0 prints the line from the totals over ranks.
     The SCALE leg of the driver is then not the first time this code runs."""
     bdist.init(backend="gloo")
     try:
         if args.config in (3, 5):
             thr = 1 if args.config == 3 else 2
-            lo, hi = bdist.graph_row_blocks(args.rows, world, bdist.graph_balance(thr))[rank]
+            lo, hi = bdist.partition(args.rows, world, rank)          # (for the totals: the shares themselves are cut by the library)
             units, unit, scaling = hi - lo, "rows/s", "strong"
-            share = {"rows_this_rank": [int(lo), int(hi)], "balance": bdist.graph_balance(thr)}
+            share = {"part": rank, "nparts": world, "threshold": thr,
+                     "cut_by": "bdg_graph_edges_part_dev (thr 1: blocks of equal rows; thr 2: shares of the 14-mer groups)"}
         else:
             units, unit, scaling = args.reads, "calls/s", "weak"
             share = {"reads_per_gpu": args.reads, "seed_this_rank": 1 + rank}

@@ -81,8 +81,8 @@ def test_clock_ramp_runs_whole_groups_of_steps_for_the_stated_time(monkeypatch):
 
 def test_multi_rank_rehearsal_over_gloo():
     """`python bench.py --gpus 2 --config 5 --rehearse` as the driver's SCALE leg starts it, minus the GPUs: the parent
-    launches torch.distributed.run as a child, two ranks rendezvous on 127.0.0.1 over gloo, cut the rows into blocks of
-    equal pair counts, time a stub step with the max-over-ranks clock, and rank 0 prints ONE line whose totals are sums
+    launches torch.distributed.run as a child, two ranks rendezvous on 127.0.0.1 over gloo, take part `rank` of 2 of the
+    edge list (the library cuts the shares), time a stub step with the max-over-ranks clock, and rank 0 prints ONE line whose totals are sums
     over the ranks.  Same for the headline config (reads per GPU, weak scaling)."""
     import subprocess
     from badger_amd import dist as bdist
@@ -96,8 +96,7 @@ def test_multi_rank_rehearsal_over_gloo():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["rehearsal"] is True and d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong"
-    assert d["config"]["units_all_ranks"] == 500000 and d["config"]["balance"] == "pairs"
-    assert d["config"]["rows_this_rank"] == list(bdist.graph_row_blocks(500000, 2, "pairs")[0])
+    assert d["config"]["units_all_ranks"] == 500000 and d["config"]["part"] == 0 and d["config"]["nparts"] == 2 and d["config"]["threshold"] == 2
     assert d["ms_per_step"] >= 3.9                      # max over ranks: rank 1's stub sleeps 4 ms a step
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--reads", "1000", "--rehearse"],
                        capture_output=True, text=True, env=env, timeout=300)

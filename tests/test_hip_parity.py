@@ -420,7 +420,7 @@ def _ranks_of(barcodes):
     return np.unique(np.array(out, dtype=np.uint32))
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3, 4])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4, 5])
 def test_graph_golden(ctx, golden_dir, algo):
     g = json.load(open(os.path.join(golden_dir, "graph.json")))
     for key in ("c1_thr1", "c1_thr2", "cells60_thr1", "cells60_thr2"):
@@ -453,7 +453,7 @@ def _observed_barcodes(n_cells, n_obs, seed):
     return np.unique(out.astype(np.uint32))
 
 
-@pytest.mark.parametrize("algo,thr", [(1, 1), (2, 1), (1, 2), (1, 3), (3, 1), (3, 2), (3, 3), (4, 1), (4, 2), (0, 2), (0, 3)])
+@pytest.mark.parametrize("algo,thr", [(1, 1), (2, 1), (1, 2), (1, 3), (3, 1), (3, 2), (3, 3), (4, 1), (4, 2), (0, 2), (0, 3), (5, 1), (5, 2)])
 def test_graph_vs_oracle(ctx, orc, algo, thr):
     ranks = _observed_barcodes(300, 12000, 31)
     ctx.graph_set_algo(algo)
@@ -465,7 +465,7 @@ def test_graph_vs_oracle(ctx, orc, algo, thr):
     ctx.graph_set_algo(0)
 
 
-@pytest.mark.parametrize("algo,thr", [(2, 1), (1, 1), (1, 2), (3, 2), (4, 2)])
+@pytest.mark.parametrize("algo,thr", [(2, 1), (1, 1), (1, 2), (3, 2), (4, 2), (5, 2)])
 def test_graph_row_blocks_partition_the_edges(ctx, orc, algo, thr):
     """a GPU owns a block of rows of the sorted rank array and emits the edges whose smaller rank lies in
     it; the blocks of any partition give disjoint lists whose union is the full list (blocks cut inside 256-row tiles,
@@ -501,6 +501,40 @@ def test_graph_row_blocks_partition_the_edges(ctx, orc, algo, thr):
     ctx.graph_set_algo(0)
 
 
+@pytest.mark.parametrize("algo,thr", [(0, 1), (0, 2), (0, 3), (3, 2), (5, 2), (5, 1), (1, 2)])
+def test_graph_parts_partition_the_edges(ctx, orc, algo, thr):
+    """bdg_graph_edges_part_dev: the nparts shares of any cut are disjoint and their union is the oracle's list, whichever
+    path serves the threshold (row blocks for the probes / the q-gram join / the sweep, shares of the 14-mer groups for the
+    deletion-variant join); a part index outside the cut is an error."""
+    import torch
+    ranks = _observed_barcodes(300, 9000, 35)
+    n = len(ranks)
+    T = orc.qgram_threshold(thr)
+    want = orc.graph_edges(ranks, thr, T, threads=8)
+    want = want[np.lexsort((want["b"], want["a"]))]
+    d_ranks = torch.from_numpy(ranks.view(np.int32)).cuda()
+    cap = 4 * n + 1024
+    d_out = torch.zeros((cap, 3), dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ctx.graph_set_algo(algo)
+    for nparts in (1, 3, 8):
+        got = []
+        for part in range(nparts):
+            ctx.graph_edges_part_dev(d_ranks, n, part, nparts, thr, T, d_out, cap, d_cnt)
+            ctx.synchronize()
+            k = int(d_cnt[0])
+            assert k <= cap
+            got.append(d_out[:k].cpu().numpy().view(np.uint32).copy())
+        assert nparts == 1 or min(len(g) for g in got) > 0
+        e = np.concatenate(got)
+        e = e[np.lexsort((e[:, 1], e[:, 0]))]
+        assert len(e) == len(want) and len(e) > 100
+        assert (e[:, 0] == want["a"]).all() and (e[:, 1] == want["b"]).all() and (e[:, 2] == want["dist"]).all()
+    with pytest.raises(_native.BadgerHipError):
+        ctx.graph_edges_part_dev(d_ranks, n, 3, 3, thr, T, d_out, cap, d_cnt)
+    ctx.graph_set_algo(0)
+
+
 def _low_complexity_barcodes(n, seed):
     """16-mers made of short repeats and homopolymer runs with a few edits: six-mers repeat inside a barcode
     (S counts products of multiplicities, index.py:80-93), buckets are very uneven, many pairs have S >= T."""
@@ -525,10 +559,14 @@ def test_graph_qjoin_low_complexity(ctx, orc, thr):
     T = orc.qgram_threshold(thr)
     w = orc.graph_edges(ranks, thr, T, threads=8)
     assert len(w) > 1000
-    for algo in (1, 3, 4):
+    for algo in (1, 3, 4) + ((5,) if thr <= 2 else ()):      # (5: the deletion-variant join; repeats make a row's 14-mers collide)
         ctx.graph_set_algo(algo)
         e = ctx.graph_edges(ranks, thr, T)
         assert len(e) == len(w) and (e == w).all(), algo
+    if thr == 3:
+        ctx.graph_set_algo(5)
+        with pytest.raises(_native.BadgerHipError):
+            ctx.graph_edges(ranks, thr, T)                     # complete for thr <= 2 only
     ctx.graph_set_algo(0)
 
 
@@ -544,7 +582,7 @@ def test_graph_qjoin_dense_slices(ctx, orc):
     assert len(ranks) > 6000                 # the shared bucket's tail alone exceeds the 4096-entry pass for the early rows
     T = orc.qgram_threshold(2)
     w = orc.graph_edges(ranks, 2, T, threads=8)
-    for algo in (3, 1):
+    for algo in (3, 1, 5):
         ctx.graph_set_algo(algo)
         e = ctx.graph_edges(ranks, 2, T)
         assert len(e) == len(w) and (e == w).all(), algo
