@@ -1025,7 +1025,31 @@ void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ 
     __shared__ unsigned long long s_base;
     __shared__ uint32_t s_incl[4][64], s_val[4][64], s_rank[4][64], s_key[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t ne = 0;
+    uint32_t ne = 0, qn = 0;
+    // meetings waiting for their verification: a, b, (rule << 7 | a's deletion pair); the queue lives across the windows
+    __shared__ uint32_t s_qa[4][128], s_qb[4][128], s_qm[4][128];
+    auto verify = [&](uint32_t a, uint32_t b, uint32_t meta, bool act) {
+        const uint32_t d = act ? dmin3(a, b) : 99u;
+        bool edge = d <= thr;
+        if (__ballot(edge)) {
+            edge = edge && (int32_t)qgram_S(a, b) >= T;
+            // rule 3, one pair at a time with the deletion pairs spread over the lanes: reported from here iff none of a's
+            // deletion pairs before this entry's leaves a 14-mer that b has, too
+            for (unsigned long long w = __ballot(edge && (meta >> 7) == 2u); w; w &= w - 1ull) {
+                const int src = __builtin_ctzll(w);
+                const uint32_t ja = (uint32_t)__builtin_amdgcn_readlane((int)a, src), jb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
+                const uint32_t jt = (uint32_t)__builtin_amdgcn_readlane((int)meta, src) & 127u;
+                bool found = false;
+                for (uint32_t t0 = 0; t0 < jt; t0 += 64u) {
+                    const uint32_t t = t0 + (uint32_t)lane;
+                    const uint32_t pq = d2_table.pq[t < D2_NPAIR ? t : 0];
+                    found = found || (t < jt && d2_subseq(d2_key(ja, pq >> 4, pq & 15u), jb));
+                }
+                if (__ballot(found) && lane == src) edge = false;
+            }
+        }
+        edge_push(edge, a, b, d, stages[wv], ne, lane, out, cap, n_edges);
+    };
     // resident grid, the windows interleaved over its waves: a wave reserves output when its stage is full and once at the end
     // (one reservation per window - returning atomics on one address complete ~11 ns apart - would cost more than the kernel)
     const unsigned long long nwin = (m + 63ull) / 64ull;
@@ -1085,30 +1109,28 @@ void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ 
             const uint32_t row_a = lower ? row_i : row_j;
             on = row_a >= row_begin && row_a < row_end;
         }
-        const uint32_t d = on ? dmin3(a, b) : 99u;
-        bool edge = d <= thr;
-        if (__ballot(edge)) {
-            edge = edge && (int32_t)qgram_S(a, b) >= T;
-            const int rep = edge ? d2_reports(a, b, kk) : 0;
-            edge = edge && rep != 0;
-            // rule 3, one pair at a time with the deletion pairs spread over the lanes: reported from here iff none of a's
-            // deletion pairs before this entry's leaves a 14-mer that b has, too
-            for (unsigned long long w = __ballot(edge && rep == 2); w; w &= w - 1ull) {
-                const int src = __builtin_ctzll(w);
-                const uint32_t ja = (uint32_t)__builtin_amdgcn_readlane((int)a, src), jb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
-                const uint32_t jt = (uint32_t)__builtin_amdgcn_readlane((int)t_a, src);
-                bool found = false;
-                for (uint32_t t0 = 0; t0 < jt; t0 += 64u) {
-                    const uint32_t t = t0 + (uint32_t)lane;
-                    const uint32_t pq = d2_table.pq[t < D2_NPAIR ? t : 0];
-                    found = found || (t < jt && d2_subseq(d2_key(ja, pq >> 4, pq & 15u), jb));
-                }
-                if (__ballot(found) && lane == src) edge = false;
-            }
+        // A pair meets in several groups and is reported from one of them; which one is asked first (a few dozen
+        // instructions), and only the meetings that would report go on to the verification (dmin and S, some hundred), 64 at a
+        // time out of a queue - on dense data four meetings of five end here
+        const int rep = on ? d2_reports(a, b, kk) : 0;
+        const unsigned long long mq = __ballot(rep != 0);
+        if (rep != 0) {
+            const uint32_t at = qn + lanes_below_u64(mq, lane);
+            s_qa[wv][at] = a; s_qb[wv][at] = b; s_qm[wv][at] = (uint32_t)rep << 7 | t_a;
         }
-        edge_push(edge, a, b, d, stages[wv], ne, lane, out, cap, n_edges);
+        qn += (uint32_t)__popcll(mq);
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64u) {
+            qn -= 64u;
+            verify(s_qa[wv][qn + lane], s_qb[wv][qn + lane], s_qm[wv][qn + lane], true);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     __builtin_amdgcn_wave_barrier();                                 // (the window's LDS rows are rewritten next)
+    }
+    if (qn) {
+        const bool act = (uint32_t)lane < qn;
+        verify(act ? s_qa[wv][lane] : 0u, act ? s_qb[wv][lane] : 1u, act ? s_qm[wv][lane] : 0u, act);
     }
     edge_finish<4>(stages, ne, s_cnt, &s_base, out, cap, n_edges);
 }
