@@ -48,3 +48,27 @@ def test_scan_kernel_budget(scan_isa):
     assert int(meta["num_vgpr"]) <= 128, "more than 128 registers: fewer than 4 waves per SIMD"
     lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", desc).group(1))
     assert 2 * lds <= 160 * 1024, "two blocks no longer fit a CU's LDS"
+
+
+def test_deletion_variant_join_kernels_budget(tmp_path):
+    """The deletion-variant join's kernels are sized by hand from these: no scratch, native LDS minimum for the row's
+    repeat table, and an LDS footprint that lets several blocks share a compute unit (the index passes run 8, the pair
+    kernel 5 resident blocks)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path / "graph.s")
+    src = os.path.join(ROOT, "badger_amd", "csrc", "graph_kernels.hip")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-Wno-unused-function",
+                    "-Wno-inline-asm", "-Wno-unused-command-line-argument", "-I", os.path.join(ROOT, "include"), "-o", out, src],
+                   check=True, timeout=900)
+    text = open(out).read()
+    for name, max_vgpr, max_lds in (("k_d2_count", 64, 20 * 1024), ("k_d2_emit", 64, 20 * 1024), ("k_d2_pairs", 128, 32 * 1024)):
+        m = re.search(r"^(_ZN\S*%s\S*):[^\n]*\n(.*?)\n\s*\.amdhsa_kernel \1\n(.*?)\.end_amdhsa_kernel" % name, text, re.S | re.M)
+        assert m, name + " not found in the generated code"
+        meta = dict(re.findall(r"\.set \S*%s\S*\.(num_vgpr|private_seg_size), (\d+)" % name, text))
+        assert int(meta["private_seg_size"]) == 0, name + " spills"
+        assert int(meta["num_vgpr"]) <= max_vgpr, (name, meta["num_vgpr"])
+        lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", m.group(3)).group(1))
+        assert lds <= max_lds, (name, lds)
+        if name != "k_d2_pairs":
+            assert "ds_min_u32" in m.group(2) and "ds_cmpst" not in m.group(2), name + ": the table update is no longer one LDS instruction"
