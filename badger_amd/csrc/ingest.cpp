@@ -39,10 +39,12 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 
 #include "ingest_internal.hpp"
+#include "pgunzip.hpp"
 
 namespace {
 
@@ -198,7 +200,15 @@ struct Source {
     size_t seg_bytes = size_t(16) << 20;
     z_stream z; bool z_init = false, member_open = false;
     uint64_t produced = 0;
+    // a plain gzip member of some size is inflated by several threads (pgunzip.hpp); small ones and threads = 1 take zlib
+    std::unique_ptr<PGunzip> pgz; unsigned gz_threads = 1;
+    static constexpr size_t PGZ_MIN_BYTES = size_t(1) << 20;
 
+    static size_t pgz_min()
+    {
+        const char* e = getenv("BADGER_AMD_GUNZIP_MIN_KB");                 // (for tests: small files through the parallel path)
+        return e ? (size_t)std::max(0, atoi(e)) << 10 : PGZ_MIN_BYTES;
+    }
     static bool is_bgzf_header(const uint8_t* h, size_t n)
     {
         return n >= 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 &&
@@ -222,6 +232,7 @@ struct Source {
     }
     ~Source()
     {
+        pgz.reset();                                         // (its threads read the mapping)
         if (z_init) inflateEnd(&z);
         if (map && size > unmapped) munmap(const_cast<uint8_t*>(map) + unmapped, size - unmapped);
         if (fd >= 0) close(fd);
@@ -273,6 +284,14 @@ struct Source {
                     if (size - pos < 2 || map[pos] != 0x1f || map[pos + 1] != 0x8b) break;
                     if (bgzf_parallel && is_bgzf_header(map + pos, size - pos)) break;          // the next claim takes the blocks
                     inflateReset(&z); member_open = true;
+                }
+                if (!pgz && gz_threads > 1 && z.total_in == 0 && size - pos >= pgz_min())       // at a member's first byte
+                    pgz.reset(new PGunzip(map + pos, size - pos, gz_threads, 0));
+                if (pgz) {
+                    out += pgz->read(s.own + out, seg_bytes - out);
+                    if (pgz->failed()) { s.failed = true; s.err = pgz->error(); pgz.reset(); break; }
+                    if (pgz->at_member_end()) { pos += pgz->consumed(); pgz.reset(); member_open = false; }
+                    continue;
                 }
                 const size_t in_av = std::min<size_t>(size - pos, 1u << 30), out_av = std::min<size_t>(seg_bytes - out, 1u << 30);
                 if (in_av == 0) { s.failed = true; s.err = "gzip: unexpected end of file"; break; }     // (gzip.open raises EOFError)
@@ -916,6 +935,7 @@ int bdg_ingest_open_ex(const char* path, const bdg_ingest_opts* o, bdg_ingest** 
     if (o->segment_bytes) g->src.seg_bytes = std::max<uint64_t>(o->segment_bytes, 64);
     else if (const char* e = getenv("BADGER_AMD_SEGMENT_MB")) { const long mb = atol(e); if (mb > 0 && mb <= 4096) g->src.seg_bytes = (size_t)mb << 20; }
     g->src.bgzf_parallel = o->threads != 1;                  // 1: every compressed input as one sequential gzip stream (what gzip.open does)
+    g->src.gz_threads = o->threads ? o->threads : std::min(12u, std::max(1u, std::thread::hardware_concurrency()));
     // pysam opens BAM and SAM by content; so does this, as far as the first bytes of an uncompressed file tell
     if (!g->src.compressed && (format == F_SAM || format == F_BAM))
         format = g->src.size >= 4 && memcmp(g->src.map, "BAM\1", 4) == 0 ? F_BAM : F_SAM;

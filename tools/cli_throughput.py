@@ -63,6 +63,9 @@ def run_cli(path, out, threads, timing, extra=()):
     return wall, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in br.items() if k.startswith("seconds") or k in ("chunks", "out_bytes")}
 
 
+GZ_SLABS = int(os.environ.get("CLI_GZ_SLABS", "1"))
+
+
 def main():
     from oracle import pyoracle as orc
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 12500000
@@ -80,15 +83,16 @@ def main():
         tb, to = synth.make_reads(k, wl, seed=1 + done // SLAB, device="cuda")
         tb, to = tb.cpu(), to.cpu()
         bases, off = tb.numpy(), to.numpy().astype(np.uint64)
+        if done < GZ_SLABS * SLAB:                      # the plain-gzip form holds the first GZ_SLABS slabs (gzip -1 of a slab takes ~10 s)
+            gz1 = os.path.join(tmp, "cli_reads_1m.fastq")
+            if done == 0 and os.path.exists(gz1):
+                os.remove(gz1)
+            assert L.fq_append(gz1.encode(), bases.ctypes.data, off.ctypes.data, k, done, b"read_") > 0
         if done == 0:
             k0 = min(k, 200000)
             recs = orc.extract_batch(bases[:int(off[k0])], off[:k0 + 1], 12, threads=16)
             seqs = synth.reads_to_list(tb[:int(off[k0])], to[:k0 + 1])
             first_rows = "".join(record_to_row("read_%d" % i, s, r) + "\n" for i, (s, r) in enumerate(zip(seqs, recs))).encode()
-            gz1 = os.path.join(tmp, "cli_reads_1m.fastq")
-            if os.path.exists(gz1):
-                os.remove(gz1)
-            assert L.fq_append(gz1.encode(), bases.ctypes.data, off.ctypes.data, k, 0, b"read_") > 0
         assert L.fq_append(fq.encode(), bases.ctypes.data, off.ctypes.data, k, done, b"read_") > 0
         done += k
     forms = "plain,bgzf,gz"
@@ -108,9 +112,9 @@ def main():
                       "cores": len(os.sched_getaffinity(0)), "cpu_count": os.cpu_count()}), flush=True)
     timing = os.path.join(tmp, "cli_timing.jsonl")
     digests = {}
-    inputs = [(fq, n)] * ("plain" in forms) + [(bgz, n)] * ("bgzf" in forms) + [(gz1 + ".gz", min(n, SLAB))] * ("gz" in forms)
+    inputs = [(fq, n)] * ("plain" in forms) + [(bgz, n)] * ("bgzf" in forms) + [(gz1 + ".gz", min(n, GZ_SLABS * SLAB))] * ("gz" in forms)
     for path, nreads in inputs:
-        for threads in (0, 1) if path != fq else (0, 1, 4, 8, 16):
+        for threads in (0, 1) if path == bgz else (0, 1, 4, 8, 16):
             # the readers alone (pageable buffers: no GPU, no pinning)
             t0 = time.perf_counter()
             ing = _native.Ingest(path, 100000, 8, pinned=False, inflate_threads=threads)
