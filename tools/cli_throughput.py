@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end throughput of the stage-1 command line (python -m badger_amd.extract_raw_barcodes) on one MI355X box, at a
 size where fixed costs stop dominating: N synthetic reads (default 12.5 M = one GPU's share of BASELINE config 4; made
-in 1 M-read slabs with seeds 1, 2, ...) as plain FASTQ, BGZF and (first slab only) plain gzip -> TSV.  Wall clock of the
+in 1 M-read slabs with seeds 1, 2, ...) as plain FASTQ, BGZF, BAM (--forms=...,bam) and (first CLI_GZ_SLABS slabs) plain gzip -> TSV.  Wall clock of the
 whole process, where its time went (BADGER_AMD_STAGE1_TIMING: the native pipeline's own breakdown), the readers alone,
 and the checks: the rows of the first slab equal the rows the CPU oracle's records give; every input form and both file
 shapes give the same rows (sha256 over the non-header lines).  One JSON object per line.
@@ -35,6 +35,8 @@ def helper(tmp):
     L = C.CDLL(so)
     L.fq_append.restype = C.c_int64
     L.fq_append.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p]
+    L.bam_raw_append.restype = C.c_int64
+    L.bam_raw_append.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p]
     L.bgzf_compress_file.restype = C.c_int64
     L.bgzf_compress_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     return L
@@ -94,6 +96,8 @@ def main():
             seqs = synth.reads_to_list(tb[:int(off[k0])], to[:k0 + 1])
             first_rows = "".join(record_to_row("read_%d" % i, s, r) + "\n" for i, (s, r) in enumerate(zip(seqs, recs))).encode()
         assert L.fq_append(fq.encode(), bases.ctypes.data, off.ctypes.data, k, done, b"read_") > 0
+        if "--forms=" in " ".join(sys.argv) and "bam" in [a for a in sys.argv if a.startswith("--forms=")][0]:
+            assert L.bam_raw_append(os.path.join(tmp, "cli_reads.rawbam").encode(), bases.ctypes.data, off.ctypes.data, k, done, b"read_") > 0
         done += k
     forms = "plain,bgzf,gz"
     for a in sys.argv[1:]:
@@ -105,6 +109,11 @@ def main():
     if "bgzf" in forms:
         assert L.bgzf_compress_file(fq.encode(), bgz.encode(), 1) > 0
         sizes["bgzf.fastq.gz"] = os.path.getsize(bgz)
+    bam = os.path.join(tmp, "cli_reads.bam")
+    if "bam" in forms:
+        assert L.bgzf_compress_file(os.path.join(tmp, "cli_reads.rawbam").encode(), bam.encode(), 1) > 0
+        os.remove(os.path.join(tmp, "cli_reads.rawbam"))
+        sizes["bam"] = os.path.getsize(bam)
     if "gz" in forms:
         subprocess.check_call("gzip -1 -k -f %s" % gz1, shell=True)
         sizes["1m.fastq.gz"] = os.path.getsize(gz1 + ".gz")
@@ -112,7 +121,7 @@ def main():
                       "cores": len(os.sched_getaffinity(0)), "cpu_count": os.cpu_count()}), flush=True)
     timing = os.path.join(tmp, "cli_timing.jsonl")
     digests = {}
-    inputs = [(fq, n)] * ("plain" in forms) + [(bgz, n)] * ("bgzf" in forms) + [(gz1 + ".gz", min(n, GZ_SLABS * SLAB))] * ("gz" in forms)
+    inputs = [(fq, n)] * ("plain" in forms) + [(bgz, n)] * ("bgzf" in forms) + [(bam, n)] * ("bam" in forms) + [(gz1 + ".gz", min(n, GZ_SLABS * SLAB))] * ("gz" in forms)
     for path, nreads in inputs:
         for threads in (0, 1) if path == bgz else (0, 1, 4, 8, 16):
             # the readers alone (pageable buffers: no GPU, no pinning)

@@ -35,6 +35,55 @@ int64_t fq_append(const char* path, const uint8_t* bases, const uint64_t* off, u
     return total;
 }
 
+/* appends n unmapped records (flag 4, quality 0xFF = absent) to the UNCOMPRESSED BAM at path, writing the header first when
+ * first_id == 0 (SAM specification 4.2; bgzf_compress_file turns the result into a .bam); returns bytes written */
+int64_t bam_raw_append(const char* path, const uint8_t* bases, const uint64_t* off, uint64_t n, uint64_t first_id, const char* prefix)
+{
+    FILE* f = fopen(path, first_id == 0 ? "wb" : "ab");
+    if (!f) return -1;
+    static uint8_t code[256];
+    memset(code, 15, sizeof(code));
+    code['A'] = 1; code['C'] = 2; code['G'] = 4; code['T'] = 8; code['N'] = 15;
+    size_t cap = 64u << 20, used = 0;
+    uint8_t* buf = (uint8_t*)malloc(cap + (32u << 20));
+    if (!buf) { fclose(f); return -2; }
+    int64_t total = 0;
+    if (first_id == 0) {
+        static const char text[] = "@HD\tVN:1.6\tSO:unsorted\n";
+        const uint32_t l_text = (uint32_t)(sizeof(text) - 1), n_ref = 0;
+        memcpy(buf, "BAM\1", 4); memcpy(buf + 4, &l_text, 4); memcpy(buf + 8, text, l_text); memcpy(buf + 8 + l_text, &n_ref, 4);
+        used = 12 + l_text;
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t L = off[i + 1] - off[i];
+        if (used + 2 * L + 256 > cap + (32u << 20) || used > cap) {
+            if (fwrite(buf, 1, used, f) != used) { free(buf); fclose(f); return -3; }
+            total += (int64_t)used; used = 0;
+        }
+        char name[64];
+        const uint32_t l_name = (uint32_t)sprintf(name, "%s%llu", prefix, (unsigned long long)(first_id + i)) + 1;
+        const uint32_t l_seq = (uint32_t)L, block = 32 + l_name + (l_seq + 1) / 2 + l_seq;
+        uint8_t* o = buf + used;
+        const int32_t minus1 = -1; const uint32_t zero = 0;
+        memcpy(o, &block, 4); memcpy(o + 4, &minus1, 4); memcpy(o + 8, &minus1, 4);
+        o[12] = (uint8_t)l_name; o[13] = 0; o[14] = 0x48; o[15] = 0x12;                 /* l_read_name, mapq, bin 4680 */
+        o[16] = 0; o[17] = 0; o[18] = 4; o[19] = 0;                                     /* n_cigar_op 0, flag 4 */
+        memcpy(o + 20, &l_seq, 4); memcpy(o + 24, &minus1, 4); memcpy(o + 28, &minus1, 4); memcpy(o + 32, &zero, 4);
+        memcpy(o + 36, name, l_name);
+        uint8_t* q = o + 36 + l_name;
+        const uint8_t* b = bases + off[i];
+        for (uint64_t k = 0; k + 1 < L; k += 2) *q++ = (uint8_t)(code[b[k]] << 4 | code[b[k + 1]]);
+        if (L & 1) *q++ = (uint8_t)(code[b[L - 1]] << 4);
+        memset(q, 0xFF, L);
+        used += 4 + block;
+    }
+    if (used && fwrite(buf, 1, used, f) != used) { free(buf); fclose(f); return -3; }
+    total += (int64_t)used;
+    free(buf);
+    if (fclose(f) != 0) return -4;
+    return total;
+}
+
 /* in -> out as BGZF (SAM specification 4.1: gzip members of <= 64 KiB with the 'BC' size field, plus the end marker);
  * blocks are compressed in parallel, written in order; returns bytes written, < 0 on error */
 int64_t bgzf_compress_file(const char* in, const char* out, int level)
