@@ -12,7 +12,8 @@
 //   * plain file: the file is mapped, a segment is a byte range of the mapping;
 //   * BGZF (bgzip / htslib: gzip members of <= 64 KiB that state their own size, SAM specification 4.1): a segment is a run
 //     of members, inflated by the worker that parses it (libdeflate when the system has it, else zlib);
-//   * plain gzip: one stream - whoever takes the next segment inflates it, parsing overlaps the next segment's inflate.
+//   * plain gzip: one stream without an index, inflated by several threads all the same (pgunzip.hpp); a segment is the
+//     next 16 MiB of its output.
 // A worker finds the first record start inside its segment (FASTQ: a line starting with '@' whose line + 2 starts with '+'
 // and whose lines + 1 / + 3 have equal lengths; FASTA: a line starting with '>'; SAM: any line), parses whole records from
 // there into a pinned chunk and reports what it could not own: the bytes before that start (HEAD) and the unfinished record
@@ -21,7 +22,7 @@
 // induction the ones a sequential parse would have produced (the guess above only decides whether the fast path is taken,
 // never what is parsed); if not - or the worker met a malformed record - the assembler parses on sequentially from there, so
 // malformed input fails with the same message and line number as a one-thread parse.  BAM records are length-prefixed
-// binary without a resynchronisation mark: their segments are inflated in parallel and decoded in sequence.
+// binary without a resynchronisation mark: a reader guesses a record start from the fixed fields of three records in a row.
 // Chunks handed out never span two segments and hold at most chunk_reads reads; a file smaller than one segment gives the
 // reference's exact READ_CHUNK_SIZE chunking.
 // Plain C++ (zlib; libdeflate by dlopen); the only HIP calls are hipHostMalloc / hipHostFree for the pinned buffers.
@@ -370,6 +371,7 @@ struct Parser {
     std::string err;
     // BAM
     int bst = 0; uint64_t skip = 0; uint32_t refs_left = 0, need = 8;
+    size_t bam_mark = 0, bam_end = 0;   // offsets into the buffer of the current feed(): where the record in progress starts / what has been looked at
     uint8_t sam_map[256]; uint16_t bam_pair[256];
 
     void init(int fmt, bool pin, bool skip2, uint32_t lim, ChunkSink* sk)
@@ -581,8 +583,10 @@ struct Parser {
     bool feed_bam(const uint8_t* p, size_t n)
     {
         size_t i = 0;
+        bam_mark = 0; bam_end = n;
         for (;;) {
             if (skip) { const size_t k = (size_t)std::min<uint64_t>(skip, n - i); i += k; skip -= k; if (skip) return true; }
+            if (bst == 4 && partial.empty()) bam_mark = i;               // a record's size word starts here
             const uint8_t* it;
             bool from_partial = false;
             if (!partial.empty()) {
@@ -625,8 +629,41 @@ struct Parser {
 };
 
 // first offset of [0, n) at which a record starts, by the format's local evidence (see the file header); n if none is found
+// BAM has no mark to look for: a record start is a place where the fixed fields are possible (block size against the lengths
+// it must hold, reference and position >= -1, a printable NUL-terminated name) and where the same holds for the two records
+// that would follow.  The assembler proves or refutes the guess like any other.
+bool bam_record_plausible(const uint8_t* d, size_t n, size_t i, size_t* next)
+{
+    if (n - i < 36) return false;
+    auto u32 = [&](size_t at) { return (uint32_t)d[at] | ((uint32_t)d[at + 1] << 8) | ((uint32_t)d[at + 2] << 16) | ((uint32_t)d[at + 3] << 24); };
+    const uint32_t bs = u32(i);
+    if (bs < 32 || bs > (1u << 29)) return false;
+    if ((int32_t)u32(i + 4) < -1 || (int32_t)u32(i + 8) < -1 || (int32_t)u32(i + 24) < -1 || (int32_t)u32(i + 28) < -1) return false;
+    const uint32_t l_name = d[i + 12], n_cig = (uint32_t)d[i + 16] | ((uint32_t)d[i + 17] << 8), l_seq = u32(i + 20);
+    if (l_name == 0 || l_seq > (1u << 29)) return false;
+    if (32ull + l_name + 4ull * n_cig + (l_seq + 1) / 2 + (uint64_t)l_seq > bs) return false;
+    const size_t name = i + 36;
+    if (name + l_name <= n) {
+        for (uint32_t k = 0; k + 1 < l_name; ++k) if (d[name + k] < '!' || d[name + k] > '~') return false;
+        if (d[name + l_name - 1] != 0) return false;
+    }
+    *next = i + 4 + (size_t)bs;
+    return true;
+}
+size_t resync_bam(const uint8_t* d, size_t n)
+{
+    for (size_t i = 0; i + 36 <= n; ++i) {
+        size_t a, b, c;
+        if (!bam_record_plausible(d, n, i, &a)) continue;
+        if (a + 36 <= n) { if (!bam_record_plausible(d, n, a, &b)) continue; if (b + 36 <= n && !bam_record_plausible(d, n, b, &c)) continue; }
+        return i;
+    }
+    return n;
+}
+
 size_t resync(int format, const uint8_t* d, size_t n)
 {
+    if (format == F_BAM) return resync_bam(d, n);
     const char* p = reinterpret_cast<const char*>(d);
     size_t i = 0;
     int tries = 0;
@@ -729,7 +766,7 @@ struct bdg_ingest : ChunkSink {
         Inflater inf;
         Parser wp;
         wp.init(format, pinned, skip_secondary, 0, nullptr);
-        const bool can_parse = format != F_BAM;
+        const bool can_parse = true;
         for (;;) {
             IngestChunk* c = nullptr;
             bool want_parse;
@@ -768,8 +805,17 @@ struct bdg_ingest : ChunkSink {
                     const size_t room = std::max(span, std::min(src.seg_bytes, src.compressed ? src.seg_bytes : src.size));
                     const bool ok = chunk_prepare(c, room / 512 + 1024, format == F_FASTQ ? room / 2 + 65536 : room + 65536, room / 32 + 4096);
                     wp.c = c; wp.st = 0; wp.partial.clear(); wp.failed = false; wp.nomem = false; wp.noseq = false; wp.err.clear(); wp.line_no = 0;
+                    wp.bst = s->first ? 0 : 4; wp.need = s->first ? 8 : 4; wp.skip = 0; wp.refs_left = 0;      // (BAM: the header, or between two records)
                     if (!ok || !wp.feed(s->data + first, span)) s->bad = true;            // the assembler parses it again, in sequence, and reports
-                    else {
+                    else if (format == F_BAM) {
+                        if (wp.bst < 4) s->bad = true;                                   // (a header longer than a segment: left to the assembler)
+                        else {
+                            // what the last record in progress has not finished goes back: from its size word on
+                            s->tail_off = first + ((wp.bst == 5 || !wp.partial.empty()) ? wp.bam_mark : wp.bam_end);
+                            s->lines = wp.line_no;                                        // (records, for messages)
+                        }
+                        wp.partial.clear();
+                    } else {
                         if (wp.record_open()) { wp.rollback_open(); s->tail_off = first + wp.rec_off; }
                         else s->tail_off = first + wp.consumed;
                         // lines inside [head_len, tail_off) = whole lines seen - whole lines of the tail
@@ -804,7 +850,7 @@ struct bdg_ingest : ChunkSink {
     void assemble()
     {
         seqp.init(format, pinned, skip_secondary, 0, this);
-        bool seq_mode = format == F_BAM;
+        bool seq_mode = false;
         // (seqp.c is the chunk the sequential parser appends to: on the fast path the previous segment's chunk, which so
         // receives the record cut by the segment boundary)
         auto fresh = [&]() -> IngestChunk* {
@@ -855,7 +901,9 @@ struct bdg_ingest : ChunkSink {
             } else {
                 ok = seqp.feed(s->data, s->head_len);
                 if (ok && s->head_len < s->len) {
-                    const bool boundary = seqp.partial.empty() && (format != F_FASTQ || seqp.st == 0);
+                    // (BAM: between two records - or nothing read yet and this is the file's first segment, whose reader took the header)
+                    const bool boundary = seqp.partial.empty() && (format != F_FASTQ || seqp.st == 0) &&
+                                          (format != F_BAM || (seqp.bst == 4 && !seqp.skip) || (s->first && seqp.bst == 0));
                     if (!boundary || s->bad) {
                         if (getenv("BADGER_AMD_INGEST_DEBUG")) fprintf(stderr, "ingest: segment %llu leaves the fast path (boundary %d, bad %d, st %d, partial %zu, head %zu, tail %zu, len %zu)\n",
                                                                        (unsigned long long)s->seq, (int)boundary, (int)s->bad, seqp.st, seqp.partial.size(), s->head_len, s->tail_off, s->len);
@@ -866,6 +914,7 @@ struct bdg_ingest : ChunkSink {
                         emit(seqp.c);
                         seqp.c = s->chunk; s->chunk = nullptr;
                         seqp.line_no += s->lines;
+                        if (format == F_BAM) { seqp.bst = 4; seqp.need = 4; seqp.skip = 0; seqp.refs_left = 0; }
                         ok = seqp.feed(s->data + s->tail_off, s->len - s->tail_off);
                     }
                 }
