@@ -24,7 +24,7 @@ constexpr uint32_t WIN = 32768;
 constexpr uint16_t MARK = 256;              // symbol >= MARK: the byte at place (symbol - MARK) of the 32 KiB before the chunk
 constexpr int FAST = 10;                    // codes of up to FAST bits are decoded by one table look-up
 
-enum { PG_OK = 0, PG_FINAL = 1, PG_DATA = -1, PG_EOF = -2, PG_NOTTEXT = -3 };
+enum { PG_OK = 0, PG_FINAL = 1, PG_DATA = -1, PG_EOF = -2, PG_NOTTEXT = -3, PG_NOMEM = -4 };
 
 // ---- bits, least significant first ---------------------------------------------------------------------------------------
 struct Bits {
@@ -207,7 +207,7 @@ int read_dynamic(Bits& b, Huff& hl, Huff& hd)
     int left = hl.build(lens, hlit);
     if (left < 0 || (left > 0 && !(hl.n_codes == 1 && hl.max_len == 1))) return PG_DATA;
     left = hd.build(lens + hlit, hdist);
-    if (left < 0 || (left > 0 && hd.n_codes > 1)) return PG_DATA;      // (one distance code, or none, may leave the code incomplete)
+    if (left < 0 || (left > 0 && hd.max_len > 1)) return PG_DATA;      // (one distance code of one bit, or none, may leave the code incomplete: zlib's rule)
     return PG_OK;
 }
 
@@ -225,7 +225,7 @@ int inflate_block(Bits& b, Out& o, size_t hist, bool text_only)
         if (!b.get(32, v)) return PG_EOF;
         const uint32_t len = v & 0xFFFF;
         if ((len ^ (v >> 16)) != 0xFFFF) return PG_DATA;
-        if (!o.reserve(o.n + len)) return PG_DATA;
+        if (!o.reserve(o.n + len)) return PG_NOMEM;
         // (the buffered bits are whole bytes now)
         uint32_t i = 0;
         for (; i < len && b.cnt >= 8; ++i) { o.d[o.n + i] = (uint16_t)(b.buf & 0xFF); b.drop(8); }
@@ -243,7 +243,7 @@ int inflate_block(Bits& b, Out& o, size_t hist, bool text_only)
     if (type == 1) { hl = &fixed_codes().lit; hd = &fixed_codes().dist; }
     else { const int rc = read_dynamic(b, dl, dd); if (rc != PG_OK) return rc; hl = &dl; hd = &dd; }
     for (;;) {
-        if (o.n + 260 > o.cap && !o.reserve(o.n + (size_t(1) << 20))) return PG_DATA;
+        if (o.n + 260 > o.cap && !o.reserve(o.n + (size_t(1) << 20))) return PG_NOMEM;
         const int s = hl->decode(b);
         if (s < 0) return s;
         if (s < 256) {
@@ -465,7 +465,7 @@ struct PGunzipImpl {
     }
     void set_error(int rc)
     {
-        err = rc == PG_EOF ? "gzip: unexpected end of file" : "gzip: corrupt data";
+        err = rc == PG_EOF ? "gzip: unexpected end of file" : rc == PG_NOMEM ? "out of memory" : "gzip: corrupt data";
         std::lock_guard<std::mutex> lk(mu);
         fail = true; chain_done = true;
     }
