@@ -142,3 +142,35 @@ def test_reader_takes_the_parallel_path(tmp_path, monkeypatch, text):
     cut.write_bytes(gz.read_bytes()[:len(gz.read_bytes()) // 2])
     with pytest.raises(Exception, match="unexpected end of file"):
         records(cut, 4)
+
+
+def test_reader_on_mixed_members_through_the_parallel_path(tmp_path, monkeypatch, text):
+    """several plain gzip members, BGZF blocks in front of and behind them, an empty member and trailing bytes that are no
+    member: every plain member goes through PGunzip (forced, 2 KiB chunks) and the records are those of the plain text"""
+    from test_ingest import _bgzf
+    monkeypatch.setenv("BADGER_AMD_GUNZIP_MIN_KB", "0")
+    monkeypatch.setenv("BADGER_AMD_GUNZIP_CHUNK_KB", "2")
+    cut = [text.index(b"@read_%d " % k) for k in (2000, 5000, 9000)]
+    plain = tmp_path / "m.fastq"
+    plain.write_bytes(text)
+    mixed = tmp_path / "m.fastq.gz"
+    mixed.write_bytes(_bgzf(text[:cut[0]], eof_marker=False) + gzip.compress(text[cut[0]:cut[1]], 6) + gzip.compress(b"") +
+                      gzip.compress(text[cut[1]:cut[2]], 1) + _bgzf(text[cut[2]:]) + b"\0\0trailing")
+
+    def records(path, threads):
+        out = []
+        ing = _native.Ingest(str(path), chunk_reads=3000, pinned=False, inflate_threads=threads, segment_bytes=300000)
+        try:
+            while True:
+                ch = ing.next()
+                if ch.n == 0:
+                    break
+                out += _native.chunk_reads(ch)
+                ing.release(ch)
+        finally:
+            ing.close()
+        return out
+    want = records(plain, 1)
+    assert len(want) == 12000
+    for threads in (0, 3):
+        assert records(mixed, threads) == want, threads

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end wall time of the stage-2 CLI (python -m badger_amd.badger) on one MI355X box: 1M synthetic reads,
 (a) from the stage-1 TSV (host route), (b) from the FASTQ itself (extraction + device hand-off), thresholds 1 and 2.
-Prints one JSON object per line.  Builder tool."""
+Prints one JSON object per line.  S2_EXTRA="-hs": more flags for badger.py.  Builder tool."""
 import json
 import os
 import subprocess
@@ -55,7 +55,7 @@ def main():
                     os.remove(timing)
                 t0 = time.perf_counter()
                 subprocess.check_call([sys.executable, "-m", "badger_amd.badger", "-r", reads, "-d", "tenX_v3", "-l", wlf, "-c", "5000",
-                                       "-t", thr, "-tr", "16", "-o", prefix], cwd=ROOT, stdout=subprocess.DEVNULL,
+                                       "-t", thr, "-tr", "16", "-o", prefix] + os.environ.get("S2_EXTRA", "").split(), cwd=ROOT, stdout=subprocess.DEVNULL,
                                       env=dict(os.environ, BADGER_AMD_STAGE2_TIMING=timing))
                 wall = time.perf_counter() - t0
                 if best is None or wall < best[0]:
