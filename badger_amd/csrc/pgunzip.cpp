@@ -3,6 +3,7 @@
 // supplies crc32().
 #include "pgunzip.hpp"
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -61,11 +62,58 @@ struct Bits {
     void align_byte() { drop(cnt & 7); }
 };
 
+// CRC-32 of a piece: libdeflate's (carry-less multiplication, several GB/s) when the system has the library, else zlib's
+typedef uint32_t (*crc_fn)(uint32_t, const void*, size_t);
+crc_fn fast_crc()
+{
+    static const crc_fn f = [] {
+        if (getenv("BADGER_AMD_NO_LIBDEFLATE")) return (crc_fn) nullptr;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        return h ? reinterpret_cast<crc_fn>(dlsym(h, "libdeflate_crc32")) : (crc_fn) nullptr;
+    }();
+    return f;
+}
+uint32_t crc_of(const uint8_t* d, size_t n)
+{
+    if (const crc_fn f = fast_crc()) return f(0, d, n);
+    uint32_t c = 0;
+    for (size_t k = 0; k < n; k += size_t(1) << 30) c = (uint32_t)crc32(c, d + k, (uInt)std::min<size_t>(n - k, size_t(1) << 30));
+    return c;
+}
+
+const uint16_t LEN_BASE[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+const uint8_t LEN_EXTRA[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+const uint16_t DIST_BASE[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193,
+                                 12289, 16385, 24577 };
+const uint8_t DIST_EXTRA[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+
+#define LEN_BASE_OF(i) LEN_BASE[i]
+#define LEN_EXTRA_OF(i) LEN_EXTRA[i]
+#define DIST_BASE_OF(i) DIST_BASE[i]
+#define DIST_EXTRA_OF(i) DIST_EXTRA[i]
+
 // ---- a canonical Huffman code -------------------------------------------------------------------------------------------
 struct Huff {
     uint16_t fast[1 << FAST];               // (symbol << 4) | length, 0: longer than FAST bits (or no such code)
     uint16_t count[16], symbol[288];
     int n_codes = 0, max_len = 0;
+    // the same look-up with what the hot loop needs next already in the entry (pack()): bits 0-3 code length, 4-7 extra bits,
+    // 8-9 kind (0 literal, 1 length or distance, 2 end of block; 3 = not in the table: the careful loop takes over), 16-31
+    // the literal / base length / base distance
+    uint32_t packed[1 << FAST];
+    void pack(bool lengths)
+    {
+        for (uint32_t x = 0; x < (1u << FAST); ++x) {
+            const uint16_t e = fast[x];
+            if (!e) { packed[x] = 3u << 8; continue; }
+            const uint32_t sym = e >> 4, l = e & 15u;
+            if (!lengths) packed[x] = sym > 29 ? 3u << 8 : l | (uint32_t)DIST_EXTRA_OF(sym) << 4 | 1u << 8 | (uint32_t)DIST_BASE_OF(sym) << 16;
+            else if (sym < 256) packed[x] = l | sym << 16;
+            else if (sym == 256) packed[x] = l | 2u << 8;
+            else if (sym > 285) packed[x] = 3u << 8;
+            else packed[x] = l | (uint32_t)LEN_EXTRA_OF(sym - 257) << 4 | 1u << 8 | (uint32_t)LEN_BASE_OF(sym - 257) << 16;
+        }
+    }
     // 0: complete; > 0: incomplete (unused code space); < 0: over-subscribed
     int build(const uint8_t* lens, int n)
     {
@@ -120,12 +168,6 @@ struct Huff {
     }
 };
 
-const uint16_t LEN_BASE[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
-const uint8_t LEN_EXTRA[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
-const uint16_t DIST_BASE[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193,
-                                 12289, 16385, 24577 };
-const uint8_t DIST_EXTRA[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
-
 struct FixedCodes {
     Huff lit, dist;
     FixedCodes()
@@ -139,6 +181,7 @@ struct FixedCodes {
         uint8_t d[30];
         for (int i = 0; i < 30; ++i) d[i] = 5;
         dist.build(d, 30);
+        lit.pack(true); dist.pack(false);
     }
 };
 const FixedCodes& fixed_codes() { static const FixedCodes f; return f; }
@@ -238,10 +281,64 @@ int inflate_block(Bits& b, Out& o, size_t hist, bool text_only)
         o.n += len;
         return final ? PG_FINAL : PG_OK;
     }
-    Huff dl, dd;                                         // (2.6 KB of stack: a block's own codes)
+    Huff dl, dd;                                         // (a block's own codes, on the stack)
     const Huff* hl; const Huff* hd;
     if (type == 1) { hl = &fixed_codes().lit; hd = &fixed_codes().dist; }
-    else { const int rc = read_dynamic(b, dl, dd); if (rc != PG_OK) return rc; hl = &dl; hd = &dd; }
+    else { const int rc = read_dynamic(b, dl, dd); if (rc != PG_OK) return rc; dl.pack(true); dd.pack(false); hl = &dl; hd = &dd; }
+    // The hot loop: while at least 16 input bytes lie ahead, one refill (>= 56 bits) covers two literals or a whole
+    // length / distance pair (15 + 5 + 15 + 13 bits); entries say what follows without a second table; copies go eight symbols
+    // at a time.  Anything unusual (a code longer than the table's 10 bits, the end of the input, a bad symbol) leaves it for
+    // the careful loop below, which decides.
+    constexpr uint32_t FM = (1u << FAST) - 1u;
+    while (b.end - b.p >= 16) {
+        if (o.n + 600 > o.cap && !o.reserve(o.n + (size_t(1) << 20))) return PG_NOMEM;
+        b.refill();
+        uint32_t e = hl->packed[b.buf & FM];
+        uint32_t kind = (e >> 8) & 3u;
+        if (kind == 0) {
+            const uint32_t c0 = e >> 16;
+            if (text_only && !is_text(c0)) return PG_NOTTEXT;
+            o.d[o.n++] = (uint16_t)c0;
+            b.drop(e & 15u);
+            e = hl->packed[b.buf & FM];                  // a second literal out of the same refill, more often than not
+            kind = (e >> 8) & 3u;
+            if (kind == 0) {
+                const uint32_t c1 = e >> 16;
+                if (text_only && !is_text(c1)) return PG_NOTTEXT;
+                o.d[o.n++] = (uint16_t)c1;
+                b.drop(e & 15u);
+                continue;
+            }
+            if (kind != 1) { if (kind == 2) { b.drop(e & 15u); return final ? PG_FINAL : PG_OK; } break; }
+            if (b.cnt < 48) b.refill();
+        }
+        else if (kind == 2) { b.drop(e & 15u); return final ? PG_FINAL : PG_OK; }
+        else if (kind == 3) break;
+        // a length, then its distance
+        const uint64_t keep_buf = b.buf; const unsigned keep_cnt = b.cnt; const uint8_t* const keep_p = b.p;
+        b.drop(e & 15u);
+        const uint32_t eb = (e >> 4) & 15u;
+        const uint32_t len = (e >> 16) + (uint32_t)(b.buf & ((1u << eb) - 1u));
+        b.drop(eb);
+        const uint32_t f = hd->packed[b.buf & FM];
+        if (((f >> 8) & 3u) != 1u) { b.buf = keep_buf; b.cnt = keep_cnt; b.p = keep_p; break; }        // (back in front of the length)
+        b.drop(f & 15u);
+        const uint32_t fb = (f >> 4) & 15u;
+        const uint32_t dist = (f >> 16) + (uint32_t)(b.buf & ((1u << fb) - 1u));
+        b.drop(fb);
+        if (dist > (o.n - WIN) + hist) return PG_DATA;
+        uint16_t* dst = o.d + o.n;
+        const uint16_t* src = dst - dist;
+        o.n += len;
+        if (dist >= 8) {                                 // (eight symbols = 16 bytes at a time; may write up to 7 symbols past the end: room is there)
+            for (uint32_t k = 0; k < len; k += 8) memcpy(dst + k, src + k, 16);
+        } else if (dist == 1) {
+            const uint16_t v1 = src[0];
+            for (uint32_t k = 0; k < len; ++k) dst[k] = v1;
+        } else {
+            for (uint32_t k = 0; k < len; ++k) dst[k] = src[k];
+        }
+    }
     for (;;) {
         if (o.n + 260 > o.cap && !o.reserve(o.n + (size_t(1) << 20))) return PG_NOMEM;
         const int s = hl->decode(b);
@@ -385,10 +482,21 @@ struct PGunzipImpl {
         const uint16_t* s = o.d + WIN;
         const uint8_t* w = pc.win.get();
         uint8_t* d = pc.bytes.data();
-        for (size_t i = 0; i < n; ++i) { const uint16_t v = s[i]; d[i] = v < MARK ? (uint8_t)v : w[v - MARK]; }
-        uint32_t c = 0;
-        for (size_t k = 0; k < n; k += size_t(1) << 30) c = (uint32_t)crc32(c, d + k, (uInt)std::min<size_t>(n - k, size_t(1) << 30));
-        pc.crc = c;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {                     // eight symbols at a time while they are plain bytes (nearly always)
+            uint64_t a, b;
+            memcpy(&a, s + i, 8); memcpy(&b, s + i + 4, 8);
+            if (((a | b) & 0xFF00FF00FF00FF00ull) == 0) {
+                a = (a | (a >> 8)) & 0x0000FFFF0000FFFFull; a = (a | (a >> 16)) & 0xFFFFFFFFull;
+                b = (b | (b >> 8)) & 0x0000FFFF0000FFFFull; b = (b | (b >> 16)) & 0xFFFFFFFFull;
+                const uint64_t out = a | b << 32;
+                memcpy(d + i, &out, 8);
+            } else {
+                for (size_t k = i; k < i + 8; ++k) { const uint16_t v = s[k]; d[k] = v < MARK ? (uint8_t)v : w[v - MARK]; }
+            }
+        }
+        for (; i < n; ++i) { const uint16_t v = s[i]; d[i] = v < MARK ? (uint8_t)v : w[v - MARK]; }
+        pc.crc = crc_of(d, n);
         pc.chunk.reset();
         pc.win.reset();
     }
@@ -525,9 +633,7 @@ struct PGunzipImpl {
         const size_t n = seq.n - WIN;
         pc->bytes.resize(n);
         for (size_t i = 0; i < n; ++i) pc->bytes[i] = (uint8_t)seq.d[WIN + i];
-        uint32_t c = 0;
-        for (size_t k = 0; k < n; k += size_t(1) << 30) c = (uint32_t)crc32(c, pc->bytes.data() + k, (uInt)std::min<size_t>(n - k, size_t(1) << 30));
-        pc->crc = c; pc->state = 2;
+        pc->crc = crc_of(pc->bytes.data(), n); pc->state = 2;
         window_take(pc->bytes.data(), n);
         total_out += n;
         cur_bit = b.bit_pos();
