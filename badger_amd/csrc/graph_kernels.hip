@@ -825,7 +825,7 @@ void k_graph_qjoin_w(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t ro
 // letters are deleted from each (two substitutions: delete the two positions; one insertion + one deletion: delete the
 // odd letter of each, then any common letter; the forms through a[:-1] / b[:-1] delete the last letter and one or two
 // more - a[:-1] minus one letter is a minus two).  So: every row emits its <= 120 distinct two-deletion 14-mers as
-// (14-mer, row << 7 | which deletion pair), the entries are sorted by 14-mer, and only rows that meet in a group are
+// (14-mer, row), the entries are sorted by 14-mer, and only rows that meet in a group are
 // verified - by the same dmin and the same S (in closed form) as everywhere else, so the filter stays the reference's.
 // A pair shares several 14-mers; it is reported from exactly one group, named by a rule that looks at the two barcodes only
 // (k_d2_pairs).  A row's entries are made distinct when they are emitted (of equal 14-mers the first deletion pair stays),
@@ -886,6 +886,7 @@ __device__ __forceinline__ bool d2_subseq(uint32_t k, uint32_t b)
 // (about three a row) compare among themselves.
 constexpr uint32_t D2_SLOTS = 1024;
 constexpr uint32_t D2_ECAP = 512;                // staged edges per wave in k_d2_pairs
+constexpr unsigned long long D2_ROUND_ENTRIES = 1500000000ull;      // index entries (estimated at 80 a row) per round of the join
 
 struct D2Row { uint32_t k0, k1; bool keep0, keep1; };
 
@@ -971,8 +972,8 @@ void k_d2_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, ui
         const D2Row o = d2_row(ranks[row], lane, pq0, pq1, s_tab[wv], part, nparts);
         const unsigned long long m0 = __ballot(o.keep0), m1 = __ballot(o.keep1);
         const uint32_t base = offset[row];
-        if (o.keep0) { const uint32_t at = base + lanes_below_u64(m0, lane); keys[at] = o.k0; vals[at] = row << 7 | (uint32_t)lane; }
-        if (o.keep1) { const uint32_t at = base + (uint32_t)__popcll(m0) + lanes_below_u64(m1, lane); keys[at] = o.k1; vals[at] = row << 7 | (uint32_t)(64 + lane); }
+        if (o.keep0) { const uint32_t at = base + lanes_below_u64(m0, lane); keys[at] = o.k0; vals[at] = row; }
+        if (o.keep1) { const uint32_t at = base + (uint32_t)__popcll(m0) + lanes_below_u64(m1, lane); keys[at] = o.k1; vals[at] = row; }
     }
 }
 
@@ -1026,26 +1027,27 @@ void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ 
     __shared__ uint32_t s_incl[4][64], s_val[4][64], s_rank[4][64], s_key[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t ne = 0, qn = 0;
-    // meetings waiting for their verification: a, b, (rule << 7 | a's deletion pair); the queue lives across the windows
+    // meetings waiting for their verification: a, b, (rule << 28 | the group's 14-mer); the queue lives across the windows
     __shared__ uint32_t s_qa[4][128], s_qb[4][128], s_qm[4][128];
     auto verify = [&](uint32_t a, uint32_t b, uint32_t meta, bool act) {
         const uint32_t d = act ? dmin3(a, b) : 99u;
         bool edge = d <= thr;
         if (__ballot(edge)) {
             edge = edge && (int32_t)qgram_S(a, b) >= T;
-            // rule 3, one pair at a time with the deletion pairs spread over the lanes: reported from here iff none of a's
-            // deletion pairs before this entry's leaves a 14-mer that b has, too
-            for (unsigned long long w = __ballot(edge && (meta >> 7) == 2u); w; w &= w - 1ull) {
+            // rule 3, one pair at a time with a's 120 deletion pairs spread over the lanes: the first of them (table order) whose
+            // 14-mer is left in b as well names the reporting group - this one, or another
+            for (unsigned long long w = __ballot(edge && (meta >> 28) == 2u); w; w &= w - 1ull) {
                 const int src = __builtin_ctzll(w);
                 const uint32_t ja = (uint32_t)__builtin_amdgcn_readlane((int)a, src), jb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
-                const uint32_t jt = (uint32_t)__builtin_amdgcn_readlane((int)meta, src) & 127u;
-                bool found = false;
-                for (uint32_t t0 = 0; t0 < jt; t0 += 64u) {
-                    const uint32_t t = t0 + (uint32_t)lane;
-                    const uint32_t pq = d2_table.pq[t < D2_NPAIR ? t : 0];
-                    found = found || (t < jt && d2_subseq(d2_key(ja, pq >> 4, pq & 15u), jb));
-                }
-                if (__ballot(found) && lane == src) edge = false;
+                const uint32_t jk = (uint32_t)__builtin_amdgcn_readlane((int)meta, src) & 0x0FFFFFFFu;
+                const uint32_t pq_lo = d2_table.pq[lane], pq_hi = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
+                const uint32_t k_lo = d2_key(ja, pq_lo >> 4, pq_lo & 15u), k_hi = d2_key(ja, pq_hi >> 4, pq_hi & 15u);
+                const unsigned long long m_lo = __ballot(d2_subseq(k_lo, jb));
+                const unsigned long long m_hi = __ballot(lane < D2_NPAIR - 64 && d2_subseq(k_hi, jb));
+                uint32_t k_first;                                          // (the group's own 14-mer is one of them: m_lo | m_hi != 0)
+                if (m_lo) k_first = (uint32_t)__builtin_amdgcn_readlane((int)k_lo, __builtin_ctzll(m_lo));
+                else k_first = (uint32_t)__builtin_amdgcn_readlane((int)k_hi, m_hi ? __builtin_ctzll(m_hi) : 0);
+                if (k_first != jk && lane == src) edge = false;
             }
         }
         edge_push(edge, a, b, d, stages[wv], ne, lane, out, cap, n_edges);
@@ -1085,7 +1087,7 @@ void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ 
     for (int s = 1; s < 64; s <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, s); if (lane >= s) incl += o; }
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     s_incl[wv][lane] = incl; s_val[wv][lane] = v; s_key[wv][lane] = k;
-    s_rank[wv][lane] = have ? ranks[v >> 7] : 0u;
+    s_rank[wv][lane] = have ? ranks[v] : 0u;
     __builtin_amdgcn_wave_barrier();
     for (uint32_t x0 = 0; x0 < total; x0 += 64u) {
         const uint32_t x = x0 + (uint32_t)lane;
@@ -1096,15 +1098,14 @@ void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ 
         o = act ? o : 0u;
         const uint32_t before = o ? s_incl[wv][o - 1u] : 0u;
         const unsigned long long e2 = wave_base + o + (x - before) + 1ull;
-        uint32_t a = 0, b = 0, t_a = 0, kk = 0;
+        uint32_t a = 0, b = 0, kk = 0;
         bool on = false;
         if (act) {
             const uint32_t v1 = s_val[wv][o], v2 = vals[e2];
-            const uint32_t row_i = v1 >> 7, row_j = v2 >> 7;
+            const uint32_t row_i = v1, row_j = v2;
             const uint32_t rank_i = s_rank[wv][o], rank_j = ranks[row_j];
             const bool lower = row_i < row_j;                      // (a row has one entry per 14-mer: row_i != row_j)
             a = lower ? rank_i : rank_j; b = lower ? rank_j : rank_i;
-            t_a = (lower ? v1 : v2) & 127u;
             kk = s_key[wv][o];
             const uint32_t row_a = lower ? row_i : row_j;
             on = row_a >= row_begin && row_a < row_end;
@@ -1116,7 +1117,7 @@ void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ 
         const unsigned long long mq = __ballot(rep != 0);
         if (rep != 0) {
             const uint32_t at = qn + lanes_below_u64(mq, lane);
-            s_qa[wv][at] = a; s_qb[wv][at] = b; s_qm[wv][at] = (uint32_t)rep << 7 | t_a;
+            s_qa[wv][at] = a; s_qb[wv][at] = b; s_qm[wv][at] = (uint32_t)rep << 28 | kk;
         }
         qn += (uint32_t)__popcll(mq);
         __builtin_amdgcn_wave_barrier();
@@ -1178,7 +1179,8 @@ int bdg_graph_plan(const bdg_ctx* ctx, uint32_t n, uint32_t thr)
 {
     if (ctx->graph_algo) return ctx->graph_algo;
     if (thr == 1) return 2;
-    if (thr >= 2 && n < (1u << 25)) return (thr == 2 && n >= ctx->g_d2_min_rows) ? 5 : 3;
+    if (thr == 2 && n >= ctx->g_d2_min_rows) return 5;                 // (any n: large inputs are taken in rounds)
+    if (thr >= 2 && n < (1u << 25)) return 3;
     return 1;
 }
 
@@ -1200,17 +1202,24 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
     int rc;
     // deletion-variant join: thr <= 2 only (what makes it complete); the automatic choice for thr 2
     const bool d2join = plan == 5;
-    if (ctx->graph_algo == 5 && (thr > 2 || n >= (1u << 25))) return bdg_fail(ctx, BDG_E_ARG, "deletion-variant join needs thr <= 2 and n < 2^25");
+    if (ctx->graph_algo == 5 && thr > 2) return bdg_fail(ctx, BDG_E_ARG, "deletion-variant join needs thr <= 2");
     if (nparts == 0 || part >= nparts) return bdg_fail(ctx, BDG_E_ARG, "part outside [0, nparts)");
     if (d2join) {
         // entries: about 71 per row on random barcodes, 120 at most.  Counted first (pass 1), so that every row knows where
-        // its entries go and the buffers are sized exactly
+        // its entries go and the buffers are sized exactly.  A large input is taken in several rounds, each over its share of
+        // the 14-mer groups (the same cut that gives several GPUs their parts): the index of a round stays below 2^31 entries
+        // (16 bytes each while it is sorted), whatever n is.
         auto* cnt = reinterpret_cast<unsigned long long*>(d_n_edges);
-        {
-            if ((rc = graph_props(ctx))) return rc;
+        if ((rc = graph_props(ctx))) return rc;
+        uint32_t rounds = (uint32_t)(((unsigned long long)n * 80ull / nparts + D2_ROUND_ENTRIES - 1) / D2_ROUND_ENTRIES);
+        if (const char* e = getenv("BADGER_AMD_D2_ROUNDS")) rounds = (uint32_t)std::max(1, atoi(e));      // (for tests)
+        if (rounds < 1) rounds = 1;
+        if ((unsigned long long)nparts * rounds > 0xFFFFFFFFull) return bdg_fail(ctx, BDG_E_ARG, "too many parts");
+        for (uint32_t round = 0; round < rounds; ++round) {
+            const uint32_t sub = part * rounds + round, nsub = nparts * rounds;
             size_t t_scan = 0;
             uint32_t* nul = nullptr;
-            BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, t_scan, nul, nul, (int)(n + 1), st));
+            BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, t_scan, nul, nul, (long long)n + 1, st));
             if ((rc = bdg_reserve(ctx, ctx->g_sig, sizeof(uint32_t) * 2ull * ((size_t)n + 1) + t_scan + 512))) return rc;   // (the sweep's signature buffer is free here)
             auto* count = static_cast<uint32_t*>(ctx->g_sig.p);
             auto* offset = count + n + 1;
@@ -1220,14 +1229,15 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             uint32_t m32 = 0;
             {
                 ScopedKernelTimer tm(ctx, "k_d2_count");
-                hipLaunchKernelGGL(k_d2_count, dim3(grid), dim3(256), 0, st, d_ranks, n, part, nparts, count);
-                BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(scan_temp, t_scan, count, offset, (int)(n + 1), st));
+                hipLaunchKernelGGL(k_d2_count, dim3(grid), dim3(256), 0, st, d_ranks, n, sub, nsub, count);
+                BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(scan_temp, t_scan, count, offset, (long long)n + 1, st));
             }
             BDG_HIP_TRY(ctx, hipMemcpyAsync(&m32, offset + n, 4, hipMemcpyDeviceToHost, st));
             BDG_HIP_TRY(ctx, hipStreamSynchronize(st));                           // (the sort needs the entry count on the host)
             const unsigned long long m = m32;
+            if (m == 0) continue;
             size_t t_sort = 0;
-            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, nul, nul, nul, nul, (long long)(m ? m : 1), 0, 28, st));
+            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, nul, nul, nul, nul, (long long)m, 0, 28, st));
             if ((rc = bdg_reserve(ctx, ctx->g_qj, sizeof(uint32_t) * 4ull * (m + 64) + t_sort + 512))) return rc;
             auto* k_in = static_cast<uint32_t*>(ctx->g_qj.p);
             auto* k_out = k_in + m + 16;
@@ -1236,9 +1246,9 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             void* temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(v_out + m + 16) + 255) & ~uintptr_t(255));
             {
                 ScopedKernelTimer tm(ctx, "k_d2_emit");
-                hipLaunchKernelGGL(k_d2_emit, dim3(grid), dim3(256), 0, st, d_ranks, n, part, nparts, offset, k_in, v_in);
+                hipLaunchKernelGGL(k_d2_emit, dim3(grid), dim3(256), 0, st, d_ranks, n, sub, nsub, offset, k_in, v_in);
             }
-            if (m) {
+            {
                 ScopedKernelTimer tm(ctx, "d2_sort");
                 size_t t = t_sort;
                 BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(temp, t, k_in, k_out, v_in, v_out, (long long)m, 0, 28, st));
@@ -1246,8 +1256,8 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             ScopedKernelTimer tm(ctx, "k_d2_pairs");
             unsigned long long pgrid = (unsigned long long)ctx->g_cus * d2_pairs_blocks_per_cu();
             if (pgrid > (m + 255) / 256) pgrid = (m + 255) / 256;
-            if (m) hipLaunchKernelGGL(k_d2_pairs, dim3((uint32_t)pgrid), dim3(256), 0, st, k_out, v_out, m, d_ranks, row_begin, row_end,
-                                      thr, qgram_T, d_out, cap, cnt);
+            hipLaunchKernelGGL(k_d2_pairs, dim3((uint32_t)pgrid), dim3(256), 0, st, k_out, v_out, m, d_ranks, row_begin, row_end,
+                               thr, qgram_T, d_out, cap, cnt);
             BDG_HIP_TRY(ctx, hipGetLastError());
         }
         return BDG_OK;

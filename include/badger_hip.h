@@ -322,7 +322,8 @@ int  bdg_graph_edges_rows_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n,
  * 2 neighbourhood probes (thr = 1 only), 3 q-gram join (the device form of QGramIndex, index.py:29-35,77-93; any thr),
  * 4 the same with every candidate verified in closed form (the join's fallback for slices its table cannot take; for tests),
  * 5 deletion-variant join (thr <= 2: rows that share a 14-mer left by two deletions meet; same dmin and S tests; work linear
- * in n where the q-gram join's is quadratic; it reads the number of its index entries back, i.e. synchronises once).
+ * in n where the q-gram join's is quadratic; any n - a large input is taken in rounds over shares of the 14-mers; it reads
+ * the number of its index entries back, i.e. synchronises once a round).
  * All give identical edge lists. */
 int  bdg_graph_set_algo(bdg_ctx* ctx, int algo);
 /* One of nparts disjoint shares of the edge list (compare_in_parallel's fan-out, barcode_graph.py:164-189, over GPUs: every

@@ -535,6 +535,34 @@ def test_graph_parts_partition_the_edges(ctx, orc, algo, thr):
     ctx.graph_set_algo(0)
 
 
+def test_graph_deletion_variant_join_in_rounds(ctx, orc, monkeypatch):
+    """a large input is taken in several rounds over shares of the 14-mer groups (the cut that gives GPUs their parts):
+    forced here on small inputs - 1, 3 and 7 rounds, alone and inside 2 parts - the list stays the oracle's"""
+    import torch
+    for ranks in (_observed_barcodes(300, 9000, 37), _low_complexity_barcodes(4000, 44)):
+        n = len(ranks)
+        T = orc.qgram_threshold(2)
+        want = orc.graph_edges(ranks, 2, T, threads=8)
+        d_ranks = torch.from_numpy(ranks.view(np.int32)).cuda()
+        cap = len(want) + 1024
+        d_out = torch.zeros((cap, 3), dtype=torch.int32, device="cuda")
+        d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ctx.graph_set_algo(5)
+        for rounds in ("1", "3", "7"):
+            monkeypatch.setenv("BADGER_AMD_D2_ROUNDS", rounds)
+            for nparts in (1, 2):
+                got = []
+                for part in range(nparts):
+                    ctx.graph_edges_part_dev(d_ranks, n, part, nparts, 2, T, d_out, cap, d_cnt)
+                    ctx.synchronize()
+                    got.append(d_out[:int(d_cnt[0])].cpu().numpy().view(np.uint32).copy())
+                e = np.concatenate(got)
+                e = e[np.lexsort((e[:, 1], e[:, 0]))]
+                assert len(e) == len(want) and (e[:, 0] == want["a"]).all() and (e[:, 1] == want["b"]).all() and (e[:, 2] == want["dist"]).all(), (rounds, nparts)
+        monkeypatch.delenv("BADGER_AMD_D2_ROUNDS")
+        ctx.graph_set_algo(0)
+
+
 def _low_complexity_barcodes(n, seed):
     """16-mers made of short repeats and homopolymer runs with a few edits: six-mers repeat inside a barcode
     (S counts products of multiplicities, index.py:80-93), buckets are very uneven, many pairs have S >= T."""

@@ -48,7 +48,7 @@ def main():
             if ne > cap:
                 raise SystemExit("edge capacity too small at %d rows: %d" % (n, ne))
             e = d_edges[:ne].to(torch.int64) & 0xFFFFFFFF
-            key = (e[:, 0] << 34) | (e[:, 1] << 2) | e[:, 2]
+            key = ((e[:, 0] - (1 << 31)) << 32) | e[:, 1]                 # (a, b) as one signed 64-bit key; the distance follows from the pair
             lists[algo] = torch.sort(key).values
             out["algo%d_ms" % algo] = round(best * 1e3, 2)
             out["edges"] = ne
