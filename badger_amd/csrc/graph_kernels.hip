@@ -877,7 +877,7 @@ __device__ __forceinline__ bool d2_subseq(uint32_t k, uint32_t b)
 // One wave per row at a time (rows interleaved over the resident waves): lane l holds deletion pairs l and 64 + l.
 // A pair is dropped when an earlier one of the row gives the same 14-mer.  Letters inside a run are interchangeable, so only
 // the first letter of a run (or the first two, for two deletions in one run) need to be deleted: that alone removes most
-// repeats and, of equal 14-mers, keeps the earliest pair of the table (which is what k_d2_pairs' rule 3 counts on).  The rest
+// repeats (and, of equal 14-mers, keeps the earliest pair of the table).  The rest
 // is settled exactly through a table of 1024 slots in LDS: a one-to-one mixing of the 28 key bits (multiply, shift-xor,
 // multiply, all mod 2^28) gives 10 bits that name the slot and 18 that are a fingerprint, and the slot takes the minimum of
 // (pair index << 18 | fingerprint).  A lane
@@ -962,7 +962,7 @@ void k_d2_count(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, u
 // pass 2: the entries, a row's side by side
 __global__ __launch_bounds__(256)
 void k_d2_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, uint32_t nparts, const uint32_t* __restrict__ offset,
-               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+               unsigned long long* __restrict__ ent)
 {
     __shared__ uint32_t s_tab[4][D2_SLOTS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -972,8 +972,8 @@ void k_d2_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, ui
         const D2Row o = d2_row(ranks[row], lane, pq0, pq1, s_tab[wv], part, nparts);
         const unsigned long long m0 = __ballot(o.keep0), m1 = __ballot(o.keep1);
         const uint32_t base = offset[row];
-        if (o.keep0) { const uint32_t at = base + lanes_below_u64(m0, lane); keys[at] = o.k0; vals[at] = row; }
-        if (o.keep1) { const uint32_t at = base + (uint32_t)__popcll(m0) + lanes_below_u64(m1, lane); keys[at] = o.k1; vals[at] = row; }
+        if (o.keep0) ent[base + lanes_below_u64(m0, lane)] = (unsigned long long)o.k0 << 32 | row;
+        if (o.keep1) ent[base + (uint32_t)__popcll(m0) + lanes_below_u64(m1, lane)] = (unsigned long long)o.k1 << 32 | row;
     }
 }
 
@@ -985,6 +985,25 @@ __device__ __forceinline__ uint32_t d1_key(uint32_t r, uint32_t p)
     return lo | (hi << (2u * p));
 }
 
+// x[:15] against y without its letter `del`, equal but for one substituted letter at place `sub` of x[:15]?  late: the
+// substitution lies at or behind the deleted letter's place (then y's letter is y[sub + 1]), else in front of it
+__device__ __forceinline__ bool d2_shifted(uint32_t x, uint32_t y, uint32_t& del, uint32_t& sub, bool& late)
+{
+    const uint32_t u = x & 0x3FFFFFFFu;
+    const uint32_t x0 = (u ^ y) & 0x3FFFFFFFu, x1 = (u ^ (y >> 2)) & 0x3FFFFFFFu;
+    const uint32_t nz0 = (x0 | (x0 >> 1)) & 0x15555555u;               // place p: x[p] != y[p]
+    const uint32_t nz1 = (x1 | (x1 >> 1)) & 0x15555555u;               // place p: x[p] != y[p + 1]
+    const uint32_t f0 = nz0 ? (uint32_t)__builtin_ctz(nz0) >> 1 : 15u;
+    const uint32_t behind = nz1 & ~((1u << (2u * f0)) - 1u);
+    if (__popc(behind) == 1) { del = f0; sub = (uint32_t)__builtin_ctz(behind) >> 1; late = true; return true; }
+    if (nz0) {
+        const uint32_t rest = nz0 & (nz0 - 1u);
+        const uint32_t j = rest ? (uint32_t)__builtin_ctz(rest) >> 1 : 15u;
+        if ((nz1 & ~((1u << (2u * j)) - 1u)) == 0u) { del = j; sub = f0; late = false; return true; }
+    }
+    return false;
+}
+
 // Which of the 14-mers a pair shares reports it.  A function of the two barcodes alone (a = the lower row), so that every
 // group the pair meets in decides alike, and always one of the shared 14-mers:
 //   1. at most two differing letters: the 14-mer without them (one differing letter: without it and letter 0, or 1);
@@ -992,8 +1011,11 @@ __device__ __forceinline__ uint32_t d1_key(uint32_t r, uint32_t p)
 //      a[:-1] / b[:-1] alone): that 15-mer without its first letter.  With lcp / lcs the common prefix / suffix of a and b,
 //      i <= j needs i <= lcp, j >= 15 - lcs and a[x + 1] == b[x] for x in [i, j): the narrowest such interval decides;
 //      j < i likewise with the roles swapped;
-//   3. otherwise: the 14-mer of a's first deletion pair (table order) that is left in b as well - found by trying them.
-// Returns 1 / 0 for rules 1 and 2 (k is / is not that 14-mer), 2 when rule 3 has to decide.
+//   3. a[:-1] against b without a letter (or b[:-1] against a without one), equal but for one substituted letter - what is
+//      left of the forms through a[:-1] / b[:-1]: the 14-mer without that letter and the dropped / deleted one;
+//   4. otherwise (not seen on the test data: every edge falls under 1 - 3): the 14-mer of a's first deletion pair (table order)
+//      that is left in b as well - found by trying them.
+// Returns 1 / 0 for rules 1 to 3 (k is / is not that 14-mer), 2 when rule 4 has to decide.
 __device__ __forceinline__ int d2_reports(uint32_t a, uint32_t b, uint32_t k)
 {
     const uint32_t x = a ^ b;                                          // (a != b)
@@ -1010,6 +1032,12 @@ __device__ __forceinline__ int d2_reports(uint32_t a, uint32_t b, uint32_t k)
     const uint32_t span = ((1u << (2u * far)) - 1u) & ~((1u << (2u * near)) - 1u);      // letters near .. far - 1
     if ((((a >> 2) ^ b) & span) == 0u) return (d1_key(a, near) >> 2) == k ? 1 : 0;       // i = near <= j = far
     if ((((b >> 2) ^ a) & span) == 0u) return (d1_key(a, far) >> 2) == k ? 1 : 0;        // j = near < i = far
+    // 3. the forms through a[:-1] / b[:-1] with one more edit: x[:15] equals y without one letter but for one substituted
+    //    letter (the shift of the deleted letter sits either in front of the substitution or behind it): the 14-mer without
+    //    the substituted letter and the dropped last one / the deleted one
+    uint32_t del, sub; bool late;
+    if (d2_shifted(a, b, del, sub, late)) return d2_key(a, sub, 15u) == k ? 1 : 0;
+    if (d2_shifted(b, a, del, sub, late)) return (late ? d2_key(a, del, sub + 1u) : d2_key(a, sub, del)) == k ? 1 : 0;
     return 2;
 }
 
@@ -1017,7 +1045,7 @@ __device__ __forceinline__ int d2_reports(uint32_t a, uint32_t b, uint32_t k)
 // the wave walks the sum of those meetings 64 at a time, whatever the group sizes are (a meeting's owner is found in the
 // running sums), so the verification always runs with full lanes.
 __global__ __launch_bounds__(256)
-void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, unsigned long long m,
+void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m,
                 const uint32_t* __restrict__ ranks, uint32_t row_begin, uint32_t row_end, uint32_t thr, int32_t T,
                 bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges)
 {
@@ -1034,7 +1062,7 @@ void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ 
         bool edge = d <= thr;
         if (__ballot(edge)) {
             edge = edge && (int32_t)qgram_S(a, b) >= T;
-            // rule 3, one pair at a time with a's 120 deletion pairs spread over the lanes: the first of them (table order) whose
+            // rule 4, one pair at a time with a's 120 deletion pairs spread over the lanes: the first of them (table order) whose
             // 14-mer is left in b as well names the reporting group - this one, or another
             for (unsigned long long w = __ballot(edge && (meta >> 28) == 2u); w; w &= w - 1ull) {
                 const int src = __builtin_ctzll(w);
@@ -1059,13 +1087,14 @@ void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ 
     const unsigned long long wave_base = win * 64ull;
     const unsigned long long e = wave_base + (unsigned long long)lane;
     const bool have = e < m;
-    const uint32_t k = have ? keys[e] : 0xFFFFFFFFu;
-    const uint32_t v = have ? vals[e] : 0u;
+    const unsigned long long mine = have ? ent[e] : 0xFFFFFFFF00000000ull;       // 14-mer in the high half, row in the low one
+    const uint32_t k = (uint32_t)(mine >> 32);
+    const uint32_t v = (uint32_t)mine;
     // entries behind this one with the same 14-mer.  Inside the wave's 64 entries that is the distance to the group's last
     // lane (groups are contiguous); only a group that runs past lane 63 looks into memory for its end (a 14-mer has at most
     // 120 * 16 = 1920 parents: fewer than 2048 entries)
     const unsigned long long next_base = wave_base + 64ull;
-    const uint32_t k_after = next_base < m ? keys[next_base] : 0xFFFFFFFEu;           // (matches no key and no padding)
+    const uint32_t k_after = next_base < m ? (uint32_t)(ent[next_base] >> 32) : 0xFFFFFFFEu;           // (matches no key and no padding)
     const uint32_t k_down = (uint32_t)__shfl_down((int)k, 1);
     const uint32_t k_next = lane == 63 ? k_after : k_down;
     const unsigned long long ends = __ballot(!have || k != k_next);                  // lanes that end a group
@@ -1077,7 +1106,7 @@ void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ 
 #pragma unroll
         for (uint32_t s = 1024; s >= 1; s >>= 1) {
             const unsigned long long j = wave_base + 63ull + tail + s;
-            if (j < m && keys[j] == k63) tail += s;
+            if (j < m && (uint32_t)(ent[j] >> 32) == k63) tail += s;
         }
         if (rest == 0ull) L += tail;
     }
@@ -1101,7 +1130,7 @@ void k_d2_pairs(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ 
         uint32_t a = 0, b = 0, kk = 0;
         bool on = false;
         if (act) {
-            const uint32_t v1 = s_val[wv][o], v2 = vals[e2];
+            const uint32_t v1 = s_val[wv][o], v2 = (uint32_t)ent[e2];
             const uint32_t row_i = v1, row_j = v2;
             const uint32_t rank_i = s_rank[wv][o], rank_j = ranks[row_j];
             const bool lower = row_i < row_j;                      // (a row has one entry per 14-mer: row_i != row_j)
@@ -1236,27 +1265,28 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             BDG_HIP_TRY(ctx, hipStreamSynchronize(st));                           // (the sort needs the entry count on the host)
             const unsigned long long m = m32;
             if (m == 0) continue;
+            // an entry is one 64-bit word, 14-mer above row: sorted as keys on bits 32 .. 59 (a fifth faster than 32-bit keys with
+            // 32-bit values beside them, tools/ubench/sort_forms.hip)
             size_t t_sort = 0;
-            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, nul, nul, nul, nul, (long long)m, 0, 28, st));
-            if ((rc = bdg_reserve(ctx, ctx->g_qj, sizeof(uint32_t) * 4ull * (m + 64) + t_sort + 512))) return rc;
-            auto* k_in = static_cast<uint32_t*>(ctx->g_qj.p);
-            auto* k_out = k_in + m + 16;
-            auto* v_in = k_out + m + 16;
-            auto* v_out = v_in + m + 16;
-            void* temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(v_out + m + 16) + 255) & ~uintptr_t(255));
+            unsigned long long* nul64 = nullptr;
+            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, t_sort, nul64, nul64, (long long)m, 32, 60, st));
+            if ((rc = bdg_reserve(ctx, ctx->g_qj, sizeof(unsigned long long) * 2ull * (m + 64) + t_sort + 512))) return rc;
+            auto* e_in = static_cast<unsigned long long*>(ctx->g_qj.p);
+            auto* e_out = e_in + m + 32;
+            void* temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(e_out + m + 32) + 255) & ~uintptr_t(255));
             {
                 ScopedKernelTimer tm(ctx, "k_d2_emit");
-                hipLaunchKernelGGL(k_d2_emit, dim3(grid), dim3(256), 0, st, d_ranks, n, sub, nsub, offset, k_in, v_in);
+                hipLaunchKernelGGL(k_d2_emit, dim3(grid), dim3(256), 0, st, d_ranks, n, sub, nsub, offset, e_in);
             }
             {
                 ScopedKernelTimer tm(ctx, "d2_sort");
                 size_t t = t_sort;
-                BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(temp, t, k_in, k_out, v_in, v_out, (long long)m, 0, 28, st));
+                BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(temp, t, e_in, e_out, (long long)m, 32, 60, st));
             }
             ScopedKernelTimer tm(ctx, "k_d2_pairs");
             unsigned long long pgrid = (unsigned long long)ctx->g_cus * d2_pairs_blocks_per_cu();
             if (pgrid > (m + 255) / 256) pgrid = (m + 255) / 256;
-            hipLaunchKernelGGL(k_d2_pairs, dim3((uint32_t)pgrid), dim3(256), 0, st, k_out, v_out, m, d_ranks, row_begin, row_end,
+            hipLaunchKernelGGL(k_d2_pairs, dim3((uint32_t)pgrid), dim3(256), 0, st, e_out, m, d_ranks, row_begin, row_end,
                                thr, qgram_T, d_out, cap, cnt);
             BDG_HIP_TRY(ctx, hipGetLastError());
         }
