@@ -133,6 +133,7 @@ int bdg_init(int device_id, bdg_ctx** out)
     }
     ctx->stream = ctx->own_stream;
     if (const char* e2 = getenv("BADGER_AMD_D2_MIN_ROWS")) ctx->g_d2_min_rows = (uint32_t)strtoul(e2, nullptr, 10);      // (for measurements)
+    if (const char* e1 = getenv("BADGER_AMD_D1_MIN_ROWS")) ctx->g_d1_min_rows = (uint32_t)strtoul(e1, nullptr, 10);
     *out = ctx;
     return BDG_OK;
 }
@@ -610,7 +611,7 @@ int bdg_nearest16(bdg_ctx* ctx, const uint32_t* q, uint32_t nq, const uint32_t* 
 // ---- graph --------------------------------------------------------------------
 int bdg_graph_set_algo(bdg_ctx* ctx, int algo)
 {
-    if (!ctx || algo < 0 || algo > 5) return BDG_E_ARG;
+    if (!ctx || algo < 0 || algo > 6) return BDG_E_ARG;
     ctx->graph_algo = algo;
     return BDG_OK;
 }
@@ -642,7 +643,7 @@ int bdg_graph_edges_part_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, 
     if (nparts == 0 || part >= nparts) return bdg_fail(ctx, BDG_E_ARG, "part outside [0, nparts)");
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int plan = bdg_graph_plan(ctx, n, thr);
-    if (plan == 5) return bdg_graph_launch(ctx, d_ranks, n, 0u, n, thr, qgram_T, d_out, cap, d_n_edges, part, nparts);
+    if (plan == 5 || plan == 6) return bdg_graph_launch(ctx, d_ranks, n, 0u, n, thr, qgram_T, d_out, cap, d_n_edges, part, nparts);
     // the other paths share by blocks of rows: equal rows where a row's work is constant (neighbourhood probes), equal numbers
     // of (i, j > i) pairs where row i meets what lies behind it (q-gram join, sweep): cuts at n (1 - sqrt(1 - g / nparts))
     auto cut = [&](uint32_t g) -> uint32_t {

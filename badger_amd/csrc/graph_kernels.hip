@@ -1044,6 +1044,58 @@ __device__ __forceinline__ int d2_reports(uint32_t a, uint32_t b, uint32_t k)
 // One wave per 64 consecutive sorted entries.  Lane l's entry meets the L_l entries behind it in its group (same 14-mer);
 // the wave walks the sum of those meetings 64 at a time, whatever the group sizes are (a meeting's owner is found in the
 // running sums), so the verification always runs with full lanes.
+// thr 1: dmin(a, b) <= 1 means one substituted letter, or a without letter i == b without letter j (which covers the forms
+// through a[:-1] / b[:-1]); either way the two share the 15-mer that is left, and the narrowest (i, j) names one of them
+// (for a substitution at s: i = j = s).  1: k is that 15-mer; 0: it is not, or the pair is no edge at all.
+__device__ __forceinline__ int d1_reports(uint32_t a, uint32_t b, uint32_t k)
+{
+    const uint32_t x = a ^ b;                                          // (a != b)
+    const uint32_t nz = (x | (x >> 1)) & 0x55555555u;
+    const uint32_t lcp = (uint32_t)__builtin_ctz(nz) >> 1, lcs = (uint32_t)__builtin_clz(nz) >> 1;
+    const uint32_t far = 15u - lcs, near = lcp < far ? lcp : far;
+    const uint32_t span = ((1u << (2u * far)) - 1u) & ~((1u << (2u * near)) - 1u);
+    if ((((a >> 2) ^ b) & span) == 0u) return d1_key(a, near) == k ? 1 : 0;
+    if ((((b >> 2) ^ a) & span) == 0u) return d1_key(a, far) == k ? 1 : 0;
+    return 0;
+}
+
+// the one-deletion 15-mers of a row: deleting any letter of a run gives the same 15-mer, so the first letter of every run is
+// deleted - exactly the distinct ones (about 12 of 16 on random barcodes).  One thread a row; count, then write.
+__global__ __launch_bounds__(256)
+void k_d1_count(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, uint32_t nparts, uint32_t* __restrict__ count)
+{
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    if (row == 0) count[n] = 0u;
+    if (row >= n) return;
+    const uint32_t r = ranks[row];
+    const uint32_t diff = r ^ (r << 2);
+    const uint32_t first = ((diff | (diff >> 1)) & 0x55555554u) | 1u;
+    uint32_t c = 0;
+    if (nparts == 1u) c = (uint32_t)__popc(first);
+    else for (uint32_t p = 0; p < 16u; ++p) c += ((first >> (2u * p)) & 1u) && d2_part(d1_key(r, p), nparts) == part ? 1u : 0u;
+    count[row] = c;
+}
+__global__ __launch_bounds__(256)
+void k_d1_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, uint32_t nparts, const uint32_t* __restrict__ offset,
+               unsigned long long* __restrict__ ent)
+{
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    if (row >= n) return;
+    const uint32_t r = ranks[row];
+    const uint32_t diff = r ^ (r << 2);
+    const uint32_t first = ((diff | (diff >> 1)) & 0x55555554u) | 1u;
+    uint32_t at = offset[row];
+    for (uint32_t p = 0; p < 16u; ++p) {
+        if (!((first >> (2u * p)) & 1u)) continue;
+        const uint32_t k = d1_key(r, p);
+        if (nparts > 1u && d2_part(k, nparts) != part) continue;
+        ent[at++] = (unsigned long long)k << 32 | row;
+    }
+}
+
+// NDEL = 2: the deletion-variant join of thr 2 (14-mers).  NDEL = 1: the same walk over one-deletion 15-mers for thr 1, where
+// rules 1 and 2 of d1_reports are complete and a meeting they do not name is no edge.
+template <int NDEL>
 __global__ __launch_bounds__(256)
 void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m,
                 const uint32_t* __restrict__ ranks, uint32_t row_begin, uint32_t row_end, uint32_t thr, int32_t T,
@@ -1064,7 +1116,7 @@ void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m
             edge = edge && (int32_t)qgram_S(a, b) >= T;
             // rule 4, one pair at a time with a's 120 deletion pairs spread over the lanes: the first of them (table order) whose
             // 14-mer is left in b as well names the reporting group - this one, or another
-            for (unsigned long long w = __ballot(edge && (meta >> 28) == 2u); w; w &= w - 1ull) {
+            for (unsigned long long w = NDEL == 2 ? __ballot(edge && (meta >> 28) == 2u) : 0ull; w; w &= w - 1ull) {
                 const int src = __builtin_ctzll(w);
                 const uint32_t ja = (uint32_t)__builtin_amdgcn_readlane((int)a, src), jb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
                 const uint32_t jk = (uint32_t)__builtin_amdgcn_readlane((int)meta, src) & 0x0FFFFFFFu;
@@ -1142,11 +1194,11 @@ void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m
         // A pair meets in several groups and is reported from one of them; which one is asked first (a few dozen
         // instructions), and only the meetings that would report go on to the verification (dmin and S, some hundred), 64 at a
         // time out of a queue - on dense data four meetings of five end here
-        const int rep = on ? d2_reports(a, b, kk) : 0;
+        const int rep = on ? (NDEL == 2 ? d2_reports(a, b, kk) : d1_reports(a, b, kk)) : 0;
         const unsigned long long mq = __ballot(rep != 0);
         if (rep != 0) {
             const uint32_t at = qn + lanes_below_u64(mq, lane);
-            s_qa[wv][at] = a; s_qb[wv][at] = b; s_qm[wv][at] = (uint32_t)rep << 28 | kk;
+            s_qa[wv][at] = a; s_qb[wv][at] = b; s_qm[wv][at] = NDEL == 2 ? (uint32_t)rep << 28 | kk : 0u;
         }
         qn += (uint32_t)__popcll(mq);
         __builtin_amdgcn_wave_barrier();
@@ -1203,11 +1255,12 @@ static int graph_props(bdg_ctx* ctx)
     return BDG_OK;
 }
 
-// which path bdg_graph_launch takes: 1 all-pairs sweep, 2 neighbourhood probes, 3 / 4 q-gram join, 5 deletion-variant join
+// which path bdg_graph_launch takes: 1 all-pairs sweep, 2 neighbourhood probes, 3 / 4 q-gram join, 5 / 6 deletion-variant join
+// over 14-mers (thr <= 2) / 15-mers (thr <= 1)
 int bdg_graph_plan(const bdg_ctx* ctx, uint32_t n, uint32_t thr)
 {
     if (ctx->graph_algo) return ctx->graph_algo;
-    if (thr == 1) return 2;
+    if (thr == 1) return n >= ctx->g_d1_min_rows ? 6 : 2;
     if (thr == 2 && n >= ctx->g_d2_min_rows) return 5;                 // (any n: large inputs are taken in rounds)
     if (thr >= 2 && n < (1u << 25)) return 3;
     return 1;
@@ -1230,8 +1283,10 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
     if ((ctx->graph_algo == 3 || ctx->graph_algo == 4) && n >= (1u << 25)) return bdg_fail(ctx, BDG_E_ARG, "q-gram join needs n < 2^25");
     int rc;
     // deletion-variant join: thr <= 2 only (what makes it complete); the automatic choice for thr 2
-    const bool d2join = plan == 5;
+    const bool d2join = plan == 5 || plan == 6;
+    const bool one_deletion = plan == 6;
     if (ctx->graph_algo == 5 && thr > 2) return bdg_fail(ctx, BDG_E_ARG, "deletion-variant join needs thr <= 2");
+    if (ctx->graph_algo == 6 && thr > 1) return bdg_fail(ctx, BDG_E_ARG, "the one-deletion join needs thr <= 1");
     if (nparts == 0 || part >= nparts) return bdg_fail(ctx, BDG_E_ARG, "part outside [0, nparts)");
     if (d2join) {
         // entries: about 71 per row on random barcodes, 120 at most.  Counted first (pass 1), so that every row knows where
@@ -1240,7 +1295,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
         // (16 bytes each while it is sorted), whatever n is.
         auto* cnt = reinterpret_cast<unsigned long long*>(d_n_edges);
         if ((rc = graph_props(ctx))) return rc;
-        uint32_t rounds = (uint32_t)(((unsigned long long)n * 80ull / nparts + D2_ROUND_ENTRIES - 1) / D2_ROUND_ENTRIES);
+        uint32_t rounds = (uint32_t)(((unsigned long long)n * (one_deletion ? 16ull : 80ull) / nparts + D2_ROUND_ENTRIES - 1) / D2_ROUND_ENTRIES);
         if (const char* e = getenv("BADGER_AMD_D2_ROUNDS")) rounds = (uint32_t)std::max(1, atoi(e));      // (for tests)
         if (rounds < 1) rounds = 1;
         if ((unsigned long long)nparts * rounds > 0xFFFFFFFFull) return bdg_fail(ctx, BDG_E_ARG, "too many parts");
@@ -1257,8 +1312,9 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             if (grid > (n + 3u) / 4u) grid = (n + 3u) / 4u;
             uint32_t m32 = 0;
             {
-                ScopedKernelTimer tm(ctx, "k_d2_count");
-                hipLaunchKernelGGL(k_d2_count, dim3(grid), dim3(256), 0, st, d_ranks, n, sub, nsub, count);
+                ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_count" : "k_d2_count");
+                if (one_deletion) hipLaunchKernelGGL(k_d1_count, dim3((n + 255u) / 256u), dim3(256), 0, st, d_ranks, n, sub, nsub, count);
+                else hipLaunchKernelGGL(k_d2_count, dim3(grid), dim3(256), 0, st, d_ranks, n, sub, nsub, count);
                 BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(scan_temp, t_scan, count, offset, (long long)n + 1, st));
             }
             BDG_HIP_TRY(ctx, hipMemcpyAsync(&m32, offset + n, 4, hipMemcpyDeviceToHost, st));
@@ -1269,25 +1325,29 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             // 32-bit values beside them, tools/ubench/sort_forms.hip)
             size_t t_sort = 0;
             unsigned long long* nul64 = nullptr;
-            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, t_sort, nul64, nul64, (long long)m, 32, 60, st));
+            const int key_end = one_deletion ? 62 : 60;                           // (15-mers: 30 bits)
+            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, t_sort, nul64, nul64, (long long)m, 32, key_end, st));
             if ((rc = bdg_reserve(ctx, ctx->g_qj, sizeof(unsigned long long) * 2ull * (m + 64) + t_sort + 512))) return rc;
             auto* e_in = static_cast<unsigned long long*>(ctx->g_qj.p);
             auto* e_out = e_in + m + 32;
             void* temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(e_out + m + 32) + 255) & ~uintptr_t(255));
             {
-                ScopedKernelTimer tm(ctx, "k_d2_emit");
-                hipLaunchKernelGGL(k_d2_emit, dim3(grid), dim3(256), 0, st, d_ranks, n, sub, nsub, offset, e_in);
+                ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_emit" : "k_d2_emit");
+                if (one_deletion) hipLaunchKernelGGL(k_d1_emit, dim3((n + 255u) / 256u), dim3(256), 0, st, d_ranks, n, sub, nsub, offset, e_in);
+                else hipLaunchKernelGGL(k_d2_emit, dim3(grid), dim3(256), 0, st, d_ranks, n, sub, nsub, offset, e_in);
             }
             {
                 ScopedKernelTimer tm(ctx, "d2_sort");
                 size_t t = t_sort;
-                BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(temp, t, e_in, e_out, (long long)m, 32, 60, st));
+                BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(temp, t, e_in, e_out, (long long)m, 32, key_end, st));
             }
-            ScopedKernelTimer tm(ctx, "k_d2_pairs");
+            ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_pairs" : "k_d2_pairs");
             unsigned long long pgrid = (unsigned long long)ctx->g_cus * d2_pairs_blocks_per_cu();
             if (pgrid > (m + 255) / 256) pgrid = (m + 255) / 256;
-            hipLaunchKernelGGL(k_d2_pairs, dim3((uint32_t)pgrid), dim3(256), 0, st, e_out, m, d_ranks, row_begin, row_end,
-                               thr, qgram_T, d_out, cap, cnt);
+            if (one_deletion) hipLaunchKernelGGL(k_d2_pairs<1>, dim3((uint32_t)pgrid), dim3(256), 0, st, e_out, m, d_ranks, row_begin, row_end,
+                                                 thr, qgram_T, d_out, cap, cnt);
+            else hipLaunchKernelGGL(k_d2_pairs<2>, dim3((uint32_t)pgrid), dim3(256), 0, st, e_out, m, d_ranks, row_begin, row_end,
+                                    thr, qgram_T, d_out, cap, cnt);
             BDG_HIP_TRY(ctx, hipGetLastError());
         }
         return BDG_OK;

@@ -221,7 +221,7 @@ def clock_ramp(step, dev, seconds=RAMP_S):
 
 
 def bench_graph(args, rank, world, dev, local_dev):
-    """BASELINE configs 3 / 5 (graph part): K3 over 500K distinct barcodes, thr 1 (neighbourhood probes) or thr 2
+    """BASELINE configs 3 / 5 (graph part): K3 over 500K distinct barcodes, thr 1 (one-deletion join) or thr 2
     (deletion-variant join).  Every rank holds the whole sorted array and builds its share of the edge list, no collective."""
     from oracle import pyoracle as orc
     thr = 1 if args.config == 3 else 2
@@ -229,8 +229,8 @@ def bench_graph(args, rank, world, dev, local_dev):
     wl = synth.make_whitelist(args.whitelist)
     ranks = observed_barcodes(n, wl)
     T = orc.qgram_threshold(thr)
-    # one of `world` shares of the edge list per rank, cut by the library (bdg_graph_edges_part_dev): thr 1 - blocks of equal
-    # rows (a row's work is its 176 probes); thr 2 - shares of the 14-mer groups of the deletion-variant join; the q-gram join
+    # one of `world` shares of the edge list per rank, cut by the library (bdg_graph_edges_part_dev): thr 1 / 2 - shares of the
+    # 15-mer / 14-mer groups of the deletion-variant joins (--graph-algo 2, the probes: blocks of equal rows); the q-gram join
     # (thr >= 3, or --graph-algo 3) - blocks of equal pair counts (a row walks its bucket tails behind it, ~ n - i)
     d_ranks = torch.from_numpy(ranks.view(np.int32)).to(dev)
     cap = 32 * n
@@ -274,6 +274,7 @@ def bench_graph(args, rank, world, dev, local_dev):
         own = {k: v for k, v in per_launch_ms.items() if k.startswith("k_")}          # (d2_sort is hipCUB's radix sort: listed, not analysed)
         dom = max(own, key=own.get)
         path, share = {"k_graph_probe": ("neighbourhood probes", "blocks of equal rows"),
+                       "k_d1_pairs": ("one-deletion join", "shares of the 15-mer groups"),
                        "k_graph_qjoin_w": ("q-gram join", "row blocks of equal pair counts"),
                        "k_graph_qjoin": ("q-gram join, closed form", "row blocks of equal pair counts"),
                        "k_graph_scan": ("all-pairs sweep", "row blocks of equal pair counts")}.get(

@@ -318,19 +318,20 @@ int  bdg_graph_edges_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint
  * lists whose union is the full list. */
 int  bdg_graph_edges_rows_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t row_begin, uint32_t row_end,
                               uint32_t thr, int32_t qgram_T, bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges);
-/* 0 automatic (thr 1: neighbourhood probes; thr 2: deletion-variant join; thr >= 3: q-gram join), 1 all-pairs scan,
+/* 0 automatic (thr 1: neighbourhood probes below 250,000 rows, the one-deletion join from there on; thr 2: deletion-variant
+ * join; thr >= 3: q-gram join), 1 all-pairs scan,
  * 2 neighbourhood probes (thr = 1 only), 3 q-gram join (the device form of QGramIndex, index.py:29-35,77-93; any thr),
  * 4 the same with every candidate verified in closed form (the join's fallback for slices its table cannot take; for tests),
  * 5 deletion-variant join (thr <= 2: rows that share a 14-mer left by two deletions meet; same dmin and S tests; work linear
  * in n where the q-gram join's is quadratic; any n - a large input is taken in rounds over shares of the 14-mers; it reads
- * the number of its index entries back, i.e. synchronises once a round).
- * All give identical edge lists. */
+ * the number of its index entries back, i.e. synchronises once a round), 6 the same over the 15-mers left by one deletion
+ * (thr <= 1).  All give identical edge lists. */
 int  bdg_graph_set_algo(bdg_ctx* ctx, int algo);
 /* One of nparts disjoint shares of the edge list (compare_in_parallel's fan-out, barcode_graph.py:164-189, over GPUs: every
  * device holds the whole sorted array and calls this with its own part; the union over the parts is the list of
  * bdg_graph_edges_dev).  Which edges a part holds is the library's choice, made so that the parts cost the same: blocks of
  * rows for the paths that work row by row (equal rows for the probes, equal pair counts for the q-gram join and the scan:
- * what bdg_graph_edges_rows_dev takes explicitly), shares of the 14-mer groups for the deletion-variant join. */
+ * what bdg_graph_edges_rows_dev takes explicitly), shares of the 14-mer / 15-mer groups for the deletion-variant joins. */
 int  bdg_graph_edges_part_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t part, uint32_t nparts,
                               uint32_t thr, int32_t qgram_T, bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges);
 /* Distinct-barcode counting of a batch on the device (BarcodeGraph.index_bc_single_thread,

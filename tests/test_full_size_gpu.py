@@ -172,6 +172,25 @@ def test_config3_graph_probe_equals_scan_and_oracle_rows(world):
     # and the whole list against the oracle's bucket method on the same 500,000 rows
     want, _, _ = orc.graph_edges_sampled(ranks, 1, 1, 5, threads=16, cap=len(e_probe) + 1)
     assert len(want) == len(e_probe) and (want == e_probe).all()
+    # the one-deletion join (what thr 1 runs on at this size) gives the same list, as a whole and in 8 shares
+    for algo in (6, 0):
+        ctx.graph_set_algo(algo)
+        e_join = ctx.graph_edges(ranks, 1, 5)
+        assert len(e_join) == len(want) and (e_join == want).all(), algo
+    import torch
+    d_ranks = torch.from_numpy(ranks.view(np.int32)).cuda()
+    cap = len(want) + 1024
+    d_out = torch.zeros((cap, 3), dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    parts = []
+    for part in range(8):
+        ctx.graph_edges_part_dev(d_ranks, len(ranks), part, 8, 1, 5, d_out, cap, d_cnt)
+        torch.cuda.synchronize()
+        parts.append(d_out[:int(d_cnt[0])].cpu().numpy().view(np.uint32).copy())
+    assert max(len(x) for x in parts) < 1.2 * min(len(x) for x in parts)
+    e = np.concatenate(parts)
+    e = e[np.lexsort((e[:, 1], e[:, 0]))]
+    assert len(e) == len(want) and (e[:, 0] == want["a"]).all() and (e[:, 1] == want["b"]).all() and (e[:, 2] == want["dist"]).all()
 
 
 def test_config2_distinct_on_device_matches_host_counting(world):

@@ -420,12 +420,12 @@ def _ranks_of(barcodes):
     return np.unique(np.array(out, dtype=np.uint32))
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4, 5, 6])
 def test_graph_golden(ctx, golden_dir, algo):
     g = json.load(open(os.path.join(golden_dir, "graph.json")))
     for key in ("c1_thr1", "c1_thr2", "cells60_thr1", "cells60_thr2"):
         thr = int(key[-1])
-        if algo == 2 and thr != 1:
+        if algo in (2, 6) and thr != 1:
             continue
         ctx.graph_set_algo(algo)
         case = g[key]
@@ -453,7 +453,7 @@ def _observed_barcodes(n_cells, n_obs, seed):
     return np.unique(out.astype(np.uint32))
 
 
-@pytest.mark.parametrize("algo,thr", [(1, 1), (2, 1), (1, 2), (1, 3), (3, 1), (3, 2), (3, 3), (4, 1), (4, 2), (0, 2), (0, 3), (5, 1), (5, 2)])
+@pytest.mark.parametrize("algo,thr", [(1, 1), (2, 1), (1, 2), (1, 3), (3, 1), (3, 2), (3, 3), (4, 1), (4, 2), (0, 2), (0, 3), (5, 1), (5, 2), (6, 1)])
 def test_graph_vs_oracle(ctx, orc, algo, thr):
     ranks = _observed_barcodes(300, 12000, 31)
     ctx.graph_set_algo(algo)
@@ -501,7 +501,7 @@ def test_graph_row_blocks_partition_the_edges(ctx, orc, algo, thr):
     ctx.graph_set_algo(0)
 
 
-@pytest.mark.parametrize("algo,thr", [(0, 1), (0, 2), (0, 3), (3, 2), (5, 2), (5, 1), (1, 2)])
+@pytest.mark.parametrize("algo,thr", [(0, 1), (0, 2), (0, 3), (3, 2), (5, 2), (5, 1), (1, 2), (6, 1)])
 def test_graph_parts_partition_the_edges(ctx, orc, algo, thr):
     """bdg_graph_edges_part_dev: the nparts shares of any cut are disjoint and their union is the oracle's list, whichever
     path serves the threshold (row blocks for the probes / the q-gram join / the sweep, shares of the 14-mer groups for the
@@ -587,7 +587,7 @@ def test_graph_qjoin_low_complexity(ctx, orc, thr):
     T = orc.qgram_threshold(thr)
     w = orc.graph_edges(ranks, thr, T, threads=8)
     assert len(w) > 1000
-    for algo in (1, 3, 4) + ((5,) if thr <= 2 else ()):      # (5: the deletion-variant join; repeats make a row's 14-mers collide)
+    for algo in (1, 3, 4) + ((5,) if thr <= 2 else ()) + ((6,) if thr == 1 else ()):      # (5 / 6: the deletion-variant joins; repeats make a row's 14-mers collide)
         ctx.graph_set_algo(algo)
         e = ctx.graph_edges(ranks, thr, T)
         assert len(e) == len(w) and (e == w).all(), algo
@@ -595,6 +595,10 @@ def test_graph_qjoin_low_complexity(ctx, orc, thr):
         ctx.graph_set_algo(5)
         with pytest.raises(_native.BadgerHipError):
             ctx.graph_edges(ranks, thr, T)                     # complete for thr <= 2 only
+    if thr >= 2:
+        ctx.graph_set_algo(6)
+        with pytest.raises(_native.BadgerHipError):
+            ctx.graph_edges(ranks, thr, T)                     # one deletion: thr <= 1 only
     ctx.graph_set_algo(0)
 
 

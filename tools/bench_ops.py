@@ -27,7 +27,7 @@ def main():
     cap = 64 * len(ranks)
     d_edges = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
     d_n = torch.zeros(1, dtype=torch.int64, device=dev)
-    for algo, thr, n in ((2, 1, 500000), (3, 1, 500000), (5, 1, 500000), (1, 1, 500000), (5, 2, 500000), (3, 2, 500000), (1, 2, 500000), (3, 3, 500000)):
+    for algo, thr, n in ((2, 1, 500000), (6, 1, 500000), (3, 1, 500000), (5, 1, 500000), (1, 1, 500000), (5, 2, 500000), (3, 2, 500000), (1, 2, 500000), (3, 3, 500000)):
         sub = d_ranks[:n].contiguous() if n == len(ranks) else torch.from_numpy(np.sort(ranks[:n]).astype(np.int64)).to(dev).to(torch.int32)
         T = orc.qgram_threshold(thr)
         ctx.graph_set_algo(algo)
@@ -55,7 +55,7 @@ def main():
             # (thr 1) every ball member present in the set
             for b, dd in mine:
                 ok &= orc.dmin3(int(a), b) == dd and orc.qgram_S(int(a), b) >= T
-        print(json.dumps({"op": "graph_edges", "algo": {1: "scan", 2: "probe", 3: "qjoin", 5: "del2 join"}[algo], "thr": thr, "n": n, "edges": ne, "ms": round(ms, 3),
+        print(json.dumps({"op": "graph_edges", "algo": {1: "scan", 2: "probe", 3: "qjoin", 5: "del2 join", 6: "del1 join"}[algo], "thr": thr, "n": n, "edges": ne, "ms": round(ms, 3),
                           "rows_per_s": n / ms * 1e3, "pair_evals_per_s": n * (n - 1) / 2 / ms * 1e3 if algo == 1 else None,
                           "alg_bytes": 4 * n + 12 * ne, "checks_ok": ok}))
     ctx.graph_set_algo(0)
