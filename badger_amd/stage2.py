@@ -149,8 +149,8 @@ class Stage2:
         rows = d_rows.to_host()
         for d in (d_edges, d_tot):
             d.free()
-        self.ea = rows[0, :tot].astype(np.intp)
-        self.eb = rows[1, :tot].astype(np.intp)
+        self.ea = rows[0, :tot]                                # (positions as uint32: numpy indexes with them as they are; at 50 M edges
+        self.eb = rows[1, :tot]                                #  the two conversions to intp cost more than the edge build)
         # the positions and the distinct barcodes stay on the device: the clustering levels and the per-read assignment run there
         self._dev = {"ctx": ctx, "rows": d_rows, "m": tot, "uniq": d_uniq}
 
@@ -224,8 +224,8 @@ class Stage2:
             self.owner = d_owner.to_host(nu).astype(np.int64) if nu else owner
             d_owner.free()
             return
-        u = np.concatenate([self.ea, self.eb])
-        v = np.concatenate([self.eb, self.ea])                            # every edge in both directions: u expands, v is reached
+        u = np.concatenate([self.ea, self.eb]).astype(np.intp)
+        v = np.concatenate([self.eb, self.ea]).astype(np.intp)            # every edge in both directions: u expands, v is reached
         for level in (1, 2):
             print(level)                                                  # the reference prints the level number (:289)
             if level == 1:
