@@ -107,8 +107,10 @@ def graph_row_blocks(n, world, balance="rows"):
 
 
 def graph_balance(thr):
-    """how graph rows are cut into per-GPU blocks: thr 1 runs the neighbourhood probes, the same 176 look-ups for every
-    row ("rows"); thr >= 2 runs the q-gram join, where row i walks its bucket tails BEHIND i, i.e. work ~ n - i ("pairs")"""
+    """how graph ROWS are cut into per-GPU blocks by the paths that work row by row (bdg_graph_edges_rows_dev): the
+    neighbourhood probes of thr 1 do the same 176 look-ups for every row ("rows"); the q-gram join and the sweep (thr >= 2 when
+    forced, thr >= 3 by default) let row i walk what lies BEHIND it, i.e. work ~ n - i ("pairs").  The deletion-variant joins
+    that serve thr 1 / 2 by default are cut by 14- / 15-mer groups instead: bdg_graph_edges_part_dev does either."""
     return "rows" if thr <= 1 else "pairs"
 
 
