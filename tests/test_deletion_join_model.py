@@ -1,0 +1,172 @@
+"""The arithmetic of the deletion-variant joins (csrc/graph_kernels.hip: d2_key, d2_subseq, the run rule of the index
+passes, d2_reports / d1_reports) restated in Python and checked on the CPU: every pair with dmin <= thr shares a group,
+and the reporting rule names exactly one of the groups a pair shares - so the model's edge list is the oracle's, no edge
+missing and none twice.  The kernels themselves are compared with the oracle on the GPU (tests/test_hip_parity.py); this
+file pins the reasoning they rest on."""
+import collections
+
+import numpy as np
+
+from badger_amd import synth
+from oracle import pyoracle as orc
+
+PQ = [(p, q) for p in range(16) for q in range(p + 1, 16)]
+M32 = 0xFFFFFFFF
+
+
+def ctz(x):
+    return (x & -x).bit_length() - 1
+
+
+def d1_key(r, p):
+    return ((r & ((1 << (2 * p)) - 1)) | ((r >> (2 * p + 2)) << (2 * p))) & M32
+
+
+def d2_key(r, p, q):
+    lo = r & ((1 << (2 * p)) - 1)
+    mid = (r >> (2 * p + 2)) & ((1 << (2 * (q - p - 1))) - 1)
+    return (lo | (mid << (2 * p)) | ((r >> (2 * q + 2)) << (2 * q - 2))) & M32
+
+
+def d2_subseq(k, b):
+    """is the 14-mer k what is left of the 16-mer b when two letters are deleted (greedy: delete at the first mismatch)"""
+    l1 = ctz((k ^ b) | (1 << 28)) >> 1
+    k1, m1, b1 = k >> (2 * l1), 14 - l1, b >> (2 * l1 + 2)
+    l2 = ctz(((k1 ^ b1) & ((1 << (2 * m1)) - 1)) | (1 << (2 * m1))) >> 1
+    k2, m2, b2 = k1 >> (2 * l2), m1 - l2, b1 >> (2 * l2 + 2)
+    return ((k2 ^ b2) & ((1 << (2 * m2)) - 1)) == 0
+
+
+def first_of_runs(r):
+    d = (r ^ (r << 2)) & M32
+    return ((d | (d >> 1)) & 0x55555554) | 1
+
+
+def entries2(r):
+    """distinct two-deletion 14-mers of r: first letters of runs only, then exact"""
+    first, seen = first_of_runs(r), set()
+    for p, q in PQ:
+        if (first >> (2 * p)) & 1 and ((first >> (2 * q)) & 1 or p + 1 == q):
+            seen.add(d2_key(r, p, q))
+    return seen
+
+
+def entries1(r):
+    first = first_of_runs(r)
+    return [d1_key(r, p) for p in range(16) if (first >> (2 * p)) & 1]
+
+
+def prefix_suffix(a, b):
+    x = a ^ b
+    nz = (x | (x >> 1)) & 0x55555555
+    return bin(nz).count("1"), ctz(nz) >> 1, (32 - nz.bit_length()) >> 1
+
+
+def one_indel(a, b):
+    """a without letter i == b without letter j: (i,) of a, by the narrowest interval (d2_reports rule 2)"""
+    _, lcp, lcs = prefix_suffix(a, b)
+    far = 15 - lcs
+    near = min(lcp, far)
+    span = ((1 << (2 * far)) - 1) & ~((1 << (2 * near)) - 1)
+    if (((a >> 2) ^ b) & span) == 0:
+        return near
+    if (((b >> 2) ^ a) & span) == 0:
+        return far
+    return None
+
+
+def shifted(x, y):
+    """x[:15] against y without a letter, one substitution (d2_shifted): (deleted place of y, substituted place of x[:15], late)"""
+    u = x & ((1 << 30) - 1)
+    x0, x1 = (u ^ y) & ((1 << 30) - 1), (u ^ (y >> 2)) & ((1 << 30) - 1)
+    nz0, nz1 = (x0 | (x0 >> 1)) & 0x15555555, (x1 | (x1 >> 1)) & 0x15555555
+    f0 = (ctz(nz0) >> 1) if nz0 else 15
+    behind = nz1 & ~((1 << (2 * f0)) - 1)
+    if bin(behind).count("1") == 1:
+        return f0, ctz(behind) >> 1, True
+    if nz0:
+        rest = nz0 & (nz0 - 1)
+        j = (ctz(rest) >> 1) if rest else 15
+        if (nz1 & ~((1 << (2 * j)) - 1)) == 0:
+            return j, f0, False
+    return None
+
+
+def reports2(a, b, k, used):
+    h, lcp, lcs = prefix_suffix(a, b)
+    if h <= 2:
+        used["letters"] += 1
+        s1, s2 = lcp, (15 - lcs) if h == 2 else (1 if lcp == 0 else 0)
+        return d2_key(a, min(s1, s2), max(s1, s2)) == k
+    i = one_indel(a, b)
+    if i is not None:
+        used["indel"] += 1
+        return (d1_key(a, i) >> 2) == k
+    r = shifted(a, b)
+    if r:
+        used["shift"] += 1
+        return d2_key(a, r[1], 15) == k
+    r = shifted(b, a)
+    if r:
+        used["shift"] += 1
+        dl, sb, late = r
+        return (d2_key(a, dl, sb + 1) if late else d2_key(a, sb, dl)) == k
+    used["trial"] += 1
+    for p, q in PQ:
+        kt = d2_key(a, p, q)
+        if d2_subseq(kt, b):
+            return kt == k
+    return False
+
+
+def reports1(a, b, k):
+    i = one_indel(a, b)
+    return i is not None and d1_key(a, i) == k
+
+
+def test_keys_subsequences_and_the_run_rule():
+    rng = np.random.default_rng(5)
+    for _ in range(1500):
+        r = int(rng.integers(0, 1 << 32))
+        s = synth.rank_to_str(r)
+        p, q = PQ[int(rng.integers(0, 120))]
+        assert synth.rank_to_str(d2_key(r, p, q))[:14] == s[:p] + s[p + 1:q] + s[q + 1:] and d2_key(r, p, q) >> 28 == 0
+        assert synth.rank_to_str(d1_key(r, p))[:15] == s[:p] + s[p + 1:]
+        every2 = {s[:a] + s[a + 1:c] + s[c + 1:] for a, c in PQ}
+        assert {synth.rank_to_str(k)[:14] for k in entries2(r)} == every2
+        assert sorted(synth.rank_to_str(k)[:15] for k in entries1(r)) == sorted({s[:a] + s[a + 1:] for a in range(16)})
+        b = int(rng.integers(0, 1 << 32)) if rng.random() < 0.5 else r ^ (int(rng.integers(1, 4)) << (2 * int(rng.integers(0, 16))))
+        k = d2_key(r, p, q)
+        sb = synth.rank_to_str(b)
+        assert d2_subseq(k, b) == (synth.rank_to_str(k)[:14] in {sb[:a] + sb[a + 1:c] + sb[c + 1:] for a, c in PQ})
+
+
+def _sets():
+    from test_hip_parity import _low_complexity_barcodes, _observed_barcodes
+    return {"observed": np.sort(_observed_barcodes(40, 900, 31)), "low complexity": np.sort(_low_complexity_barcodes(700, 41))}
+
+
+def test_every_edge_from_exactly_one_group():
+    for name, ranks in _sets().items():
+        for thr, entries, reports in ((2, entries2, None), (1, entries1, reports1)):
+            T = orc.qgram_threshold(thr)
+            want = [(int(e["a"]), int(e["b"]), int(e["dist"])) for e in orc.graph_edges(ranks, thr, T, threads=4)]
+            groups = collections.defaultdict(list)
+            for i, r in enumerate(ranks):
+                for k in entries(int(r)):
+                    groups[k].append(i)
+            used = collections.Counter()
+            got = []
+            for k, g in groups.items():
+                assert len(set(g)) == len(g)                          # a row meets a group once
+                for x in range(len(g)):
+                    for y in range(x + 1, len(g)):
+                        a, b = int(ranks[min(g[x], g[y])]), int(ranks[max(g[x], g[y])])
+                        ok = reports2(a, b, k, used) if thr == 2 else reports(a, b, k)
+                        if ok:
+                            d = orc.dmin3(a, b)
+                            if d <= thr and orc.qgram_S(a, b) >= T:
+                                got.append((a, b, d))
+            assert sorted(got) == want and len(want) > 300, (name, thr)
+            if thr == 2:
+                assert used["letters"] and used["indel"] and used["shift"] and used["trial"] <= len(want), (name, dict(used))
