@@ -458,7 +458,7 @@ int bdg_import_stage1_tsv(const char* path, uint32_t bc_len, bdg_idstore* ids, u
         uint64_t lines = 0, bad = 0;                     // lines seen; 1-based line (inside the range) of the first bad letter
     };
     const size_t body_bytes = (size_t)(end - body);
-    unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));       // (12.5 M rows: 0.45 / 0.17 / 0.12 s with 4 / 16 / 32 threads)
     if (const char* e = getenv("BADGER_AMD_IMPORT_THREADS")) nt = (unsigned)std::max(1, atoi(e));
     nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, body_bytes >> 20));        // a megabyte per thread at least
     std::vector<Part> parts(nt);

@@ -1,0 +1,13 @@
+import sys, time, os
+sys.path.insert(0, "/root/repo")
+from badger_amd import _native
+_native.PRELOAD_TORCH = False
+_native.load()
+p = sys.argv[1]
+for th in ("4", "8", "16", "32"):
+    os.environ["BADGER_AMD_IMPORT_THREADS"] = th
+    best = 9
+    for rep in range(3):
+        t0 = time.perf_counter(); ids, r, u = _native.import_stage1_tsv(p, 16); dt = time.perf_counter() - t0
+        best = min(best, dt); del ids, r, u
+    print("threads", th, round(best, 3), "s")
