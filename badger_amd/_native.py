@@ -36,7 +36,7 @@ EXPORTS = [
     "bdg_extract_set_strand_rule",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo", "bdg_nearest16_index_bytes",
     "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_edges_part_dev", "bdg_graph_set_algo", "bdg_distinct_dev", "bdg_rows_of_dev",
-    "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host", "bdg_keep_observed",
+    "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host", "bdg_keep_observed", "bdg_touched_count_dev",
     "bdg_ingest_open", "bdg_ingest_open_mt", "bdg_ingest_open_ex", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error",
     "bdg_ingest_reads", "bdg_ingest_close", "bdg_format_rows", "bdg_stage1_run",
     "bdg_cluster_dev", "bdg_assign_reads_dev", "bdg_idstore_new", "bdg_idstore_free", "bdg_idstore_count", "bdg_idstore_append",
@@ -146,6 +146,7 @@ def load():
     L.bdg_kept_records.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.bdg_kept_records_to_host.argtypes = [vp, vp, u64]
     L.bdg_keep_observed.argtypes = [vp, vp, vp, u64]
+    L.bdg_touched_count_dev.argtypes = [vp, vp, vp, u64, u32, vp, u32, C.POINTER(u64)]
     L.bdg_ingest_open.argtypes = [C.c_char_p, u32, u32, C.c_int, C.POINTER(vp)]
     L.bdg_ingest_open_mt.argtypes = [C.c_char_p, u32, u32, C.c_int, u32, C.POINTER(vp)]
     L.bdg_ingest_open_ex.argtypes = [C.c_char_p, C.POINTER(IngestOpts), C.POINTER(vp)]
@@ -374,6 +375,13 @@ class Context:
     def rows_of_dev(self, d_sorted, n, d_values, m, stride_words, d_rows, value_offset_words=0):
         """d_rows[i] = position of d_values[value_offset_words + i * stride_words] in the ascending d_sorted[0..n), NONE if absent"""
         self._check(self.lib.bdg_rows_of_dev(self.h, _ptr(d_sorted), n, _ptr(d_values, 4 * value_offset_words), m, stride_words, _ptr(d_rows)))
+
+    def touched_count_dev(self, d_ea, d_eb, m, nu, d_extra, n_extra):
+        """how many of nu barcodes appear in the m edges (positions) or in d_extra (bdg_touched_count_dev)"""
+        out = C.c_uint64(0)
+        self._check(self.lib.bdg_touched_count_dev(self.h, _ptr(d_ea) if m else None, _ptr(d_eb) if m else None, m, nu,
+                                                   _ptr(d_extra) if n_extra else None, n_extra, C.byref(out)))
+        return int(out.value)
 
     def cluster_dev(self, d_ea, d_eb, m, nu, d_owner):
         """the two clustering levels over m edges given as positions in the distinct array (bdg_cluster_dev)"""

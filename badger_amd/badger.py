@@ -168,9 +168,10 @@ def main(args):
     logger.info("Clustering done")
     st2.output_file_from_device(read_ids, from_device, args.output, args.high_sens)
     from_device.extract_keep_records(False)
+    disconnected = st2.disconnected()  # (counted where the edges are, before they are given back)
     st2.release_device()
     mark("output")
-    print(st2.disconnected())          # "disconnected" count (reference :131-132)
+    print(disconnected)                # "disconnected" count (reference :131-132)
     timing = os.environ.get("BADGER_AMD_STAGE2_TIMING")
     if timing:                                   # where the run's time went (tools/stage2_throughput.py reads it)
         import json

@@ -24,6 +24,7 @@ int bdg_records_of_observed_launch(bdg_ctx*, const uint32_t*, const uint8_t*, ui
 int bdg_rows_of_launch(bdg_ctx*, const uint32_t*, uint32_t, const uint32_t*, uint64_t, uint32_t, uint32_t*);
 int bdg_cluster_launch(bdg_ctx*, const uint32_t*, const uint32_t*, uint64_t, uint32_t, int32_t*);
 int bdg_assign_reads_launch(bdg_ctx*, const bdg_extract_rec*, uint64_t, const uint32_t*, uint32_t, const uint32_t*, const uint8_t*, uint32_t*, uint8_t*);
+int bdg_touched_count_launch(bdg_ctx*, const uint32_t*, const uint32_t*, uint64_t, uint32_t, const uint32_t*, uint32_t, uint64_t*);
 
 static thread_local std::string g_err_noctx;
 
@@ -731,6 +732,15 @@ int bdg_assign_reads_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint64_t n
     if (n && (!d_recs || !d_out_rank || !d_out_has || (nu && (!d_uniq || !d_assigned || !d_has)))) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return bdg_assign_reads_launch(ctx, d_recs, n, d_uniq, nu, d_assigned, d_has, d_out_rank, d_out_has);
+}
+
+int bdg_touched_count_dev(bdg_ctx* ctx, const uint32_t* d_ea, const uint32_t* d_eb, uint64_t m, uint32_t nu,
+                          const uint32_t* d_extra, uint32_t n_extra, uint64_t* count)
+{
+    if (!ctx) return BDG_E_ARG;
+    if (!count || (m && (!d_ea || !d_eb)) || (n_extra && !d_extra)) return bdg_fail(ctx, BDG_E_ARG, "null pointer");
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return bdg_touched_count_launch(ctx, d_ea, d_eb, m, nu, d_extra, n_extra, count);
 }
 
 }  // extern "C"

@@ -236,6 +236,54 @@ int bdg_cluster_launch(bdg_ctx* ctx, const uint32_t* d_ea, const uint32_t* d_eb,
     return BDG_OK;
 }
 
+// how many of the nu distinct barcodes have an edge or are listed in `extra` (the centres that were observed): what the
+// reference's `len(self.edges)` counts (badger.py:131-132), without the edge positions leaving the device
+namespace {
+__global__ __launch_bounds__(256)
+void k_touch(const uint32_t* __restrict__ ea, const uint32_t* __restrict__ eb, uint64_t m, const uint32_t* __restrict__ extra, uint32_t n_extra,
+             uint32_t nu, uint8_t* __restrict__ flags)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256ull + threadIdx.x;
+    if (i < m) { const uint32_t a = ea[i], b = eb[i]; if (a < nu) flags[a] = 1; if (b < nu) flags[b] = 1; }
+    if (i < n_extra) { const uint32_t c = extra[i]; if (c < nu) flags[c] = 1; }
+}
+__global__ __launch_bounds__(256)
+void k_count_flags(const uint8_t* __restrict__ flags, uint32_t nu, unsigned long long* __restrict__ total)
+{
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256ull + threadIdx.x; i < nu; i += (uint64_t)gridDim.x * 256ull) c += flags[i] ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, (unsigned long long)c);
+}
+}  // namespace
+
+int bdg_touched_count_launch(bdg_ctx* ctx, const uint32_t* d_ea, const uint32_t* d_eb, uint64_t m, uint32_t nu,
+                             const uint32_t* d_extra, uint32_t n_extra, uint64_t* count)
+{
+    *count = 0;
+    if (nu == 0) return BDG_OK;
+    int rc;
+    if ((rc = bdg_reserve(ctx, ctx->g_tmp1, (size_t)nu + 64))) return rc;
+    auto* total = static_cast<unsigned long long*>(ctx->g_tmp1.p);
+    auto* flags = reinterpret_cast<uint8_t*>(total + 1);
+    hipStream_t st = ctx->stream;
+    BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->g_tmp1.p, 0, (size_t)nu + 8, st));
+    const uint64_t work = m > n_extra ? m : n_extra;
+    {
+        ScopedKernelTimer tm(ctx, "k_touch");
+        if (work) hipLaunchKernelGGL(k_touch, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, d_ea, d_eb, m, d_extra, n_extra, nu, flags);
+        unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)nu + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_count_flags, dim3(grid), dim3(256), 0, st, flags, nu, total);
+    }
+    BDG_HIP_TRY(ctx, hipGetLastError());
+    unsigned long long h = 0;
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(&h, total, 8, hipMemcpyDeviceToHost, st));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *count = h;
+    return BDG_OK;
+}
+
 int bdg_assign_reads_launch(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint64_t n, const uint32_t* d_uniq, uint32_t nu,
                             const uint32_t* d_assigned, const uint8_t* d_has, uint32_t* d_out_rank, uint8_t* d_out_has)
 {

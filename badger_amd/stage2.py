@@ -67,12 +67,40 @@ class Stage2:
         self.uniq = np.zeros(0, np.uint32)       # distinct barcodes, ascending
         self.count = np.zeros(0, np.int64)
         self.first = np.zeros(0, np.int64)       # position of the first occurrence among the counted barcodes
-        self.ea = self.eb = np.zeros(0, np.intp)  # edges as indices into uniq
+        self._ea = self._eb = np.zeros(0, np.uint32)  # edges as indices into uniq (on the host only if something asks for them)
         self.owner = np.zeros(0, np.int64)       # per distinct barcode: index of its centre, -1 conflict, -2 unclustered
         self.centers = []
 
     def _ctx(self):
         return _native.default_context(self.device)
+
+    # the edges as positions in uniq.  After build_edges() they live on the device (self._dev); the host copy is made when
+    # something reads it (the numpy clustering, tests) - the command line never does.
+    def _edges_to_host(self):
+        dev = getattr(self, "_dev", None)
+        if self._ea is None:
+            if dev is None:
+                raise RuntimeError("the edges went back with the device buffers (release_device) before anything read them")
+            rows = dev["rows"].to_host()
+            self._ea, self._eb = rows[0, :dev["m"]], rows[1, :dev["m"]]
+
+    @property
+    def ea(self):
+        self._edges_to_host()
+        return self._ea
+
+    @ea.setter
+    def ea(self, v):
+        self._ea = v
+
+    @property
+    def eb(self):
+        self._edges_to_host()
+        return self._eb
+
+    @eb.setter
+    def eb(self, v):
+        self._eb = v
 
     # ------------------------------------------------------------------ counting
     def count_host(self, obs_rank, usable):
@@ -129,7 +157,7 @@ class Stage2:
         nu = len(self.uniq)
         T = qgram_threshold(self.threshold, 16)
         if nu < 2:
-            self.ea = self.eb = np.zeros(0, np.intp)
+            self._ea = self._eb = np.zeros(0, np.uint32)
             return
         ctx = ctx or self._ctx()
         d_uniq = self._d_uniq if on_device else _native.DeviceArray.from_host(ctx, self.uniq)
@@ -146,12 +174,11 @@ class Stage2:
         d_rows = _native.DeviceArray(ctx, (2, max(tot, 1)), np.uint32)
         ctx.rows_of_dev(d_uniq, nu, d_edges, tot, 3, d_rows.data_ptr(), 0)
         ctx.rows_of_dev(d_uniq, nu, d_edges, tot, 3, d_rows.data_ptr() + 4 * max(tot, 1), 1)
-        rows = d_rows.to_host()
         for d in (d_edges, d_tot):
             d.free()
-        self.ea = rows[0, :tot]                                # (positions as uint32: numpy indexes with them as they are; at 50 M edges
-        self.eb = rows[1, :tot]                                #  the two conversions to intp cost more than the edge build)
-        # the positions and the distinct barcodes stay on the device: the clustering levels and the per-read assignment run there
+        # the positions and the distinct barcodes stay on the device: the clustering levels, the count badger.py prints and the
+        # per-read assignment run there (50 M edges are 400 MB that the host would only hold)
+        self._ea = self._eb = None
         self._dev = {"ctx": ctx, "rows": d_rows, "m": tot, "uniq": d_uniq}
 
     # ------------------------------------------------------------------ centres
@@ -212,7 +239,7 @@ class Stage2:
         cidx = pos[present]                                               # centres that were observed (the others have no edges)
         owner[cidx] = cidx
         dev = getattr(self, "_dev", None)
-        if dev is not None and dev["m"] == len(self.ea):
+        if dev is not None and self._ea is None:
             # the edges are on the device: both levels there (bdg_cluster_dev), the same rule as the array code below
             print(1)
             print(2)                                                      # the reference prints the level numbers (:289)
@@ -256,12 +283,23 @@ class Stage2:
         besides the barcodes that have an edge it holds a key for every barcode whose neighbours were looked up while
         clustering, i.e. for every centre (observed or not)."""
         nu = len(self.uniq)
-        key = np.zeros(nu, bool)
-        key[self.ea] = True
-        key[self.eb] = True
         cr = np.unique(np.array(self.centers, dtype=np.uint32))                # a dict key exists once however often it is looked up
         pos = np.searchsorted(self.uniq, cr)
         present = ((pos < nu) & (self.uniq[np.minimum(pos, nu - 1)] == cr)) if nu else np.zeros(len(cr), bool)
+        dev = getattr(self, "_dev", None)
+        if dev is not None and self._ea is None:
+            # the edges are on the device: counted there (bdg_touched_count_dev)
+            ctx, m = dev["ctx"], dev["m"]
+            cidx = np.ascontiguousarray(pos[present], dtype=np.uint32)
+            d_c = _native.DeviceArray.from_host(ctx, cidx) if len(cidx) else None
+            touched = ctx.touched_count_dev(dev["rows"].data_ptr(), dev["rows"].data_ptr() + 4 * max(m, 1), m, nu,
+                                            d_c.data_ptr() if d_c is not None else 0, len(cidx))
+            if d_c is not None:
+                d_c.free()
+            return nu - (touched + int((~present).sum()))
+        key = np.zeros(nu, bool)
+        key[self.ea] = True
+        key[self.eb] = True
         key[pos[present]] = True
         return nu - (int(key.sum()) + int((~present).sum()))
 

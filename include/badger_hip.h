@@ -360,6 +360,12 @@ int  bdg_cluster_dev(bdg_ctx* ctx, const uint32_t* d_ea, const uint32_t* d_eb, u
  * assigned to (has = 0: nothing, the row prints '*').  Asynchronous. */
 int  bdg_assign_reads_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint64_t n, const uint32_t* d_uniq, uint32_t nu,
                           const uint32_t* d_assigned, const uint8_t* d_has, uint32_t* d_out_rank, uint8_t* d_out_has);
+/* How many of the nu distinct barcodes appear in the m edges given as positions (d_ea, d_eb: what bdg_rows_of_dev made of
+ * the edge array) or in d_extra (n_extra positions: the centres that were observed): the barcodes that are keys of the
+ * reference's `edges` dict when badger.py prints len(counts) - len(edges) (:131-132) - without the positions leaving the
+ * device.  Synchronises; *count is a host variable. */
+int  bdg_touched_count_dev(bdg_ctx* ctx, const uint32_t* d_ea, const uint32_t* d_eb, uint64_t m, uint32_t nu,
+                           const uint32_t* d_extra, uint32_t n_extra, uint64_t* count);
 
 /* ---- stage 2's read-side plumbing on the host (badger.py:112-121,129; barcode_graph.py:388-410) -------------- */
 /* Read ids of a run, kept natively (12 bytes per read instead of a Python string each). */

@@ -184,7 +184,7 @@ def test_device_clustering_and_assignment_equal_the_array_code(seed, thr, n_cell
     ctx = _native.default_context(0)
     dev = Stage2(thr)
     dev.count_host(obs_rank, usable)
-    dev.ea, dev.eb = ref.ea, ref.eb
+    dev.ea = dev.eb = None                                    # (the edges exist on the device only, as after build_edges)
     m = len(ref.ea)
     d_rows = _native.DeviceArray.from_host(ctx, np.stack([ref.ea, ref.eb]).astype(np.uint32) if m else np.zeros((2, 1), np.uint32))
     dev._dev = {"ctx": ctx, "rows": d_rows, "m": m, "uniq": _native.DeviceArray.from_host(ctx, dev.uniq)}
@@ -192,6 +192,10 @@ def test_device_clustering_and_assignment_equal_the_array_code(seed, thr, n_cell
         dev.cluster(None, None, max(4, n_cells // 2), 16, 25)
     assert o.getvalue() == "1\n2\n"
     assert (dev.owner == ref.owner).all() and (ref.owner == -1).sum() > 0 and (ref.owner >= 0).sum() > n_cells // 2
+    # the count badger.py prints, taken where the edges are (bdg_touched_count_dev) = the numpy form; then the host copy on demand
+    assert dev._ea is None and dev.disconnected() == ref.disconnected() and dev._ea is None
+    assert (dev.ea == ref.ea).all() and (dev.eb == ref.eb).all()
+    dev.ea = dev.eb = None
     # per read, from extraction records on the device
     recs = np.zeros(len(obs_rank), dtype=_native.REC_DTYPE)
     recs["valid"] = 1
