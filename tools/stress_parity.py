@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Large randomized parity run on the GPU box (not part of the test suite: minutes of oracle time).
 For several seeds / error profiles: extraction of N synthetic reads on the GPU vs the C oracle on all host cores,
-then nearest16 of the extracted barcodes vs the oracle on a sample, and graph edges (thr 1 and 2) of a slice of the
+then nearest16 of the extracted barcodes vs the oracle on a sample, and graph edges (thr 1, 2, 3) of a slice and of all of the
 distinct barcodes vs the oracle.  Prints one line per case; exit code 1 on any mismatch.
 
     python tools/stress_parity.py [--reads 1000000] [--cases 6] [--n-rate 0.001]
@@ -79,16 +79,20 @@ def main():
         sel = np.random.default_rng(case).integers(0, len(q), 96)
         xi, xe, xt = orc.nearest16(q[sel], wl, 2, threads=cores)
         nm += int((wi[sel] != xi).sum() + (we[sel] != xe).sum() + (wt[sel] != xt).sum())
-        # graph edges of a slice of the distinct barcodes (thr 1: neighbourhood probes, thr 2 and 3: q-gram join)
-        ranks = np.unique(got["bc_rank"][ok])[:60000]
-        gm = 0
-        for thr in (1, 2, 3):
-            T = orc.qgram_threshold(thr)
-            e = ctx.graph_edges(ranks, thr, T)
-            w = orc.graph_edges(ranks, thr, T, threads=cores)
-            gm += int(len(e) != len(w) or (len(e) and (e != w).any()))
-        print("case %d %s: %d reads, valid %.3f, extract mismatches %d (oracle %.1f s), nearest mismatches %d / 200000, graph mismatching lists %d / 3"
-              % (case, prof, n, float(got["valid"].mean()), mism, t_orc, nm, gm), flush=True)
+        # graph edges: of a slice of 60,000 of the distinct barcodes (thr 1: neighbourhood probes, thr 2: deletion-variant join,
+        # thr 3: q-gram join) and of ALL of them (some 600,000; thr 1: one-deletion join, thr 2: deletion-variant join) against
+        # the oracle's whole lists
+        every = np.unique(got["bc_rank"][ok])
+        gm, lists = 0, 0
+        for ranks, thrs in ((every[:60000], (1, 2, 3)), (every, (1, 2))):
+            for thr in thrs:
+                T = orc.qgram_threshold(thr)
+                e = ctx.graph_edges(ranks, thr, T)
+                w, _, _ = orc.graph_edges_sampled(ranks, thr, 1, T, threads=cores, cap=len(e) + 1)
+                gm += int(len(e) != len(w) or (len(e) and (e != w).any()))
+                lists += 1
+        print("case %d %s: %d reads, valid %.3f, extract mismatches %d (oracle %.1f s), nearest mismatches %d / 200000, graph mismatching lists %d / %d"
+              % (case, prof, n, float(got["valid"].mean()), mism, t_orc, nm, gm, lists), flush=True)
         bad += mism + nm + gm
     print("STRESS PARITY %s" % ("OK" if bad == 0 else "FAILED (%d)" % bad))
     return 1 if bad else 0
