@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""bdg_import_stage1_tsv on a stage-1 TSV with 4 / 8 / 16 / 32 parser threads (BADGER_AMD_IMPORT_THREADS), best of three.
+usage: import_threads_probe.py <stage-1 TSV>.  Builder tool."""
 import sys, time, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from badger_amd import _native
 _native.PRELOAD_TORCH = False
 _native.load()
