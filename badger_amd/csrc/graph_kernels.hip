@@ -969,11 +969,12 @@ void k_d2_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, ui
     const uint32_t wave = blockIdx.x * 4u + (uint32_t)wv, nwaves = gridDim.x * 4u;
     const uint32_t pq0 = d2_table.pq[lane], pq1 = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
     for (uint32_t row = wave; row < n; row += nwaves) {
-        const D2Row o = d2_row(ranks[row], lane, pq0, pq1, s_tab[wv], part, nparts);
+        const uint32_t r = ranks[row];
+        const D2Row o = d2_row(r, lane, pq0, pq1, s_tab[wv], part, nparts);
         const unsigned long long m0 = __ballot(o.keep0), m1 = __ballot(o.keep1);
         const uint32_t base = offset[row];
-        if (o.keep0) ent[base + lanes_below_u64(m0, lane)] = (unsigned long long)o.k0 << 32 | row;
-        if (o.keep1) ent[base + (uint32_t)__popcll(m0) + lanes_below_u64(m1, lane)] = (unsigned long long)o.k1 << 32 | row;
+        if (o.keep0) ent[base + lanes_below_u64(m0, lane)] = (unsigned long long)o.k0 << 32 | r;
+        if (o.keep1) ent[base + (uint32_t)__popcll(m0) + lanes_below_u64(m1, lane)] = (unsigned long long)o.k1 << 32 | r;
     }
 }
 
@@ -1089,7 +1090,7 @@ void k_d1_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, ui
         if (!((first >> (2u * p)) & 1u)) continue;
         const uint32_t k = d1_key(r, p);
         if (nparts > 1u && d2_part(k, nparts) != part) continue;
-        ent[at++] = (unsigned long long)k << 32 | row;
+        ent[at++] = (unsigned long long)k << 32 | r;
     }
 }
 
@@ -1104,9 +1105,10 @@ void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m
     __shared__ EdgeStageT<D2_ECAP> stages[4];
     __shared__ uint32_t s_cnt[4];
     __shared__ unsigned long long s_base;
-    __shared__ uint32_t s_incl[4][64], s_val[4][64], s_rank[4][64], s_key[4][64];
+    __shared__ uint32_t s_incl[4][64], s_val[4][64], s_key[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t ne = 0, qn = 0;
+    const uint32_t rank_lo = ranks[row_begin], rank_hi = ranks[row_end - 1u];       // (row_begin < row_end: the launcher's check)
     // meetings waiting for their verification: a, b, (rule << 28 | the group's 14-mer); the queue lives across the windows
     __shared__ uint32_t s_qa[4][128], s_qb[4][128], s_qm[4][128];
     auto verify = [&](uint32_t a, uint32_t b, uint32_t meta, bool act) {
@@ -1139,7 +1141,7 @@ void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m
     const unsigned long long wave_base = win * 64ull;
     const unsigned long long e = wave_base + (unsigned long long)lane;
     const bool have = e < m;
-    const unsigned long long mine = have ? ent[e] : 0xFFFFFFFF00000000ull;       // 14-mer in the high half, row in the low one
+    const unsigned long long mine = have ? ent[e] : 0xFFFFFFFF00000000ull;       // 14-mer in the high half, the row's barcode in the low one
     const uint32_t k = (uint32_t)(mine >> 32);
     const uint32_t v = (uint32_t)mine;
     // entries behind this one with the same 14-mer.  Inside the wave's 64 entries that is the distance to the group's last
@@ -1168,7 +1170,6 @@ void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m
     for (int s = 1; s < 64; s <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, s); if (lane >= s) incl += o; }
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     s_incl[wv][lane] = incl; s_val[wv][lane] = v; s_key[wv][lane] = k;
-    s_rank[wv][lane] = have ? ranks[v] : 0u;
     __builtin_amdgcn_wave_barrier();
     for (uint32_t x0 = 0; x0 < total; x0 += 64u) {
         const uint32_t x = x0 + (uint32_t)lane;
@@ -1182,14 +1183,13 @@ void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m
         uint32_t a = 0, b = 0, kk = 0;
         bool on = false;
         if (act) {
+            // (an entry carries the barcode itself - ranks ascend with the rows, so the smaller one is the lower row - and a
+            // meeting costs no look-up into the rank array: at 16 M rows those were a random 64-byte sector each)
             const uint32_t v1 = s_val[wv][o], v2 = (uint32_t)ent[e2];
-            const uint32_t row_i = v1, row_j = v2;
-            const uint32_t rank_i = s_rank[wv][o], rank_j = ranks[row_j];
-            const bool lower = row_i < row_j;                      // (a row has one entry per 14-mer: row_i != row_j)
-            a = lower ? rank_i : rank_j; b = lower ? rank_j : rank_i;
+            const bool lower = v1 < v2;                            // (a row has one entry per 14-mer: v1 != v2)
+            a = lower ? v1 : v2; b = lower ? v2 : v1;
             kk = s_key[wv][o];
-            const uint32_t row_a = lower ? row_i : row_j;
-            on = row_a >= row_begin && row_a < row_end;
+            on = a >= rank_lo && a <= rank_hi;
         }
         // A pair meets in several groups and is reported from one of them; which one is asked first (a few dozen
         // instructions), and only the meetings that would report go on to the verification (dmin and S, some hundred), 64 at a
