@@ -174,3 +174,36 @@ def test_reader_on_mixed_members_through_the_parallel_path(tmp_path, monkeypatch
     assert len(want) == 12000
     for threads in (0, 3):
         assert records(mixed, threads) == want, threads
+
+
+def test_streams_of_another_compressor(text):
+    """libdeflate (when the system has it) cuts blocks differently from zlib, uses static-code blocks for short stretches
+    and, at its high levels, near-optimal parsing with long distances: levels 1, 6 and 12 through the parallel inflate"""
+    import ctypes.util
+    name = ctypes.util.find_library("deflate") or "libdeflate.so.0"
+    try:
+        ld = C.CDLL(name)
+    except OSError:
+        pytest.skip("no libdeflate on this system")
+    ld.libdeflate_alloc_compressor.restype = C.c_void_p
+    ld.libdeflate_alloc_compressor.argtypes = [C.c_int]
+    ld.libdeflate_gzip_compress.restype = C.c_size_t
+    ld.libdeflate_gzip_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    ld.libdeflate_gzip_compress_bound.restype = C.c_size_t
+    ld.libdeflate_gzip_compress_bound.argtypes = [C.c_void_p, C.c_size_t]
+    ld.libdeflate_free_compressor.argtypes = [C.c_void_p]
+    for level in (1, 6, 12):
+        comp = ld.libdeflate_alloc_compressor(level)
+        assert comp
+        for data in (text, text[:70000], b"ACGT" * 50000 + text[:30000]):
+            bound = ld.libdeflate_gzip_compress_bound(comp, len(data))
+            buf = C.create_string_buffer(bound)
+            n = ld.libdeflate_gzip_compress(comp, data, len(data), buf, bound)
+            assert n > 0
+            z = buf.raw[:n]
+            assert zlib.decompress(z, 31) == data
+            for chunk in (2 << 10, 64 << 10, 0):
+                for th in (1, 4):
+                    rc, out, err = gunzip(z, th, chunk)
+                    assert rc == 0 and out == data, (level, len(data), chunk, th, err)
+        ld.libdeflate_free_compressor(comp)
