@@ -860,20 +860,6 @@ __device__ __forceinline__ uint32_t d2_part(uint32_t k, uint32_t nparts)
     return (uint32_t)(((unsigned long long)(k * 2654435761u) * nparts) >> 32);
 }
 
-// is the 14-mer k what is left of the 16-mer b when two of its letters are deleted?  (greedy: delete at the first mismatch)
-__device__ __forceinline__ bool d2_subseq(uint32_t k, uint32_t b)
-{
-    const uint32_t x1 = (k ^ b) | (1u << 28);
-    const uint32_t l1 = (uint32_t)__builtin_ctz(x1) >> 1;                              // common prefix, <= 14
-    const uint32_t k1 = k >> (2u * l1), m1 = 14u - l1;
-    const uint32_t b1 = (uint32_t)((unsigned long long)b >> (2u * l1 + 2u));           // b behind the deleted letter
-    const uint32_t x2 = ((k1 ^ b1) & ((1u << (2u * m1)) - 1u)) | (1u << (2u * m1));
-    const uint32_t l2 = (uint32_t)__builtin_ctz(x2) >> 1;                              // <= m1
-    const uint32_t k2 = k1 >> (2u * l2), m2 = m1 - l2;
-    const uint32_t b2 = (uint32_t)((unsigned long long)b1 >> (2u * l2 + 2u));
-    return ((k2 ^ b2) & ((1u << (2u * m2)) - 1u)) == 0u;
-}
-
 // One wave per row at a time (rows interleaved over the resident waves): lane l holds deletion pairs l and 64 + l.
 // A pair is dropped when an earlier one of the row gives the same 14-mer.  Letters inside a run are interchangeable, so only
 // the first letter of a run (or the first two, for two deletions in one run) need to be deleted: that alone removes most
@@ -1013,10 +999,12 @@ __device__ __forceinline__ bool d2_shifted(uint32_t x, uint32_t y, uint32_t& del
 //      i <= j needs i <= lcp, j >= 15 - lcs and a[x + 1] == b[x] for x in [i, j): the narrowest such interval decides;
 //      j < i likewise with the roles swapped;
 //   3. a[:-1] against b without a letter (or b[:-1] against a without one), equal but for one substituted letter - what is
-//      left of the forms through a[:-1] / b[:-1]: the 14-mer without that letter and the dropped / deleted one;
-//   4. otherwise (not seen on the test data: every edge falls under 1 - 3): the 14-mer of a's first deletion pair (table order)
-//      that is left in b as well - found by trying them.
-// Returns 1 / 0 for rules 1 to 3 (k is / is not that 14-mer), 2 when rule 4 has to decide.
+//      left of the forms through a[:-1] / b[:-1]: the 14-mer without that letter and the dropped / deleted one.
+// These are all the ways to dmin(a, b) <= 2: ed(a, b) <= 2 between two 16-mers is at most two substitutions (1) or one
+// insertion and one deletion (2); ed(a[:-1], b) <= 2 between a 15-mer and a 16-mer is one insertion (2, with i = 15) or one
+// insertion and one substitution (3) - and the tests behind 2 and 3 find the relation whenever it exists (the narrowest
+// interval; the two places the shift can sit relative to the substituted letter).  So a pair that none of them names is no
+// edge and is not even verified.  Returns 1: k is that 14-mer; 0: it is not, or there is no such relation.
 __device__ __forceinline__ int d2_reports(uint32_t a, uint32_t b, uint32_t k)
 {
     const uint32_t x = a ^ b;                                          // (a != b)
@@ -1039,7 +1027,7 @@ __device__ __forceinline__ int d2_reports(uint32_t a, uint32_t b, uint32_t k)
     uint32_t del, sub; bool late;
     if (d2_shifted(a, b, del, sub, late)) return d2_key(a, sub, 15u) == k ? 1 : 0;
     if (d2_shifted(b, a, del, sub, late)) return (late ? d2_key(a, del, sub + 1u) : d2_key(a, sub, del)) == k ? 1 : 0;
-    return 2;
+    return 0;                                                          // none of the relations holds: dmin(a, b) > 2, no edge
 }
 
 // One wave per 64 consecutive sorted entries.  Lane l's entry meets the L_l entries behind it in its group (same 14-mer);
@@ -1109,29 +1097,12 @@ void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t ne = 0, qn = 0;
     const uint32_t rank_lo = ranks[row_begin], rank_hi = ranks[row_end - 1u];       // (row_begin < row_end: the launcher's check)
-    // meetings waiting for their verification: a, b, (rule << 28 | the group's 14-mer); the queue lives across the windows
-    __shared__ uint32_t s_qa[4][128], s_qb[4][128], s_qm[4][128];
-    auto verify = [&](uint32_t a, uint32_t b, uint32_t meta, bool act) {
+    // meetings waiting for their verification: a, b; the queue lives across the windows
+    __shared__ uint32_t s_qa[4][128], s_qb[4][128];
+    auto verify = [&](uint32_t a, uint32_t b, bool act) {
         const uint32_t d = act ? dmin3(a, b) : 99u;
         bool edge = d <= thr;
-        if (__ballot(edge)) {
-            edge = edge && (int32_t)qgram_S(a, b) >= T;
-            // rule 4, one pair at a time with a's 120 deletion pairs spread over the lanes: the first of them (table order) whose
-            // 14-mer is left in b as well names the reporting group - this one, or another
-            for (unsigned long long w = NDEL == 2 ? __ballot(edge && (meta >> 28) == 2u) : 0ull; w; w &= w - 1ull) {
-                const int src = __builtin_ctzll(w);
-                const uint32_t ja = (uint32_t)__builtin_amdgcn_readlane((int)a, src), jb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
-                const uint32_t jk = (uint32_t)__builtin_amdgcn_readlane((int)meta, src) & 0x0FFFFFFFu;
-                const uint32_t pq_lo = d2_table.pq[lane], pq_hi = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
-                const uint32_t k_lo = d2_key(ja, pq_lo >> 4, pq_lo & 15u), k_hi = d2_key(ja, pq_hi >> 4, pq_hi & 15u);
-                const unsigned long long m_lo = __ballot(d2_subseq(k_lo, jb));
-                const unsigned long long m_hi = __ballot(lane < D2_NPAIR - 64 && d2_subseq(k_hi, jb));
-                uint32_t k_first;                                          // (the group's own 14-mer is one of them: m_lo | m_hi != 0)
-                if (m_lo) k_first = (uint32_t)__builtin_amdgcn_readlane((int)k_lo, __builtin_ctzll(m_lo));
-                else k_first = (uint32_t)__builtin_amdgcn_readlane((int)k_hi, m_hi ? __builtin_ctzll(m_hi) : 0);
-                if (k_first != jk && lane == src) edge = false;
-            }
-        }
+        if (__ballot(edge)) edge = edge && (int32_t)qgram_S(a, b) >= T;
         edge_push(edge, a, b, d, stages[wv], ne, lane, out, cap, n_edges);
     };
     // resident grid, the windows interleaved over its waves: a wave reserves output when its stage is full and once at the end
@@ -1198,13 +1169,13 @@ void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m
         const unsigned long long mq = __ballot(rep != 0);
         if (rep != 0) {
             const uint32_t at = qn + lanes_below_u64(mq, lane);
-            s_qa[wv][at] = a; s_qb[wv][at] = b; s_qm[wv][at] = NDEL == 2 ? (uint32_t)rep << 28 | kk : 0u;
+            s_qa[wv][at] = a; s_qb[wv][at] = b;
         }
         qn += (uint32_t)__popcll(mq);
         __builtin_amdgcn_wave_barrier();
         if (qn >= 64u) {
             qn -= 64u;
-            verify(s_qa[wv][qn + lane], s_qb[wv][qn + lane], s_qm[wv][qn + lane], true);
+            verify(s_qa[wv][qn + lane], s_qb[wv][qn + lane], true);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1212,7 +1183,7 @@ void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m
     }
     if (qn) {
         const bool act = (uint32_t)lane < qn;
-        verify(act ? s_qa[wv][lane] : 0u, act ? s_qb[wv][lane] : 1u, act ? s_qm[wv][lane] : 0u, act);
+        verify(act ? s_qa[wv][lane] : 0u, act ? s_qb[wv][lane] : 1u, act);
     }
     edge_finish<4>(stages, ne, s_cnt, &s_base, out, cap, n_edges);
 }
