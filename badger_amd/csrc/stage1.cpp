@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -555,24 +556,66 @@ int bdg_write_assignments(const bdg_idstore* ids, const uint32_t* rank, const ui
     const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
     if (fd < 0) return BDG_E_ARG;
     bool ok = write_all(fd, "readID\tbarcode\n", 15);
-    std::vector<char> buf;
-    buf.reserve(size_t(8) << 20);
-    for (uint64_t i = 0; i < n && ok; ++i) {
-        const size_t idl = (size_t)(ids->off[i + 1] - ids->off[i]);
-        const size_t at = buf.size();
-        buf.resize(at + idl + 19);
-        char* o = buf.data() + at;
-        memcpy(o, ids->text.data() + ids->off[i], idl); o += idl;
-        *o++ = '\t';
-        if (has[i]) { const uint32_t r = rank[i]; for (int b = 0; b < 16; ++b) *o++ = "ACGT"[(r >> (2 * b)) & 3u]; }   // unrank, common.py:27-38
-        else *o++ = '*';
-        *o++ = '\n';
-        buf.resize((size_t)(o - buf.data()));
-        if (buf.size() > (size_t(8) << 20) - 4096) { ok = write_all(fd, buf.data(), buf.size()); buf.clear(); }
+    // a row's length is known before it is written (id + tab + 16 letters or '*' + newline): the rows are cut into ranges,
+    // every range knows its place in the file, and a thread formats and pwrite()s its range by itself
+    unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("BADGER_AMD_WRITE_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+    nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(1, n >> 16));                 // 65,536 rows per thread at least
+    std::vector<uint64_t> lo(nt + 1), at(nt + 1);
+    for (unsigned k = 0; k <= nt; ++k) lo[k] = n * k / nt;
+    at[0] = 15;
+    {
+        std::vector<uint64_t> bytes(nt, 0);
+        std::vector<std::thread> th;
+        auto size_of = [&](unsigned k) {
+            uint64_t b = ids->off[lo[k + 1]] - ids->off[lo[k]] + 2 * (lo[k + 1] - lo[k]);
+            for (uint64_t i = lo[k]; i < lo[k + 1]; ++i) b += has[i] ? 16 : 1;
+            bytes[k] = b;
+        };
+        for (unsigned k = 1; k < nt; ++k) th.emplace_back(size_of, k);
+        size_of(0);
+        for (auto& t : th) t.join();
+        for (unsigned k = 0; k < nt; ++k) at[k + 1] = at[k] + bytes[k];
     }
-    if (ok && !buf.empty()) ok = write_all(fd, buf.data(), buf.size());
+    std::atomic<bool> good{ ok };
+    auto write_range = [&](unsigned k) {
+        std::vector<char> buf;
+        buf.reserve(size_t(8) << 20);
+        uint64_t pos = at[k];
+        auto flush = [&]() {
+            size_t done = 0;
+            while (done < buf.size()) {
+                const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(pos + done));
+                if (w <= 0) { good = false; return; }
+                done += (size_t)w;
+            }
+            pos += buf.size(); buf.clear();
+        };
+        for (uint64_t i = lo[k]; i < lo[k + 1] && good; ++i) {
+            const size_t idl = (size_t)(ids->off[i + 1] - ids->off[i]);
+            const size_t a = buf.size();
+            buf.resize(a + idl + 19);
+            char* o = buf.data() + a;
+            memcpy(o, ids->text.data() + ids->off[i], idl); o += idl;
+            *o++ = '\t';
+            if (has[i]) { const uint32_t r = rank[i]; for (int b = 0; b < 16; ++b) *o++ = "ACGT"[(r >> (2 * b)) & 3u]; }   // unrank, common.py:27-38
+            else *o++ = '*';
+            *o++ = '\n';
+            buf.resize((size_t)(o - buf.data()));
+            if (buf.size() > (size_t(8) << 20) - 4096) flush();
+        }
+        if (good && !buf.empty()) flush();
+    };
+    if (ok) {
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; ++k) th.emplace_back(write_range, k);
+        write_range(0);
+        for (auto& t : th) t.join();
+    }
+    ok = good;
     if (::close(fd) != 0) ok = false;
     return ok ? BDG_OK : BDG_E_ARG;
 }
+
 
 }  // extern "C"

@@ -308,3 +308,22 @@ def test_native_tsv_import_in_ranges(tmp_path, monkeypatch):
         monkeypatch.setenv("BADGER_AMD_IMPORT_THREADS", threads)
         with pytest.raises(KeyError, match="line %d " % (bad_at + 1)):
             _native.import_stage1_tsv(str(p), 16)
+
+
+def test_output_writer_in_ranges(tmp_path, monkeypatch):
+    """bdg_write_assignments cuts the rows into ranges whose place in the file is known beforehand; every range is written
+    by a thread of its own: 1, 3 and 7 threads give the file Python writes, for ids of uneven length and a mix of rows
+    with and without a barcode"""
+    from badger_amd import _native
+    rng = np.random.default_rng(8)
+    n = 300000
+    names = ["read_%d%s" % (i, "x" * int(rng.integers(0, 9))) for i in range(n)]
+    rank = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    has = (rng.random(n) < 0.7).astype(np.uint8)
+    want = "readID\tbarcode\n" + "".join("%s\t%s\n" % (nm, synth.rank_to_str(int(r)) if h else "*") for nm, r, h in zip(names, rank, has))
+    ids = _native.IdStore(names)
+    for threads in ("1", "3", "7"):
+        monkeypatch.setenv("BADGER_AMD_WRITE_THREADS", threads)
+        out = str(tmp_path / ("o%s.tsv" % threads))
+        _native.write_assignments(ids, rank, has, out)
+        assert open(out).read() == want, threads
