@@ -1115,23 +1115,31 @@ void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m
     const unsigned long long mine = have ? ent[e] : 0xFFFFFFFF00000000ull;       // 14-mer in the high half, the row's barcode in the low one
     const uint32_t k = (uint32_t)(mine >> 32);
     const uint32_t v = (uint32_t)mine;
-    // entries behind this one with the same 14-mer.  Inside the wave's 64 entries that is the distance to the group's last
-    // lane (groups are contiguous); only a group that runs past lane 63 looks into memory for its end (a 14-mer has at most
-    // 120 * 16 = 1920 parents: fewer than 2048 entries)
+    // entries behind this one in its group.  Inside the wave's 64 entries that is the distance to the group's last lane
+    // (groups are contiguous); only a group that runs past lane 63 looks into memory for its end (a 14-mer has at most
+    // 120 * 16 = 1920 parents: fewer than 2^11 entries)
     const unsigned long long next_base = wave_base + 64ull;
+    const uint32_t kb = k;
     const uint32_t k_after = next_base < m ? (uint32_t)(ent[next_base] >> 32) : 0xFFFFFFFEu;           // (matches no key and no padding)
-    const uint32_t k_down = (uint32_t)__shfl_down((int)k, 1);
+    const uint32_t k_down = (uint32_t)__shfl_down((int)kb, 1);
     const uint32_t k_next = lane == 63 ? k_after : k_down;
-    const unsigned long long ends = __ballot(!have || k != k_next);                  // lanes that end a group
+    const unsigned long long ends = __ballot(!have || kb != k_next);                 // lanes that end a group
     const unsigned long long rest = ends >> lane;
     uint32_t L = rest ? (uint32_t)__builtin_ctzll(rest) : 63u - (uint32_t)lane;
     if (__ballot(have && rest == 0ull)) {                                             // the last group continues behind the window
-        const uint32_t k63 = (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
+        const uint32_t k63 = (uint32_t)__builtin_amdgcn_readlane((int)kb, 63);
+        // how far: doubling steps until an entry of another bucket (or the end) is met, then halving ones - a bucket that
+        // ends a few entries behind the window, as nearly all do, costs two or three look-ups (all lanes ask alike)
+        auto same = [&](uint32_t t) {
+            const unsigned long long j = wave_base + 63ull + t;
+            return j < m && (uint32_t)(ent[j] >> 32) == k63;
+        };
         uint32_t tail = 0;
-#pragma unroll
-        for (uint32_t s = 1024; s >= 1; s >>= 1) {
-            const unsigned long long j = wave_base + 63ull + tail + s;
-            if (j < m && (uint32_t)(ent[j] >> 32) == k63) tail += s;
+        if (same(1u)) {
+            uint32_t hi = 2;
+            while (hi < (1u << 12) && same(hi)) hi <<= 1;
+            tail = hi >> 1;
+            for (uint32_t s = hi >> 2; s >= 1; s >>= 1) if (same(tail + s)) tail += s;
         }
         if (rest == 0ull) L += tail;
     }
@@ -1297,7 +1305,10 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             size_t t_sort = 0;
             unsigned long long* nul64 = nullptr;
             const int key_end = one_deletion ? 62 : 60;                           // (15-mers: 30 bits)
-            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, t_sort, nul64, nul64, (long long)m, 32, key_end, st));
+            // (sorting only the key's upper 24 bits - three radix passes instead of four - and letting the pair walk meet every pair
+            // of a bucket of keys was measured: 0.73 against 0.79 ms at 250 K rows, 2.19 against 1.78 at config 5: not kept)
+            const int key_begin = 32;
+            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, t_sort, nul64, nul64, (long long)m, key_begin, key_end, st));
             if ((rc = bdg_reserve(ctx, ctx->g_qj, sizeof(unsigned long long) * 2ull * (m + 64) + t_sort + 512))) return rc;
             auto* e_in = static_cast<unsigned long long*>(ctx->g_qj.p);
             auto* e_out = e_in + m + 32;
@@ -1310,7 +1321,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             {
                 ScopedKernelTimer tm(ctx, "d2_sort");
                 size_t t = t_sort;
-                BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(temp, t, e_in, e_out, (long long)m, 32, key_end, st));
+                BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(temp, t, e_in, e_out, (long long)m, key_begin, key_end, st));
             }
             ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_pairs" : "k_d2_pairs");
             unsigned long long pgrid = (unsigned long long)ctx->g_cus * d2_pairs_blocks_per_cu();
