@@ -937,10 +937,20 @@ void k_d2_count(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, u
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t wave = blockIdx.x * 4u + (uint32_t)wv, nwaves = gridDim.x * 4u;
     const uint32_t pq0 = d2_table.pq[lane], pq1 = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
-    for (uint32_t row = wave; row < n; row += nwaves) {
-        const D2Row o = d2_row(ranks[row], lane, pq0, pq1, s_tab[wv], part, nparts);
-        const uint32_t c = (uint32_t)__popcll(__ballot(o.keep0)) + (uint32_t)__popcll(__ballot(o.keep1));
-        if (lane == 0) count[row] = c;
+    // a wave takes up to 64 consecutive rows at a time (fewer when there are not that many rows per wave): one coalesced load
+    // of their barcodes, one coalesced store of their counts instead of a load per row that everything else waits for
+    const uint32_t G = n / nwaves >= 64u ? 64u : (n / nwaves ? n / nwaves : 1u);
+    for (unsigned long long base = (unsigned long long)wave * G; base < n; base += (unsigned long long)nwaves * G) {
+        const uint32_t mine = (uint32_t)lane < G && base + (uint32_t)lane < n ? ranks[base + (uint32_t)lane] : 0u;
+        const uint32_t rows = n - base < G ? (uint32_t)(n - base) : G;
+        uint32_t my_count = 0;
+        for (uint32_t i = 0; i < rows; ++i) {
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)i);
+            const D2Row o = d2_row(r, lane, pq0, pq1, s_tab[wv], part, nparts);
+            const uint32_t c = (uint32_t)__popcll(__ballot(o.keep0)) + (uint32_t)__popcll(__ballot(o.keep1));
+            if ((uint32_t)lane == i) my_count = c;
+        }
+        if ((uint32_t)lane < rows) count[base + (uint32_t)lane] = my_count;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) count[n] = 0u;              // (its exclusive sum is the number of entries)
 }
@@ -954,13 +964,20 @@ void k_d2_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, ui
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t wave = blockIdx.x * 4u + (uint32_t)wv, nwaves = gridDim.x * 4u;
     const uint32_t pq0 = d2_table.pq[lane], pq1 = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
-    for (uint32_t row = wave; row < n; row += nwaves) {
-        const uint32_t r = ranks[row];
-        const D2Row o = d2_row(r, lane, pq0, pq1, s_tab[wv], part, nparts);
-        const unsigned long long m0 = __ballot(o.keep0), m1 = __ballot(o.keep1);
-        const uint32_t base = offset[row];
-        if (o.keep0) ent[base + lanes_below_u64(m0, lane)] = (unsigned long long)o.k0 << 32 | r;
-        if (o.keep1) ent[base + (uint32_t)__popcll(m0) + lanes_below_u64(m1, lane)] = (unsigned long long)o.k1 << 32 | r;
+    const uint32_t G = n / nwaves >= 64u ? 64u : (n / nwaves ? n / nwaves : 1u);          // (as in k_d2_count)
+    for (unsigned long long base0 = (unsigned long long)wave * G; base0 < n; base0 += (unsigned long long)nwaves * G) {
+        const bool mine_ok = (uint32_t)lane < G && base0 + (uint32_t)lane < n;
+        const uint32_t mine = mine_ok ? ranks[base0 + (uint32_t)lane] : 0u;
+        const uint32_t mine_at = mine_ok ? offset[base0 + (uint32_t)lane] : 0u;
+        const uint32_t rows = n - base0 < G ? (uint32_t)(n - base0) : G;
+        for (uint32_t i = 0; i < rows; ++i) {
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)i);
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)mine_at, (int)i);
+            const D2Row o = d2_row(r, lane, pq0, pq1, s_tab[wv], part, nparts);
+            const unsigned long long m0 = __ballot(o.keep0), m1 = __ballot(o.keep1);
+            if (o.keep0) ent[base + lanes_below_u64(m0, lane)] = (unsigned long long)o.k0 << 32 | r;
+            if (o.keep1) ent[base + (uint32_t)__popcll(m0) + lanes_below_u64(m1, lane)] = (unsigned long long)o.k1 << 32 | r;
+        }
     }
 }
 
