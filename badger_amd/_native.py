@@ -29,13 +29,13 @@ SLOTS = 4
 STRAND_RULE_DEFAULT, STRAND_RULE_NO_POLYA = 0, 1
 
 EXPORTS = [
-    "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_device_count",
+    "bdg_init", "bdg_free", "bdg_last_error", "bdg_version", "bdg_device_count", "bdg_selftest_dj_codec",
     "bdg_mem_alloc", "bdg_mem_free", "bdg_mem_to_host", "bdg_mem_from_host", "bdg_set_stream", "bdg_synchronize", "bdg_set_overlap",
     "bdg_profile_enable", "bdg_profile_only", "bdg_profile_reset", "bdg_profile_read",
     "bdg_extract_batch", "bdg_extract_batch_dev", "bdg_extract_status", "bdg_extract_counters", "bdg_extract_set_queue_capacity",
     "bdg_extract_set_strand_rule",
     "bdg_nearest16", "bdg_whitelist_load", "bdg_nearest16_dev", "bdg_nearest16_recs_dev", "bdg_nearest16_set_algo", "bdg_nearest16_index_bytes",
-    "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_edges_part_dev", "bdg_graph_set_algo", "bdg_distinct_dev", "bdg_rows_of_dev",
+    "bdg_graph_edges", "bdg_graph_edges_dev", "bdg_graph_edges_rows_dev", "bdg_graph_edges_part_dev", "bdg_graph_set_algo", "bdg_graph_status", "bdg_distinct_dev", "bdg_rows_of_dev",
     "bdg_extract_submit", "bdg_extract_collect", "bdg_extract_keep_records", "bdg_kept_records", "bdg_kept_records_to_host", "bdg_keep_observed", "bdg_touched_count_dev",
     "bdg_ingest_open", "bdg_ingest_open_mt", "bdg_ingest_open_ex", "bdg_ingest_next", "bdg_ingest_release", "bdg_ingest_error",
     "bdg_ingest_reads", "bdg_ingest_close", "bdg_format_rows", "bdg_stage1_run",
@@ -109,6 +109,7 @@ def load():
     L.bdg_last_error.restype = C.c_char_p
     L.bdg_version.restype = C.c_char_p
     L.bdg_device_count.restype = C.c_int
+    L.bdg_selftest_dj_codec.argtypes = [C.c_uint64, C.c_uint32]
     L.bdg_mem_alloc.argtypes = [vp, u64, C.POINTER(vp)]
     L.bdg_mem_free.argtypes = [vp, vp]
     L.bdg_mem_to_host.argtypes = [vp, vp, vp, u64]
@@ -138,6 +139,7 @@ def load():
     L.bdg_graph_edges_rows_dev.argtypes = [vp, vp, u32, u32, u32, u32, i32, vp, u64, vp]
     L.bdg_graph_edges_part_dev.argtypes = [vp, vp, u32, u32, u32, u32, i32, vp, u64, vp]
     L.bdg_graph_set_algo.argtypes = [vp, C.c_int]
+    L.bdg_graph_status.argtypes = [vp]
     L.bdg_distinct_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp]
     L.bdg_rows_of_dev.argtypes = [vp, vp, u32, vp, u64, u32, vp]
     L.bdg_extract_submit.argtypes = [vp, u32, vp, vp, u32, u32]
@@ -371,6 +373,10 @@ class Context:
 
     def graph_set_algo(self, algo):
         self._check(self.lib.bdg_graph_set_algo(self.h, algo))
+
+    def graph_status(self):
+        """waits for the stream; raises if a deletion-variant join of the last *_dev graph call could not group its input"""
+        self._check(self.lib.bdg_graph_status(self.h))
 
     def rows_of_dev(self, d_sorted, n, d_values, m, stride_words, d_rows, value_offset_words=0):
         """d_rows[i] = position of d_values[value_offset_words + i * stride_words] in the ascending d_sorted[0..n), NONE if absent"""

@@ -104,6 +104,7 @@ class BarcodeGraph:
             d_tot = torch.zeros(1, dtype=torch.int64, device=dev)
             ctx.graph_edges_dev(uniq, nu, self.threshold, T, d_edges, cap, d_tot)
             ctx.synchronize()
+            ctx.graph_status()
             tot = int(d_tot[0])
             if tot <= cap:
                 break

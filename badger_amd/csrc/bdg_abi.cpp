@@ -1,6 +1,7 @@
 // C ABI of libbadger_hip.so (include/badger_hip.h): context management, host-buffer
 // wrappers (H2D, launch, D2H) and the device-resident entry points.
 #include "bdg_common.hpp"
+#include "dj_codec.hpp"
 
 #include <cstddef>
 
@@ -19,6 +20,8 @@ int bdg_whitelist_load_impl(bdg_ctx*, const uint32_t*, uint32_t);
 int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, int, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
 int bdg_graph_launch(bdg_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, int32_t, bdg_edge*, uint64_t, uint64_t*, uint32_t part = 0, uint32_t nparts = 1);
 int bdg_graph_plan(const bdg_ctx*, uint32_t, uint32_t);
+int bdg_graph_join_flags(bdg_ctx*, uint32_t*);
+int bdg_graph_flags_error(bdg_ctx*, uint32_t);
 int bdg_distinct_launch(bdg_ctx*, const bdg_extract_rec*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 int bdg_records_of_observed_launch(bdg_ctx*, const uint32_t*, const uint8_t*, uint64_t, bdg_extract_rec*);
 int bdg_rows_of_launch(bdg_ctx*, const uint32_t*, uint32_t, const uint32_t*, uint64_t, uint32_t, uint32_t*);
@@ -111,6 +114,43 @@ extern "C" {
 #define BDG_HOST_HASH "unhashed"
 #endif
 const char* bdg_version(void) { return "badger_hip 0.3 (gfx950) kernels " BDG_KERNEL_HASH " host " BDG_HOST_HASH; }
+
+int bdg_selftest_dj_codec(uint64_t seed, uint32_t rounds)
+{
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 16); };
+    for (uint32_t t = 0, k = 0; t < 16; ++t) for (uint32_t q = t + 1; q < 16; ++q, ++k) if (djc::pair_of(k) != (t << 4 | q)) return 1;
+    for (uint32_t it = 0; it < rounds; ++it) {
+        const uint32_t r = it == 0 ? 0u : (it == 1 ? 0xFFFFFFFFu : rnd());
+        const uint32_t k28 = rnd() & 0x0FFFFFFFu, k30 = rnd() & 0x3FFFFFFFu;
+        if (djc::unmix<28>(djc::mix<28>(k28)) != k28 || djc::mix<28>(k28) >> 28) return 2;
+        if (djc::unmix<30>(djc::mix<30>(k30)) != k30 || djc::mix<30>(k30) >> 30) return 3;
+        if (djc::mix<28>(djc::unmix<28>(k28)) != k28 || djc::mix<30>(djc::unmix<30>(k30)) != k30) return 4;
+        for (uint32_t p = 0; p < 16; ++p) {
+            const uint32_t k = djc::del1(r, p);
+            if (k >> 30 || djc::ins1(k, p, (r >> (2 * p)) & 3u) != r) return 5;
+            for (uint32_t l1 = 8; l1 <= 10; ++l1) {
+                const uint32_t zb = 30 - l1, z = djc::mix<30>(k), e = djc::enc1(z, zb, p, r);
+                uint32_t k2, r2;
+                djc::dec1(e, z >> zb, zb, k2, r2);
+                if (k2 != k || r2 != r || (e >> (zb + 6))) return 6;
+            }
+        }
+        for (uint32_t t = 0; t < 120; ++t) {
+            const uint32_t pq = djc::pair_of(t), p = pq >> 4, q = pq & 15u;
+            const uint32_t k = djc::del2(r, p, q);
+            if (k >> 28 || djc::ins2(k, p, q, (r >> (2 * p)) & 3u, (r >> (2 * q)) & 3u) != r) return 7;
+            if (djc::del1(djc::del1(r, q), p) != k) return 8;
+            for (uint32_t l1 = 8; l1 <= 10; ++l1) {
+                const uint32_t zb = 28 - l1, z = djc::mix<28>(k), e = djc::enc2(z, zb, t, r, pq);
+                uint32_t k2, r2;
+                djc::dec2(e, z >> zb, zb, pq, k2, r2);
+                if (k2 != k || r2 != r || (e >> (zb + 11))) return 9;
+            }
+        }
+    }
+    return 0;
+}
 
 int bdg_device_count(void)
 {
@@ -617,6 +657,16 @@ int bdg_graph_set_algo(bdg_ctx* ctx, int algo)
     return BDG_OK;
 }
 
+int bdg_graph_status(bdg_ctx* ctx)
+{
+    if (!ctx) return BDG_E_ARG;
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t flags = 0;
+    int rc;
+    if ((rc = bdg_graph_join_flags(ctx, &flags))) return rc;
+    return flags ? bdg_graph_flags_error(ctx, flags) : BDG_OK;
+}
+
 int bdg_graph_edges_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t thr, int32_t qgram_T,
                         bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges)
 {
@@ -685,6 +735,7 @@ int bdg_graph_edges(bdg_ctx* ctx, const uint32_t* ranks, uint32_t n, uint32_t th
         uint64_t total = 0;
         BDG_HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->g_cnt.p, 8, hipMemcpyDeviceToHost, st));
         BDG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if ((rc = bdg_graph_status(ctx))) return rc;
         if (total > dcap) { dcap = total; continue; }
         all.resize(total);
         if (total) BDG_HIP_TRY(ctx, hipMemcpy(all.data(), ctx->g_tmp1.p, sizeof(bdg_edge) * total, hipMemcpyDeviceToHost));

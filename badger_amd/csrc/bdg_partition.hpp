@@ -1,0 +1,132 @@
+// Grouping by key without a sort library: bucket partition in two levels, exact and without one atomic on global memory.
+//
+// What the reference does with dict buckets (index.py:29-35, barcode_graph.py:192-204) needs GROUPS of equal keys, and
+// the distinct-barcode count needs them in ascending order; neither needs a full radix sort of the entries through HBM.
+//
+//   level 1  the producer runs twice over tiles of its input (a tile = what one block handles): the first run counts, per
+//            tile, how many entries go to each of NB1 coarse buckets (histogram in LDS, one row of `hist` per tile);
+//            k_part_colscan turns the columns of that matrix into every tile's write position inside each bucket,
+//            k_part_bases turns the column totals into the buckets' places (and picks NB2 from the total, on the
+//            device: the host never waits for a count); the second run writes each entry to its place (cursor per
+//            bucket in LDS).
+//   level 2  k_part_split: one block per coarse bucket reads it twice (the second time out of L2), counts NB2 sub-buckets
+//            in LDS and writes the entries grouped by sub-bucket into a second buffer, with the start of every fine
+//            bucket in `fstart`.
+//   then     a consumer takes one fine bucket (about a thousand entries) into LDS and finishes the grouping there.
+//
+// Every entry is written twice and read three times (the radix sort this replaces: ten times each).  gfx950 only.
+#pragma once
+
+#include "bdg_common.hpp"
+
+namespace bdgpart {
+
+constexpr uint32_t NB1_MAX = 1024;     // coarse buckets (the producer's LDS histogram)
+constexpr uint32_t NB2_MAX = 1024;     // sub-buckets of one coarse bucket (k_part_split's LDS histogram)
+
+// geom[]: what the device decides and the later kernels read
+enum { G_L2 = 0, G_M_LO = 1, G_M_HI = 2, G_FLAGS = 3, G_WORDS = 8 };
+
+#if defined(__HIPCC__)
+
+// exclusive prefix sums over the values the threads of a block hold (one each); every thread calls; s_w: one word per wave + 1
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t& total)
+{
+    constexpr int NW = THREADS / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(v);
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const uint32_t x = s_w[w]; all += x; if (w < wv) before += x; }
+    total = all;
+    __syncthreads();                                   // (s_w is free again)
+    return before + incl - v;
+}
+
+// hist[t][b] (counts of tile t for bucket b) -> the tile's offset inside column b, in place; tot[b] = the column's sum.
+// One block per column; a thread takes a run of consecutive tiles.
+static __global__ __launch_bounds__(256)
+void k_part_colscan(uint32_t* __restrict__ hist, uint32_t ntiles, uint32_t nb1, uint32_t* __restrict__ tot)
+{
+    __shared__ uint32_t s_w[5];
+    const uint32_t b = blockIdx.x;
+    const uint32_t per = (ntiles + 255u) / 256u;
+    const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; ++t) sum += hist[(size_t)t * nb1 + b];
+    uint32_t total;
+    uint32_t run = block_excl_scan<256>(sum, s_w, total);
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = hist[(size_t)t * nb1 + b];
+        hist[(size_t)t * nb1 + b] = run;
+        run += c;
+    }
+    if (threadIdx.x == 0) tot[b] = total;
+}
+
+// base[b] = where coarse bucket b starts (64-bit sums: the total is checked, not assumed), base[nb1] = m, the number of
+// entries; geom: log2 of the sub-bucket count that brings a fine bucket to about `target` entries (at most l2_max), m, and
+// flag bit 0 when m does not fit the limit the caller can index (the caller then cuts its work smaller).
+static __global__ __launch_bounds__(1024)
+void k_part_bases(const uint32_t* __restrict__ tot, uint32_t nb1, uint32_t target, uint32_t l2_max, unsigned long long limit,
+                  unsigned long long* __restrict__ base, uint32_t* __restrict__ geom)
+{
+    __shared__ unsigned long long s_w[17];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long v = threadIdx.x < nb1 ? tot[threadIdx.x] : 0ull;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { const unsigned long long o = __shfl_up(incl, s); if (lane >= s) incl += o; }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    unsigned long long before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const unsigned long long x = s_w[w]; all += x; if (w < wv) before += x; }
+    if (threadIdx.x < nb1) base[threadIdx.x] = before + incl - v;
+    if (threadIdx.x == 0) {
+        base[nb1] = all;
+        uint32_t l2 = 0;
+        while (l2 < l2_max && (all >> l2) > (unsigned long long)nb1 * target) ++l2;
+        geom[G_L2] = l2; geom[G_M_LO] = (uint32_t)all; geom[G_M_HI] = (uint32_t)(all >> 32);
+        geom[G_FLAGS] = all > limit ? 1u : 0u;
+    }
+}
+
+// One block per coarse bucket: its entries grouped by sub-bucket (bits [sh_top - l2, sh_top) of an entry) into `out`,
+// the places of the fine buckets into fstart[b << l2 | j], fstart[nb1 << l2] = m.  Any bucket size (streamed twice).
+template <class E>
+__global__ __launch_bounds__(1024)
+void k_part_split(const E* __restrict__ in, E* __restrict__ out, const unsigned long long* __restrict__ base,
+                  const uint32_t* __restrict__ geom, uint32_t nb1, uint32_t sh_top, uint32_t* __restrict__ fstart)
+{
+    __shared__ uint32_t s_h[NB2_MAX];
+    __shared__ uint32_t s_w[17];
+    if (geom[G_FLAGS] & 1u) return;
+    const uint32_t l2 = geom[G_L2], nb2 = 1u << l2, sh = sh_top - l2, mask = nb2 - 1u;
+    for (uint32_t b = blockIdx.x; b < nb1; b += gridDim.x) {
+        const unsigned long long s = base[b];
+        const uint32_t c = (uint32_t)(base[b + 1] - s);
+        if (threadIdx.x < nb2) s_h[threadIdx.x] = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < c; i += 1024u) atomicAdd(&s_h[(uint32_t)(in[s + i] >> sh) & mask], 1u);
+        __syncthreads();
+        const uint32_t v = threadIdx.x < nb2 ? s_h[threadIdx.x] : 0u;
+        uint32_t total;
+        const uint32_t at = (uint32_t)s + block_excl_scan<1024>(v, s_w, total);
+        if (threadIdx.x < nb2) { s_h[threadIdx.x] = at; fstart[(b << l2) + threadIdx.x] = at; }
+        if (b == nb1 - 1u && threadIdx.x == 0) fstart[nb1 << l2] = (uint32_t)base[nb1];
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < c; i += 1024u) {
+            const E e = in[s + i];
+            out[atomicAdd(&s_h[(uint32_t)(e >> sh) & mask], 1u)] = e;
+        }
+        __syncthreads();
+    }
+}
+
+#endif  // __HIPCC__
+
+}  // namespace bdgpart

@@ -1,44 +1,214 @@
 // Distinct-barcode counting on the device (reference BarcodeGraph.index_bc_single_thread,
 // barcode_graph.py:192-204): from the extraction records of a batch, the distinct 16-base
-// barcodes, how often each occurs and where it occurs first (the reference's `counts` dict is in
+// barcodes ascending, how often each occurs and where it occurs first (the reference's `counts` dict is in
 // first-occurrence order, which get_cluster_centers depends on, barcode_graph.py:253-255).
-// Stable LSD radix sort of (33-bit key = unusable << 32 | rank, value = read index) + run-length
-// encode, both from hipCUB; the first element of each run is its first occurrence because the
-// sort is stable.
+//
+// No sort library: the records' (rank, index) pairs are grouped by the rank's top bits in the two bucket levels of
+// bdg_partition.hpp (exact places from counting passes, no atomics on global memory), and a block then sorts one fine
+// bucket - about a thousand pairs - inside LDS as 64-bit words rank << 32 | index (bitonic network), so that equal ranks
+// stand together with their smallest index first: a run's length is the multiplicity, its first element the first
+// occurrence.  Buckets ascend with the rank, so the runs of bucket after bucket are the answer in order; two small passes
+// (sums of the buckets' run counts, copy) close the gaps.  A bucket larger than the LDS capacity - a barcode seen tens of
+// thousands of times, or an adversarial input - is taken apart by the next key bits, eight at a time, with a run of one
+// repeated rank reduced in a streaming pass whatever its length.
 #include "bdg_common.hpp"
-
-#include <hipcub/hipcub.hpp>
+#include "bdg_partition.hpp"
 
 namespace {
 
+constexpr uint32_t DS_CAP = 2048;                // pairs a block sorts in LDS at a time
+constexpr int DS_THREADS = 256;
+constexpr uint32_t DS_PER = DS_CAP / DS_THREADS;
+
+// level 1 (bdg_partition.hpp), run twice over tiles of records: counts per coarse bucket (the rank's top l1 bits), then the
+// pairs at their places.  Records without a usable barcode take no part; out_n[1] counts the 16-base barcodes with a non-ACGT base.
+template <bool EMIT>
 __global__ __launch_bounds__(256)
-void k_distinct_keys(const bdg_extract_rec* __restrict__ recs, uint32_t n,
-                     unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
-                     uint32_t* __restrict__ out_n /* [0] n_uniq (later), [1] barcodes of 16 bases holding a non-ACGT base */)
+void k_distinct_rows(const bdg_extract_rec* __restrict__ recs, uint32_t n, uint32_t per_tile, uint32_t l1,
+                     uint32_t* __restrict__ hist, const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
+                     unsigned long long* __restrict__ ent, uint32_t* __restrict__ out_n)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const bdg_extract_rec r = recs[i];
-    const bool ok = r.valid && (r.flags & BDG_FLAG_RANK_OK);
-    keys[i] = ok ? (unsigned long long)r.bc_rank : (1ull << 32);
-    vals[i] = i;
-    if (r.valid && !ok && (r.flags & BDG_FLAG_BC16)) atomicAdd(&out_n[1], 1u);
+    __shared__ uint32_t s_h[bdgpart::NB1_MAX];
+    const uint32_t nb1 = 1u << l1, sh = 32u - l1;
+    const uint32_t row0 = blockIdx.x * per_tile;
+    const uint32_t row1 = n - row0 < per_tile ? n : row0 + per_tile;
+    if (EMIT && (geom[bdgpart::G_FLAGS] & 1u)) return;
+    for (uint32_t i = threadIdx.x; i < nb1; i += 256u) s_h[i] = EMIT ? (uint32_t)base[i] + hist[(size_t)blockIdx.x * nb1 + i] : 0u;
+    __syncthreads();
+    for (uint32_t i = row0 + threadIdx.x; i < row1; i += 256u) {
+        const bdg_extract_rec r = recs[i];
+        const bool ok = r.valid && (r.flags & BDG_FLAG_RANK_OK);
+        if (ok) {
+            if (EMIT) ent[atomicAdd(&s_h[r.bc_rank >> sh], 1u)] = (unsigned long long)r.bc_rank << 32 | i;
+            else atomicAdd(&s_h[r.bc_rank >> sh], 1u);
+        } else if (!EMIT && r.valid && (r.flags & BDG_FLAG_BC16)) atomicAdd(&out_n[1], 1u);
+    }
+    if (!EMIT) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb1; i += 256u) hist[(size_t)blockIdx.x * nb1 + i] = s_h[i];
+    }
 }
 
-__global__ __launch_bounds__(256)
-void k_distinct_finish(const unsigned long long* __restrict__ ukeys, const uint32_t* __restrict__ ucounts,
-                       const uint32_t* __restrict__ uoffsets, const uint32_t* __restrict__ sorted_vals,
-                       const uint32_t* __restrict__ n_runs,
-                       uint32_t* __restrict__ uniq, uint32_t* __restrict__ count, uint32_t* __restrict__ first,
-                       uint32_t* __restrict__ out_n)
+// One fine bucket per block at a time: its pairs sorted in LDS, the runs (rank, length, first index) written to the
+// bucket's own stretch of the temporary arrays, their number to nuniq[bucket].
+__global__ __launch_bounds__(DS_THREADS)
+void k_distinct_buckets(const unsigned long long* __restrict__ ent, const uint32_t* __restrict__ fstart,
+                        const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom, uint32_t l1,
+                        uint32_t* __restrict__ t_uniq, uint32_t* __restrict__ t_count, uint32_t* __restrict__ t_first,
+                        uint32_t* __restrict__ nuniq)
 {
-    const uint32_t nr = *n_runs;
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j == 0) out_n[0] = (nr && ukeys[nr - 1] >= (1ull << 32)) ? nr - 1 : nr;     // the unusable run sorts last
-    if (j >= nr || ukeys[j] >= (1ull << 32)) return;
-    uniq[j] = (uint32_t)ukeys[j];
-    count[j] = ucounts[j];
-    first[j] = sorted_vals[uoffsets[j]];
+    __shared__ unsigned long long s_e[DS_CAP];
+    __shared__ uint32_t s_head[DS_CAP];
+    __shared__ uint32_t s_hist[4][256];
+    __shared__ uint32_t s_w[DS_THREADS / 64 + 1];
+    __shared__ unsigned long long s_r[4][DS_THREADS / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (geom[bdgpart::G_FLAGS] & 1u) return;
+    const uint32_t l2 = fstart ? geom[bdgpart::G_L2] : 0u;
+    const uint32_t nfb = 1u << (l1 + l2);
+    for (uint32_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
+        const uint32_t start = fstart ? fstart[fb] : (uint32_t)base[fb];
+        const uint32_t cnt = (fstart ? fstart[fb + 1u] : (uint32_t)base[fb + 1u]) - start;
+        uint32_t emitted = 0;
+        // the pairs of [start, start + cnt) whose rank has the top `bits` bits `val` (at most DS_CAP of them): sorted, their runs written
+        auto sort_emit = [&](uint32_t bits, uint32_t val) {
+            if (threadIdx.x == 0) s_w[DS_THREADS / 64] = 0u;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < cnt; i += DS_THREADS) {
+                const unsigned long long e = ent[start + i];
+                if ((uint32_t)(e >> (64u - bits)) == val) s_e[atomicAdd(&s_w[DS_THREADS / 64], 1u)] = e;
+            }
+            __syncthreads();
+            const uint32_t held = s_w[DS_THREADS / 64];
+            uint32_t N = 64;
+            while (N < held) N <<= 1;
+            for (uint32_t i = held + threadIdx.x; i < N; i += DS_THREADS) s_e[i] = ~0ull;
+            __syncthreads();
+            for (uint32_t k = 2; k <= N; k <<= 1)
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t t = threadIdx.x; t < N / 2u; t += DS_THREADS) {
+                        const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
+                        const unsigned long long x = s_e[i], y = s_e[l];
+                        if ((x > y) == ((i & k) == 0u)) { s_e[i] = y; s_e[l] = x; }
+                    }
+                    __syncthreads();
+                }
+            // runs: a thread looks at DS_PER consecutive places
+            uint32_t heads = 0;
+            const uint32_t i0 = threadIdx.x * DS_PER;
+#pragma unroll
+            for (uint32_t j = 0; j < DS_PER; ++j) {
+                const uint32_t i = i0 + j;
+                if (i < held && (i == 0u || (uint32_t)(s_e[i] >> 32) != (uint32_t)(s_e[i - 1u] >> 32))) heads |= 1u << j;
+            }
+            uint32_t nrun;
+            uint32_t at = bdgpart::block_excl_scan<DS_THREADS>((uint32_t)__popc(heads), s_w, nrun);
+#pragma unroll
+            for (uint32_t j = 0; j < DS_PER; ++j) if (heads >> j & 1u) s_head[at++] = i0 + j;
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < nrun; j += DS_THREADS) {
+                const uint32_t i = s_head[j], nxt = j + 1u < nrun ? s_head[j + 1u] : held;
+                const unsigned long long e = s_e[i];
+                const size_t o = (size_t)start + emitted + j;
+                t_uniq[o] = (uint32_t)(e >> 32); t_count[o] = nxt - i; t_first[o] = (uint32_t)e;
+            }
+            emitted += nrun;
+            __syncthreads();
+        };
+        if (cnt == 0u) { if (threadIdx.x == 0) nuniq[fb] = 0u; continue; }
+        if (cnt <= DS_CAP) { sort_emit(l1 + l2, fb); if (threadIdx.x == 0) nuniq[fb] = emitted; continue; }
+        // cold path: the bucket is taken apart by the next key bits, eight at a time (ascending, so the output stays in order)
+        uint32_t st_bits[5], st_val[5], st_next[5], st_w[5];
+        int sp = 0;
+        st_bits[0] = l1 + l2; st_val[0] = fb; st_next[0] = 0xFFFFFFFFu; st_w[0] = 0;
+        while (sp >= 0) {
+            const uint32_t bits = st_bits[sp], val = st_val[sp];
+            if (st_next[sp] == 0xFFFFFFFFu) {
+                // how many pairs this prefix holds, their smallest and largest rank, the smallest index
+                unsigned long long c = 0, kmin = ~0ull, kmax = 0, imin = ~0ull;
+                for (uint32_t i = threadIdx.x; i < cnt; i += DS_THREADS) {
+                    const unsigned long long e = ent[start + i];
+                    if ((uint32_t)(e >> (64u - bits)) != val) continue;
+                    const unsigned long long k = e >> 32, ix = e & 0xFFFFFFFFull;
+                    ++c; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; imin = ix < imin ? ix : imin;
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    c += __shfl_xor(c, d);
+                    const unsigned long long a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d), m = __shfl_xor(imin, d);
+                    kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; imin = m < imin ? m : imin;
+                }
+                if (lane == 0) { s_r[0][wv] = c; s_r[1][wv] = kmin; s_r[2][wv] = kmax; s_r[3][wv] = imin; }
+                __syncthreads();
+                c = 0; kmin = ~0ull; kmax = 0; imin = ~0ull;
+#pragma unroll
+                for (int w = 0; w < DS_THREADS / 64; ++w) {
+                    c += s_r[0][w]; kmin = s_r[1][w] < kmin ? s_r[1][w] : kmin; kmax = s_r[2][w] > kmax ? s_r[2][w] : kmax;
+                    imin = s_r[3][w] < imin ? s_r[3][w] : imin;
+                }
+                __syncthreads();
+                if (c == 0ull) { --sp; continue; }
+                if (kmin == kmax) {                                          // one rank, however often: a run
+                    if (threadIdx.x == 0) { const size_t o = (size_t)start + emitted; t_uniq[o] = (uint32_t)kmin; t_count[o] = (uint32_t)c; t_first[o] = (uint32_t)imin; }
+                    ++emitted; --sp; continue;
+                }
+                if (c <= DS_CAP) { sort_emit(bits, val); --sp; continue; }
+                const uint32_t w = 32u - bits < 8u ? 32u - bits : 8u;            // (bits < 32: two different ranks share this prefix)
+                s_hist[sp][threadIdx.x] = 0u;
+                __syncthreads();
+                for (uint32_t i = threadIdx.x; i < cnt; i += DS_THREADS) {
+                    const unsigned long long e = ent[start + i];
+                    if ((uint32_t)(e >> (64u - bits)) == val) atomicAdd(&s_hist[sp][(uint32_t)(e >> (64u - bits - w)) & ((1u << w) - 1u)], 1u);
+                }
+                __syncthreads();
+                st_next[sp] = 0; st_w[sp] = w;
+            }
+            const uint32_t w = st_w[sp];
+            uint32_t ch = st_next[sp];
+            while (ch < (1u << w) && s_hist[sp][ch] == 0u) ++ch;
+            if (ch == (1u << w)) { --sp; continue; }
+            st_next[sp] = ch + 1u;
+            ++sp;
+            st_bits[sp] = bits + w; st_val[sp] = (val << w) | ch; st_next[sp] = 0xFFFFFFFFu; st_w[sp] = 0;
+        }
+        if (threadIdx.x == 0) nuniq[fb] = emitted;
+    }
+}
+
+// off[b] = runs in the buckets before b (one block; the bucket count is a power of two, read from geom); out_n[0] = all runs
+__global__ __launch_bounds__(1024)
+void k_distinct_offsets(const uint32_t* __restrict__ nuniq, const uint32_t* __restrict__ geom, uint32_t l1, int have_l2,
+                        uint32_t* __restrict__ off, uint32_t* __restrict__ out_n)
+{
+    __shared__ uint32_t s_w[17];
+    if (geom[bdgpart::G_FLAGS] & 1u) return;
+    const uint32_t nfb = 1u << (l1 + (have_l2 ? geom[bdgpart::G_L2] : 0u));
+    const uint32_t per = (nfb + 1023u) / 1024u;
+    const uint32_t b0 = threadIdx.x * per, b1 = b0 + per < nfb ? b0 + per : nfb;
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; ++b) sum += nuniq[b];
+    uint32_t total;
+    uint32_t run = bdgpart::block_excl_scan<1024>(sum, s_w, total);
+    for (uint32_t b = b0; b < b1; ++b) { off[b] = run; run += nuniq[b]; }
+    if (threadIdx.x == 0) out_n[0] = total;
+}
+
+// the runs of bucket after bucket, side by side
+__global__ __launch_bounds__(256)
+void k_distinct_compact(const uint32_t* __restrict__ fstart, const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
+                        uint32_t l1, const uint32_t* __restrict__ nuniq, const uint32_t* __restrict__ off,
+                        const uint32_t* __restrict__ t_uniq, const uint32_t* __restrict__ t_count, const uint32_t* __restrict__ t_first,
+                        uint32_t* __restrict__ uniq, uint32_t* __restrict__ count, uint32_t* __restrict__ first)
+{
+    if (geom[bdgpart::G_FLAGS] & 1u) return;
+    const uint32_t nfb = 1u << (l1 + (fstart ? geom[bdgpart::G_L2] : 0u));
+    // a wave a bucket (a bucket holds about a thousand pairs, fewer runs)
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t fb = blockIdx.x * 4u + (threadIdx.x >> 6); fb < nfb; fb += gridDim.x * 4u) {
+        const uint32_t start = fstart ? fstart[fb] : (uint32_t)base[fb];
+        const uint32_t k = nuniq[fb], o = off[fb];
+        for (uint32_t j = lane; j < k; j += 64u) { uniq[o + j] = t_uniq[start + j]; count[o + j] = t_count[start + j]; first[o + j] = t_first[start + j]; }
+    }
 }
 
 // Observed barcodes that come from a stage-1 TSV (badger.py:91-111) instead of from an extraction: the records the
@@ -105,43 +275,58 @@ int bdg_distinct_launch(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
     hipStream_t st = ctx->stream;
     BDG_HIP_TRY(ctx, hipMemsetAsync(d_n, 0, 8, st));
     if (n == 0) return BDG_OK;
-    size_t t_sort = 0, t_rle = 0, t_scan = 0;
-    unsigned long long* kp = nullptr; uint32_t* vp = nullptr;
-    BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, kp, kp, vp, vp, (int)n, 0, 33, st));
-    BDG_HIP_TRY(ctx, hipcub::DeviceRunLengthEncode::Encode(nullptr, t_rle, kp, kp, vp, vp, (int)n, st));
-    BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, t_scan, vp, vp, (int)n, st));
-    const size_t t_max = std::max(t_sort, std::max(t_rle, t_scan));
-    // workspace: keys in/out (8n each), vals in/out (4n each), unique keys (8n), counts (4n), offsets (4n), n_runs, temp
-    const size_t need = 8ull * n * 3 + 4ull * n * 4 + 256 + t_max;
+    if (!ctx->g_cus) {
+        hipDeviceProp_t prop;
+        BDG_HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->g_cus_distinct = prop.multiProcessorCount;
+    }
+    const uint32_t cus = (uint32_t)(ctx->g_cus ? ctx->g_cus : ctx->g_cus_distinct);
+    // geometry: coarse buckets by the rank's top l1 bits; below about a million records they are the fine buckets already
+    // (no second level), beyond that the device picks the sub-bucket count from the number of usable records
+    uint32_t l1 = 8;
+    while (l1 < 10u && (n >> l1) > DS_CAP / 2u) ++l1;
+    const bool two_levels = (n >> l1) > DS_CAP / 2u;
+    const uint32_t nb1 = 1u << l1, l2_max = two_levels ? 10u : 0u;
+    uint32_t per_tile = ((n + cus * 8u - 1u) / (cus * 8u) + 255u) & ~255u;
+    const uint32_t ntiles = (n + per_tile - 1u) / per_tile;
+    const size_t nfb_max = (size_t)nb1 << l2_max;
+    // workspace: base u64 [nb1 + 1] | pairs u64 [n] twice | hist [ntiles][nb1] | tot | geom | fstart | nuniq | off | temporary runs 3 x [n]
+    const size_t w_hist = (size_t)ntiles * nb1;
+    const size_t need = 8 * ((size_t)nb1 + 1 + 2 * (size_t)n) + 4 * (w_hist + nb1 + bdgpart::G_WORDS + (nfb_max + 1) + 2 * nfb_max + 3 * (size_t)n) + 256;
     int rc;
     if ((rc = bdg_reserve(ctx, ctx->g_tmp1, need))) return rc;
-    char* base = static_cast<char*>(ctx->g_tmp1.p);
-    auto* k_in = reinterpret_cast<unsigned long long*>(base);
-    auto* k_out = k_in + n;
-    auto* u_keys = k_out + n;
-    auto* v_in = reinterpret_cast<uint32_t*>(u_keys + n);
-    auto* v_out = v_in + n;
-    auto* u_cnt = v_out + n;
-    auto* u_off = u_cnt + n;
-    auto* n_runs = u_off + n;
-    void* temp = reinterpret_cast<char*>(n_runs) + 256;
+    auto* base = static_cast<unsigned long long*>(ctx->g_tmp1.p);
+    auto* e_a = base + nb1 + 1;
+    auto* e_b = e_a + n;
+    auto* hist = reinterpret_cast<uint32_t*>(e_b + n);
+    auto* tot = hist + w_hist;
+    auto* geom = tot + nb1;
+    auto* fstart = geom + bdgpart::G_WORDS;
+    auto* nuniq = fstart + nfb_max + 1;
+    auto* off = nuniq + nfb_max;
+    auto* t_uniq = off + nfb_max;
+    auto* t_count = t_uniq + n;
+    auto* t_first = t_count + n;
     {
-        ScopedKernelTimer tm(ctx, "k_distinct_keys");
-        hipLaunchKernelGGL(k_distinct_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_recs, n, k_in, v_in, d_n);
+        ScopedKernelTimer tm(ctx, "k_distinct_rows");
+        hipLaunchKernelGGL(k_distinct_rows<false>, dim3(ntiles), dim3(256), 0, st, d_recs, n, per_tile, l1, hist, base, geom, e_a, d_n);
+        hipLaunchKernelGGL(bdgpart::k_part_colscan, dim3(nb1), dim3(256), 0, st, hist, ntiles, nb1, tot);
+        hipLaunchKernelGGL(bdgpart::k_part_bases, dim3(1), dim3(1024), 0, st, tot, nb1, DS_CAP / 2u, l2_max, (unsigned long long)n, base, geom);
+        hipLaunchKernelGGL(k_distinct_rows<true>, dim3(ntiles), dim3(256), 0, st, d_recs, n, per_tile, l1, hist, base, geom, e_a, d_n);
+        if (two_levels) hipLaunchKernelGGL(bdgpart::k_part_split<unsigned long long>, dim3(nb1), dim3(1024), 0, st, e_a, e_b, base, geom, nb1, 64u - l1, fstart);
     }
     {
-        ScopedKernelTimer tm(ctx, "hipcub_sort_rle_scan");
-        size_t t = t_max;
-        BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(temp, t, k_in, k_out, v_in, v_out, (int)n, 0, 33, st));
-        t = t_max;
-        BDG_HIP_TRY(ctx, hipcub::DeviceRunLengthEncode::Encode(temp, t, k_out, u_keys, u_cnt, n_runs, (int)n, st));
-        t = t_max;
-        BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(temp, t, u_cnt, u_off, (int)n, st));
+        ScopedKernelTimer tm(ctx, "k_distinct_buckets");
+        const uint32_t grid = (uint32_t)std::min<size_t>(nfb_max, (size_t)cus * 6u);
+        hipLaunchKernelGGL(k_distinct_buckets, dim3(grid), dim3(DS_THREADS), 0, st, two_levels ? e_b : e_a, two_levels ? fstart : nullptr, base, geom, l1,
+                           t_uniq, t_count, t_first, nuniq);
     }
     {
         ScopedKernelTimer tm(ctx, "k_distinct_finish");
-        hipLaunchKernelGGL(k_distinct_finish, dim3((n + 255) / 256), dim3(256), 0, st, u_keys, u_cnt, u_off, v_out, n_runs,
-                           d_uniq, d_count, d_first, d_n);
+        hipLaunchKernelGGL(k_distinct_offsets, dim3(1), dim3(1024), 0, st, nuniq, geom, l1, two_levels ? 1 : 0, off, d_n);
+        const uint32_t grid = (uint32_t)std::min<size_t>((nfb_max + 3) / 4, (size_t)cus * 8u);
+        hipLaunchKernelGGL(k_distinct_compact, dim3(grid), dim3(256), 0, st, two_levels ? fstart : nullptr, base, geom, l1, nuniq, off,
+                           t_uniq, t_count, t_first, d_uniq, d_count, d_first);
     }
     BDG_HIP_TRY(ctx, hipGetLastError());
     return BDG_OK;

@@ -20,6 +20,8 @@
 //
 // k_graph_qjoin (thr >= 2): the device form of the reference's QGramIndex, see further down.
 #include "bdg_common.hpp"
+#include "bdg_partition.hpp"
+#include "dj_codec.hpp"
 
 #include <hipcub/hipcub.hpp>
 
@@ -871,10 +873,12 @@ __device__ __forceinline__ uint32_t d2_part(uint32_t k, uint32_t nparts)
 // fingerprint lost the slot to a different 14-mer - so did every other holder of its own 14-mer, and those few lanes
 // (about three a row) compare among themselves.
 constexpr uint32_t D2_SLOTS = 1024;
-constexpr uint32_t D2_ECAP = 512;                // staged edges per wave in k_d2_pairs
-constexpr unsigned long long D2_ROUND_ENTRIES = 1500000000ull;      // index entries (estimated at 80 a row) per round of the join
+constexpr unsigned long long D2_ROUND_ENTRIES = 1000000000ull;      // index entries (estimated at 72 / 12 a row) per round of the join
+constexpr int DJ_THREADS = 512;                  // k_d2_pairs: threads of a block,
+constexpr uint32_t DJ_CAP = 2048;                // entries of a fine bucket it holds in LDS at a time (>= the largest group: 1920),
+constexpr uint32_t DJ_ECAPW = 256;               // edges a wave stages before it reserves output
 
-struct D2Row { uint32_t k0, k1; bool keep0, keep1; };
+struct D2Row { uint32_t k0, k1, z0, z1; bool keep0, keep1; };      // the lane's two 14-mers, their mixed keys, which stay
 
 __device__ __forceinline__ D2Row d2_row(uint32_t r, int lane, uint32_t pq0, uint32_t pq1, uint32_t* __restrict__ tab,
                                         uint32_t part, uint32_t nparts)
@@ -896,8 +900,9 @@ __device__ __forceinline__ D2Row d2_row(uint32_t r, int lane, uint32_t pq0, uint
     for (uint32_t i = 0; i < D2_SLOTS / 4u / 64u; ++i) tab4[i * 64u + (uint32_t)lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
     __builtin_amdgcn_wave_barrier();
     // (a row's 14-mers agree in their low letters whenever both deletions lie behind them: the slot must come from all 28 bits)
-    auto mix = [](uint32_t k) { uint32_t x = (k * 0x9E3779B1u) & 0x0FFFFFFFu; x ^= x >> 15; return (x * 0x85EBCA6Bu) & 0x0FFFFFFFu; };
-    const uint32_t x0 = mix(o.k0), x1 = mix(o.k1);
+    // (the same mixed key names the entry's bucket afterwards, dj_codec.hpp)
+    const uint32_t x0 = djc::mix<28>(o.k0), x1 = djc::mix<28>(o.k1 & 0x0FFFFFFFu);
+    o.z0 = x0; o.z1 = x1;
     const uint32_t mine0 = (uint32_t)lane << 18 | (x0 & 0x3FFFFu), mine1 = (uint32_t)(64 + lane) << 18 | (x1 & 0x3FFFFu);
     if (keep0) atomicMin(&tab[x0 >> 18], mine0);
     if (keep1) atomicMin(&tab[x1 >> 18], mine1);
@@ -927,58 +932,6 @@ __device__ __forceinline__ D2Row d2_row(uint32_t r, int lane, uint32_t pq0, uint
     }
     o.keep0 = keep0; o.keep1 = keep1;
     return o;
-}
-
-// pass 1: how many entries a row has (the exclusive sums of these are where pass 2 writes them)
-__global__ __launch_bounds__(256)
-void k_d2_count(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, uint32_t nparts, uint32_t* __restrict__ count)
-{
-    __shared__ uint32_t s_tab[4][D2_SLOTS];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t wave = blockIdx.x * 4u + (uint32_t)wv, nwaves = gridDim.x * 4u;
-    const uint32_t pq0 = d2_table.pq[lane], pq1 = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
-    // a wave takes up to 64 consecutive rows at a time (fewer when there are not that many rows per wave): one coalesced load
-    // of their barcodes, one coalesced store of their counts instead of a load per row that everything else waits for
-    const uint32_t G = n / nwaves >= 64u ? 64u : (n / nwaves ? n / nwaves : 1u);
-    for (unsigned long long base = (unsigned long long)wave * G; base < n; base += (unsigned long long)nwaves * G) {
-        const uint32_t mine = (uint32_t)lane < G && base + (uint32_t)lane < n ? ranks[base + (uint32_t)lane] : 0u;
-        const uint32_t rows = n - base < G ? (uint32_t)(n - base) : G;
-        uint32_t my_count = 0;
-        for (uint32_t i = 0; i < rows; ++i) {
-            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)i);
-            const D2Row o = d2_row(r, lane, pq0, pq1, s_tab[wv], part, nparts);
-            const uint32_t c = (uint32_t)__popcll(__ballot(o.keep0)) + (uint32_t)__popcll(__ballot(o.keep1));
-            if ((uint32_t)lane == i) my_count = c;
-        }
-        if ((uint32_t)lane < rows) count[base + (uint32_t)lane] = my_count;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) count[n] = 0u;              // (its exclusive sum is the number of entries)
-}
-
-// pass 2: the entries, a row's side by side
-__global__ __launch_bounds__(256)
-void k_d2_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, uint32_t nparts, const uint32_t* __restrict__ offset,
-               unsigned long long* __restrict__ ent)
-{
-    __shared__ uint32_t s_tab[4][D2_SLOTS];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t wave = blockIdx.x * 4u + (uint32_t)wv, nwaves = gridDim.x * 4u;
-    const uint32_t pq0 = d2_table.pq[lane], pq1 = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
-    const uint32_t G = n / nwaves >= 64u ? 64u : (n / nwaves ? n / nwaves : 1u);          // (as in k_d2_count)
-    for (unsigned long long base0 = (unsigned long long)wave * G; base0 < n; base0 += (unsigned long long)nwaves * G) {
-        const bool mine_ok = (uint32_t)lane < G && base0 + (uint32_t)lane < n;
-        const uint32_t mine = mine_ok ? ranks[base0 + (uint32_t)lane] : 0u;
-        const uint32_t mine_at = mine_ok ? offset[base0 + (uint32_t)lane] : 0u;
-        const uint32_t rows = n - base0 < G ? (uint32_t)(n - base0) : G;
-        for (uint32_t i = 0; i < rows; ++i) {
-            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)i);
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)mine_at, (int)i);
-            const D2Row o = d2_row(r, lane, pq0, pq1, s_tab[wv], part, nparts);
-            const unsigned long long m0 = __ballot(o.keep0), m1 = __ballot(o.keep1);
-            if (o.keep0) ent[base + lanes_below_u64(m0, lane)] = (unsigned long long)o.k0 << 32 | r;
-            if (o.keep1) ent[base + (uint32_t)__popcll(m0) + lanes_below_u64(m1, lane)] = (unsigned long long)o.k1 << 32 | r;
-        }
-    }
 }
 
 // r without its base p: a 15-mer in 30 bits
@@ -1065,167 +1018,243 @@ __device__ __forceinline__ int d1_reports(uint32_t a, uint32_t b, uint32_t k)
     return 0;
 }
 
-// the one-deletion 15-mers of a row: deleting any letter of a run gives the same 15-mer, so the first letter of every run is
-// deleted - exactly the distinct ones (about 12 of 16 on random barcodes).  One thread a row; count, then write.
+// ---- level 1 of the grouping (bdg_partition.hpp): a tile of rows per block, run twice.  EMIT = false: how many entries
+// the tile has for each coarse bucket (the top l1 bits of the variant's mixed key); EMIT = true: the entries, each at its
+// bucket's cursor (the tile's place inside the bucket, from the counts of all tiles).  The two runs see the same rows and
+// drop the same repeats, so the places are exact: no atomic on global memory, nothing to size by guessing.
+// thr <= 2: one wave per row at a time (d2_row), up to 64 consecutive rows per coalesced load of their barcodes.
+template <bool EMIT>
 __global__ __launch_bounds__(256)
-void k_d1_count(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, uint32_t nparts, uint32_t* __restrict__ count)
+void k_d2_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per_tile, uint32_t part, uint32_t nparts, uint32_t l1,
+               uint32_t* __restrict__ hist, const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
+               uint32_t* __restrict__ ent)
 {
-    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
-    if (row == 0) count[n] = 0u;
-    if (row >= n) return;
-    const uint32_t r = ranks[row];
-    const uint32_t diff = r ^ (r << 2);
-    const uint32_t first = ((diff | (diff >> 1)) & 0x55555554u) | 1u;
-    uint32_t c = 0;
-    if (nparts == 1u) c = (uint32_t)__popc(first);
-    else for (uint32_t p = 0; p < 16u; ++p) c += ((first >> (2u * p)) & 1u) && d2_part(d1_key(r, p), nparts) == part ? 1u : 0u;
-    count[row] = c;
-}
-__global__ __launch_bounds__(256)
-void k_d1_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t part, uint32_t nparts, const uint32_t* __restrict__ offset,
-               unsigned long long* __restrict__ ent)
-{
-    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
-    if (row >= n) return;
-    const uint32_t r = ranks[row];
-    const uint32_t diff = r ^ (r << 2);
-    const uint32_t first = ((diff | (diff >> 1)) & 0x55555554u) | 1u;
-    uint32_t at = offset[row];
-    for (uint32_t p = 0; p < 16u; ++p) {
-        if (!((first >> (2u * p)) & 1u)) continue;
-        const uint32_t k = d1_key(r, p);
-        if (nparts > 1u && d2_part(k, nparts) != part) continue;
-        ent[at++] = (unsigned long long)k << 32 | r;
+    __shared__ uint32_t s_tab[4][D2_SLOTS];
+    __shared__ uint32_t s_h[bdgpart::NB1_MAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t nb1 = 1u << l1, zb = 28u - l1;
+    const uint32_t row0 = blockIdx.x * rows_per_tile;
+    const uint32_t row1 = n - row0 < rows_per_tile ? n : row0 + rows_per_tile;
+    if (EMIT && (geom[bdgpart::G_FLAGS] & 1u)) return;                 // (more entries than the caller can index: it cuts smaller)
+    for (uint32_t i = threadIdx.x; i < nb1; i += 256u) s_h[i] = EMIT ? (uint32_t)base[i] + hist[(size_t)blockIdx.x * nb1 + i] : 0u;
+    __syncthreads();
+    const uint32_t pq0 = d2_table.pq[lane], pq1 = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
+    for (uint32_t chunk = row0 + (uint32_t)wv * 64u; chunk < row1; chunk += 256u) {
+        const uint32_t rows = row1 - chunk < 64u ? row1 - chunk : 64u;
+        const uint32_t mine = (uint32_t)lane < rows ? ranks[chunk + (uint32_t)lane] : 0u;
+        for (uint32_t i = 0; i < rows; ++i) {
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)i);
+            const D2Row o = d2_row(r, lane, pq0, pq1, s_tab[wv], part, nparts);
+            if (EMIT) {
+                if (o.keep0) ent[atomicAdd(&s_h[o.z0 >> zb], 1u)] = djc::enc2(o.z0, zb, (uint32_t)lane, r, pq0);
+                if (o.keep1) ent[atomicAdd(&s_h[o.z1 >> zb], 1u)] = djc::enc2(o.z1, zb, 64u + (uint32_t)lane, r, pq1);
+            } else {
+                if (o.keep0) atomicAdd(&s_h[o.z0 >> zb], 1u);
+                if (o.keep1) atomicAdd(&s_h[o.z1 >> zb], 1u);
+            }
+        }
+    }
+    if (!EMIT) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb1; i += 256u) hist[(size_t)blockIdx.x * nb1 + i] = s_h[i];
     }
 }
 
-// NDEL = 2: the deletion-variant join of thr 2 (14-mers).  NDEL = 1: the same walk over one-deletion 15-mers for thr 1, where
-// rules 1 and 2 of d1_reports are complete and a meeting they do not name is no edge.
-template <int NDEL>
+// thr <= 1: the one-deletion 15-mers of a row.  Deleting any letter of a run gives the same 15-mer, so the first letter of
+// every run is deleted - exactly the distinct ones (about 12 of 16 on random barcodes).  One thread a row.
+template <bool EMIT>
 __global__ __launch_bounds__(256)
-void k_d2_pairs(const unsigned long long* __restrict__ ent, unsigned long long m,
+void k_d1_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per_tile, uint32_t part, uint32_t nparts, uint32_t l1,
+               uint32_t* __restrict__ hist, const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
+               uint32_t* __restrict__ ent)
+{
+    __shared__ uint32_t s_h[bdgpart::NB1_MAX];
+    const uint32_t nb1 = 1u << l1, zb = 30u - l1;
+    const uint32_t row0 = blockIdx.x * rows_per_tile;
+    const uint32_t row1 = n - row0 < rows_per_tile ? n : row0 + rows_per_tile;
+    if (EMIT && (geom[bdgpart::G_FLAGS] & 1u)) return;
+    for (uint32_t i = threadIdx.x; i < nb1; i += 256u) s_h[i] = EMIT ? (uint32_t)base[i] + hist[(size_t)blockIdx.x * nb1 + i] : 0u;
+    __syncthreads();
+    for (uint32_t row = row0 + threadIdx.x; row < row1; row += 256u) {
+        const uint32_t r = ranks[row];
+        const uint32_t diff = r ^ (r << 2);
+        const uint32_t first = ((diff | (diff >> 1)) & 0x55555554u) | 1u;
+#pragma unroll
+        for (uint32_t p = 0; p < 16u; ++p) {
+            if (!((first >> (2u * p)) & 1u)) continue;
+            const uint32_t k = d1_key(r, p);
+            if (nparts > 1u && d2_part(k, nparts) != part) continue;
+            const uint32_t z = djc::mix<30>(k);
+            if (EMIT) ent[atomicAdd(&s_h[z >> zb], 1u)] = djc::enc1(z, zb, p, r);
+            else atomicAdd(&s_h[z >> zb], 1u);
+        }
+    }
+    if (!EMIT) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb1; i += 256u) hist[(size_t)blockIdx.x * nb1 + i] = s_h[i];
+    }
+}
+
+// ---- the consumer: one fine bucket at a time in LDS.
+// A fine bucket holds the entries whose mixed keys share their top l1 + l2 bits - whole groups, about a thousand entries.
+// The block finishes the grouping there: a counting pass over NBIN bins named by the next key bits (an LDS atomic gives an
+// entry its place inside its bin, no order is needed), then every entry meets the entries behind it in its bin.  A bin is
+// mostly one group; where two variants share a bin the meeting ends at one compare.  The walk itself is round 3's: a wave
+// takes 64 consecutive places, lane l's entry meets the L_l entries behind it, and the wave walks the SUM of the meetings
+// 64 at a time (a meeting's owner is found in the running sums), so lanes stay full whatever the group sizes; which group
+// reports a pair is a function of the two barcodes (d2_reports / d1_reports); only meetings that would report are verified
+// (the same Myers dmin3 and the same S >= T as on every other path), 64 at a time out of a per-wave queue.
+// A bucket larger than CAP (the hash spreads keys evenly, so this is for adversarial inputs) is taken in shares of the low
+// key bits, each share through the same code; a group never exceeds 1920 (thr <= 2) / 64 (thr <= 1) entries, CAP >= 2048.
+template <int NDEL, int THREADS, uint32_t CAP, uint32_t ECAPW>
+__global__ __launch_bounds__(THREADS)
+void k_d2_pairs(const uint32_t* __restrict__ ent, const uint32_t* __restrict__ fstart, uint32_t* __restrict__ geom, uint32_t l1,
                 const uint32_t* __restrict__ ranks, uint32_t row_begin, uint32_t row_end, uint32_t thr, int32_t T,
                 bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges)
 {
-    __shared__ EdgeStageT<D2_ECAP> stages[4];
-    __shared__ uint32_t s_cnt[4];
+    constexpr int KB = NDEL == 2 ? 28 : 30;
+    constexpr int NW = THREADS / 64;
+    constexpr uint32_t NBIN = CAP, LBIN = 31u - (uint32_t)__builtin_clz(CAP), PER = NBIN / THREADS;
+    static_assert((CAP & (CAP - 1u)) == 0u && CAP >= 2048u && NBIN % THREADS == 0u, "CAP: a power of two that holds the largest group");
+    __shared__ uint32_t s_k[CAP], s_v[CAP];
+    __shared__ uint32_t s_bin[NBIN + 1];
+    __shared__ EdgeStageT<ECAPW> stages[NW];
+    __shared__ uint32_t s_qa[NW][128], s_qb[NW][128];
+    __shared__ uint32_t s_incl[NW][64];
+    __shared__ uint32_t s_cnt[NW], s_w[NW + 1];
     __shared__ unsigned long long s_base;
-    __shared__ uint32_t s_incl[4][64], s_val[4][64], s_key[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t ne = 0, qn = 0;
+    const uint32_t flags = geom[bdgpart::G_FLAGS];
+    const uint32_t l2 = geom[bdgpart::G_L2];
+    const uint32_t nfb = (flags & 1u) ? 0u : 1u << (l1 + l2);
+    const uint32_t zb = (uint32_t)KB - l1;                              // key bits an entry carries
+    const uint32_t rb = zb - l2;                                        // ... of which these are not spelled by the fine bucket
+    const uint32_t lb = rb < LBIN ? rb : LBIN, bin_sh = rb - lb, bin_mask = (1u << lb) - 1u;
     const uint32_t rank_lo = ranks[row_begin], rank_hi = ranks[row_end - 1u];       // (row_begin < row_end: the launcher's check)
-    // meetings waiting for their verification: a, b; the queue lives across the windows
-    __shared__ uint32_t s_qa[4][128], s_qb[4][128];
     auto verify = [&](uint32_t a, uint32_t b, bool act) {
         const uint32_t d = act ? dmin3(a, b) : 99u;
         bool edge = d <= thr;
         if (__ballot(edge)) edge = edge && (int32_t)qgram_S(a, b) >= T;
         edge_push(edge, a, b, d, stages[wv], ne, lane, out, cap, n_edges);
     };
-    // resident grid, the windows interleaved over its waves: a wave reserves output when its stage is full and once at the end
-    // (one reservation per window - returning atomics on one address complete ~11 ns apart - would cost more than the kernel)
-    const unsigned long long nwin = (m + 63ull) / 64ull;
-    for (unsigned long long win = (unsigned long long)blockIdx.x * 4ull + (unsigned long long)wv; win < nwin; win += (unsigned long long)gridDim.x * 4ull) {
-    const unsigned long long wave_base = win * 64ull;
-    const unsigned long long e = wave_base + (unsigned long long)lane;
-    const bool have = e < m;
-    const unsigned long long mine = have ? ent[e] : 0xFFFFFFFF00000000ull;       // 14-mer in the high half, the row's barcode in the low one
-    const uint32_t k = (uint32_t)(mine >> 32);
-    const uint32_t v = (uint32_t)mine;
-    // entries behind this one in its group.  Inside the wave's 64 entries that is the distance to the group's last lane
-    // (groups are contiguous); only a group that runs past lane 63 looks into memory for its end (a 14-mer has at most
-    // 120 * 16 = 1920 parents: fewer than 2^11 entries)
-    const unsigned long long next_base = wave_base + 64ull;
-    const uint32_t kb = k;
-    const uint32_t k_after = next_base < m ? (uint32_t)(ent[next_base] >> 32) : 0xFFFFFFFEu;           // (matches no key and no padding)
-    const uint32_t k_down = (uint32_t)__shfl_down((int)kb, 1);
-    const uint32_t k_next = lane == 63 ? k_after : k_down;
-    const unsigned long long ends = __ballot(!have || kb != k_next);                 // lanes that end a group
-    const unsigned long long rest = ends >> lane;
-    uint32_t L = rest ? (uint32_t)__builtin_ctzll(rest) : 63u - (uint32_t)lane;
-    if (__ballot(have && rest == 0ull)) {                                             // the last group continues behind the window
-        const uint32_t k63 = (uint32_t)__builtin_amdgcn_readlane((int)kb, 63);
-        // how far: doubling steps until an entry of another bucket (or the end) is met, then halving ones - a bucket that
-        // ends a few entries behind the window, as nearly all do, costs two or three look-ups (all lanes ask alike)
-        auto same = [&](uint32_t t) {
-            const unsigned long long j = wave_base + 63ull + t;
-            return j < m && (uint32_t)(ent[j] >> 32) == k63;
-        };
-        uint32_t tail = 0;
-        if (same(1u)) {
-            uint32_t hi = 2;
-            while (hi < (1u << 12) && same(hi)) hi <<= 1;
-            tail = hi >> 1;
-            for (uint32_t s = hi >> 2; s >= 1; s >>= 1) if (same(tail + s)) tail += s;
-        }
-        if (rest == 0ull) L += tail;
-    }
-    if (!have) L = 0;
-    uint32_t incl = L;
+    // the entries of [start, start + cnt) whose low sb key bits spell `share` (sb = 0: all of them), at most CAP: into the
+    // bins, then the walk
+    auto process = [&](uint32_t start, uint32_t cnt, uint32_t b1, uint32_t sb, uint32_t share) {
+        const uint32_t smask = (1u << sb) - 1u;
 #pragma unroll
-    for (int s = 1; s < 64; s <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, s); if (lane >= s) incl += o; }
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    s_incl[wv][lane] = incl; s_val[wv][lane] = v; s_key[wv][lane] = k;
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t x0 = 0; x0 < total; x0 += 64u) {
-        const uint32_t x = x0 + (uint32_t)lane;
-        const bool act = x < total;
-        uint32_t o = 0;                                            // owner: the number of lanes whose running sum is <= x
+        for (uint32_t j = 0; j < PER; ++j) s_bin[threadIdx.x * PER + j] = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt; i += THREADS) {
+            const uint32_t e = ent[start + i];
+            if ((e & smask) == share) atomicAdd(&s_bin[(e >> bin_sh) & bin_mask], 1u);
+        }
+        __syncthreads();
+        uint32_t c[PER], sum = 0;
 #pragma unroll
-        for (uint32_t s = 32; s >= 1; s >>= 1) if (s_incl[wv][o + s - 1u] <= x) o += s;
-        o = act ? o : 0u;
-        const uint32_t before = o ? s_incl[wv][o - 1u] : 0u;
-        const unsigned long long e2 = wave_base + o + (x - before) + 1ull;
-        uint32_t a = 0, b = 0, kk = 0;
-        bool on = false;
-        if (act) {
-            // (an entry carries the barcode itself - ranks ascend with the rows, so the smaller one is the lower row - and a
-            // meeting costs no look-up into the rank array: at 16 M rows those were a random 64-byte sector each)
-            const uint32_t v1 = s_val[wv][o], v2 = (uint32_t)ent[e2];
-            const bool lower = v1 < v2;                            // (a row has one entry per 14-mer: v1 != v2)
-            a = lower ? v1 : v2; b = lower ? v2 : v1;
-            kk = s_key[wv][o];
-            on = a >= rank_lo && a <= rank_hi;
+        for (uint32_t j = 0; j < PER; ++j) { c[j] = s_bin[threadIdx.x * PER + j]; sum += c[j]; }
+        uint32_t held;
+        uint32_t run = bdgpart::block_excl_scan<THREADS>(sum, s_w, held);
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) { s_bin[threadIdx.x * PER + j] = run; run += c[j]; }
+        if (threadIdx.x == 0) s_bin[NBIN] = held;
+        __syncthreads();
+        // (held <= CAP: the caller's check)  second pass: decode, and place every entry - the bins' starts count up to their ends
+        for (uint32_t i = threadIdx.x; i < cnt; i += THREADS) {
+            const uint32_t e = ent[start + i];
+            if ((e & smask) != share) continue;
+            const uint32_t at = atomicAdd(&s_bin[(e >> bin_sh) & bin_mask], 1u);
+            uint32_t k, r;
+            if (NDEL == 2) djc::dec2(e, b1, zb, d2_table.pq[(e >> zb) & 127u], k, r); else djc::dec1(e, b1, zb, k, r);
+            s_k[at] = k; s_v[at] = r;
         }
-        // A pair meets in several groups and is reported from one of them; which one is asked first (a few dozen
-        // instructions), and only the meetings that would report go on to the verification (dmin and S, some hundred), 64 at a
-        // time out of a queue - on dense data four meetings of five end here
-        const int rep = on ? (NDEL == 2 ? d2_reports(a, b, kk) : d1_reports(a, b, kk)) : 0;
-        const unsigned long long mq = __ballot(rep != 0);
-        if (rep != 0) {
-            const uint32_t at = qn + lanes_below_u64(mq, lane);
-            s_qa[wv][at] = a; s_qb[wv][at] = b;
-        }
-        qn += (uint32_t)__popcll(mq);
-        __builtin_amdgcn_wave_barrier();
-        if (qn >= 64u) {
-            qn -= 64u;
-            verify(s_qa[wv][qn + lane], s_qb[wv][qn + lane], true);
+        __syncthreads();
+        // now s_bin[b] = END of bin b (= start of bin b + 1); an entry's place inside its bin is its place minus the start
+        for (uint32_t wbase = (uint32_t)wv * 64u; wbase < held; wbase += (uint32_t)NW * 64u) {
+            const uint32_t pos = wbase + (uint32_t)lane;
+            const bool have = pos < held;
+            const uint32_t k = have ? s_k[pos] : 0u;
+            const uint32_t bin = (djc::mix<KB>(k) >> bin_sh) & bin_mask;
+            const uint32_t L = have ? s_bin[bin] - pos - 1u : 0u;       // entries behind this one in its bin
+            const uint32_t incl = wave_incl_scan(L);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (total == 0u) continue;
+            s_incl[wv][lane] = incl;
             __builtin_amdgcn_wave_barrier();
+            for (uint32_t x0 = 0; x0 < total; x0 += 64u) {
+                const uint32_t x = x0 + (uint32_t)lane;
+                const bool act = x < total;
+                uint32_t o = 0;                                        // owner: the number of lanes whose running sum is <= x
+#pragma unroll
+                for (uint32_t s = 32; s >= 1; s >>= 1) if (s_incl[wv][o + s - 1u] <= x) o += s;
+                o = act ? o : 0u;
+                const uint32_t before = o ? s_incl[wv][o - 1u] : 0u;
+                const uint32_t p1 = wbase + o, p2 = p1 + (x - before) + 1u;
+                uint32_t a = 0, b = 0, kk = 0;
+                bool on = false;
+                if (act) {
+                    kk = s_k[p1];
+                    if (kk == s_k[p2]) {                               // (the same variant, not just the same bin)
+                        const uint32_t v1 = s_v[p1], v2 = s_v[p2];
+                        const bool lower = v1 < v2;                    // (a row has one entry per variant: v1 != v2)
+                        a = lower ? v1 : v2; b = lower ? v2 : v1;
+                        on = a >= rank_lo && a <= rank_hi;
+                    }
+                }
+                const int rep = on ? (NDEL == 2 ? d2_reports(a, b, kk) : d1_reports(a, b, kk)) : 0;
+                const unsigned long long mq = __ballot(rep != 0);
+                if (rep != 0) {
+                    const uint32_t at = qn + lanes_below_u64(mq, lane);
+                    s_qa[wv][at] = a; s_qb[wv][at] = b;
+                }
+                qn += (uint32_t)__popcll(mq);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= 64u) {
+                    qn -= 64u;
+                    verify(s_qa[wv][qn + lane], s_qb[wv][qn + lane], true);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                             // (the window's running sums are rewritten next)
         }
-    }
-    __builtin_amdgcn_wave_barrier();                                 // (the window's LDS rows are rewritten next)
+        __syncthreads();                                                 // (the bucket's arrays are rewritten next)
+    };
+    for (uint32_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
+        const uint32_t start = fstart[fb], cnt = fstart[fb + 1u] - start;
+        if (cnt < 2u) continue;
+        const uint32_t b1 = fb >> l2;
+        if (cnt <= CAP) { process(start, cnt, b1, 0u, 0u); continue; }
+        // cold path: shares by the low sb key bits, sb grown until every share fits (counted first: a share is walked once)
+        uint32_t sb = 1;
+        while ((cnt >> sb) > CAP / 2u && sb < LBIN) ++sb;
+        bool fits = false;
+        for (; sb <= LBIN && !fits; ++sb) {
+            for (uint32_t i = threadIdx.x; i < (1u << sb); i += THREADS) s_k[i] = 0u;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < cnt; i += THREADS) atomicAdd(&s_k[ent[start + i] & ((1u << sb) - 1u)], 1u);
+            __syncthreads();
+            uint32_t worst = 0;
+            for (uint32_t i = threadIdx.x; i < (1u << sb); i += THREADS) worst = s_k[i] > worst ? s_k[i] : worst;
+            fits = __syncthreads_or(worst > CAP) == 0;
+        }
+        if (!fits) { if (threadIdx.x == 0) atomicOr(&geom[bdgpart::G_FLAGS], 2u); continue; }       // (reported by the launcher's caller)
+        --sb;
+        for (uint32_t share = 0; share < (1u << sb); ++share) process(start, cnt, b1, sb, share);
     }
     if (qn) {
         const bool act = (uint32_t)lane < qn;
         verify(act ? s_qa[wv][lane] : 0u, act ? s_qb[wv][lane] : 1u, act);
     }
-    edge_finish<4>(stages, ne, s_cnt, &s_base, out, cap, n_edges);
+    edge_finish<NW>(stages, ne, s_cnt, &s_base, out, cap, n_edges);
 }
 
 }  // namespace
 
 // ---------------------------------------------------------------------------
-static uint32_t d2_emit_blocks_per_cu()
-{
-    static const uint32_t v = [] { const char* e = getenv("BADGER_AMD_D2_EMIT_BLOCKS"); const int x = e ? atoi(e) : 8; return (uint32_t)(x < 1 ? 1 : (x > 8 ? 8 : x)); }();
-    return v;                                                          // (16 KB of LDS a block; measured 2 / 4 / 6 / 8: 0.53 / 0.34 / 0.28 / 0.25 ms at 500 K rows)
-}
-
 static uint32_t d2_pairs_blocks_per_cu()
 {
-    static const uint32_t v = [] { const char* e = getenv("BADGER_AMD_D2_PAIRS_BLOCKS"); const int x = e ? atoi(e) : 8; return (uint32_t)(x < 1 ? 1 : (x > 8 ? 8 : x)); }();
-    return v;                                                          // (22 KB of LDS a block; measured 2 / 4 / 6 / 8: 1.23 / 1.00 / 0.94 / 0.86 ms at 500 K rows)
+    static const uint32_t v = [] { const char* e = getenv("BADGER_AMD_D2_PAIRS_BLOCKS"); const int x = e ? atoi(e) : 3; return (uint32_t)(x < 1 ? 1 : (x > 8 ? 8 : x)); }();
+    return v;                                                          // (53 KB of LDS a block of 8 waves: three fit a compute unit)
 }
 
 // once per context: the device's compute units and how many blocks of the join kernels a unit holds (resident grids are sized from these)
@@ -1249,6 +1278,22 @@ static int graph_props(bdg_ctx* ctx)
         ctx->g_cus = prop.multiProcessorCount; ctx->g_qj_per_cu = per_cu < 1 ? 1 : per_cu; ctx->g_qjw_per_cu = per_cu_w < 1 ? 1 : per_cu_w;
     }
     return BDG_OK;
+}
+
+// what the join kernels of the last launch reported (waits for the stream): bit 0 - a round held more entries than can be
+// indexed, bit 1 - a fine bucket could not be taken apart (2048 shares of its low key bits, one of them above the LDS capacity)
+int bdg_graph_join_flags(bdg_ctx* ctx, uint32_t* flags)
+{
+    *flags = 0;
+    if (!ctx->g_dj_geom) return BDG_OK;
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(flags, ctx->g_dj_geom + bdgpart::G_FLAGS, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDG_OK;
+}
+int bdg_graph_flags_error(bdg_ctx* ctx, uint32_t flags)
+{
+    if (flags & 1u) return bdg_fail(ctx, BDG_E_CAPACITY, "deletion-variant join: a round holds more entries than 32 bits index (set BADGER_AMD_D2_ROUNDS higher)");
+    return bdg_fail(ctx, BDG_E_CAPACITY, "deletion-variant join: a bucket of variants could not be taken apart");
 }
 
 // which path bdg_graph_launch takes: 1 all-pairs sweep, 2 neighbourhood probes, 3 / 4 q-gram join, 5 / 6 deletion-variant join
@@ -1285,69 +1330,86 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
     if (ctx->graph_algo == 6 && thr > 1) return bdg_fail(ctx, BDG_E_ARG, "the one-deletion join needs thr <= 1");
     if (nparts == 0 || part >= nparts) return bdg_fail(ctx, BDG_E_ARG, "part outside [0, nparts)");
     if (d2join) {
-        // entries: about 71 per row on random barcodes, 120 at most.  Counted first (pass 1), so that every row knows where
-        // its entries go and the buffers are sized exactly.  A large input is taken in several rounds, each over its share of
-        // the 14-mer groups (the same cut that gives several GPUs their parts): the index of a round stays below 2^31 entries
-        // (16 bytes each while it is sorted), whatever n is.
+        // entries: about 71 per row on random barcodes, 120 at most (one deletion: 12, 16 at most).  They are grouped by
+        // their variant in two bucket levels and one pass in LDS (bdg_partition.hpp, k_d2_pairs) - no sort, no count the host
+        // waits for: the buffers hold the most a round can emit, the fine bucket count is chosen on the device from the true
+        // total.  A large input is taken in several rounds, each over its share of the variant groups (the same cut that
+        // gives several GPUs their parts), so that a round's entries can be indexed with 32 bits whatever n is.
         auto* cnt = reinterpret_cast<unsigned long long*>(d_n_edges);
         if ((rc = graph_props(ctx))) return rc;
-        uint32_t rounds = (uint32_t)(((unsigned long long)n * (one_deletion ? 16ull : 80ull) / nparts + D2_ROUND_ENTRIES - 1) / D2_ROUND_ENTRIES);
+        const unsigned long long per_row_max = one_deletion ? 16ull : 120ull, per_row_est = one_deletion ? 12ull : 72ull;
+        // rounds: so that a round expects at most D2_ROUND_ENTRIES entries.  Its buffers hold whatever it can emit - every
+        // entry of every row - up to what 32 bits index; only beyond that (thr 2: from 35 M rows on) can a round's share of
+        // the groups fail to fit, which the device reports (geom flags) and the loop below asks after each such round.
+        uint32_t rounds = (uint32_t)(((unsigned long long)n * per_row_est / nparts + D2_ROUND_ENTRIES - 1) / D2_ROUND_ENTRIES);
         if (const char* e = getenv("BADGER_AMD_D2_ROUNDS")) rounds = (uint32_t)std::max(1, atoi(e));      // (for tests)
         if (rounds < 1) rounds = 1;
         if ((unsigned long long)nparts * rounds > 0xFFFFFFFFull) return bdg_fail(ctx, BDG_E_ARG, "too many parts");
+        const uint32_t keybits = one_deletion ? 30u : 28u;
+        const unsigned long long cap_ent = std::min((unsigned long long)n * per_row_max, 0xFFFFFFF0ull);
+        const bool may_overflow = (unsigned long long)n * per_row_max > cap_ent;
+        ctx->g_dj_geom = nullptr;
         for (uint32_t round = 0; round < rounds; ++round) {
             const uint32_t sub = part * rounds + round, nsub = nparts * rounds;
-            size_t t_scan = 0;
-            uint32_t* nul = nullptr;
-            BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, t_scan, nul, nul, (long long)n + 1, st));
-            if ((rc = bdg_reserve(ctx, ctx->g_sig, sizeof(uint32_t) * 2ull * ((size_t)n + 1) + t_scan + 512))) return rc;   // (the sweep's signature buffer is free here)
-            auto* count = static_cast<uint32_t*>(ctx->g_sig.p);
-            auto* offset = count + n + 1;
-            void* scan_temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(offset + n + 1) + 255) & ~uintptr_t(255));
-            uint32_t grid = (uint32_t)ctx->g_cus * d2_emit_blocks_per_cu();
-            if (grid > (n + 3u) / 4u) grid = (n + 3u) / 4u;
-            uint32_t m32 = 0;
+            const unsigned long long est = (unsigned long long)n * per_row_est / nsub + 1ull;
+            uint32_t l1 = 8;
+            while (l1 < 10u && (est >> l1) > (1ull << 18)) ++l1;                    // coarse buckets of at most ~256 K entries
+            if (const char* e = getenv("BADGER_AMD_DJ_L1")) l1 = (uint32_t)std::min(10, std::max(8, atoi(e)));      // (for measurements)
+            const uint32_t nb1 = 1u << l1;
+            uint32_t l2_max = std::min(10u, keybits - l1 - 4u);
+            uint32_t target = DJ_CAP / 2u;                                          // entries a fine bucket should hold
+            if (const char* e = getenv("BADGER_AMD_DJ_TARGET")) target = (uint32_t)std::max(1, atoi(e));          // (for tests: oversize buckets)
+            if (const char* e = getenv("BADGER_AMD_DJ_L2MAX")) l2_max = (uint32_t)std::min((int)l2_max, std::max(0, atoi(e)));
+            uint32_t tiles_want = (uint32_t)ctx->g_cus * 8u;
+            uint32_t rows_per_tile = ((n + tiles_want - 1u) / tiles_want + 63u) & ~63u;
+            if (rows_per_tile < 64u) rows_per_tile = 64u;
+            const uint32_t ntiles = (n + rows_per_tile - 1u) / rows_per_tile;
+            // workspace: hist [ntiles][nb1] | tot [nb1] | geom | base u64 [nb1 + 1] | fstart [(nb1 << l2_max) + 1]; entries twice
+            const size_t w_hist = (size_t)ntiles * nb1, w_fstart = ((size_t)nb1 << l2_max) + 1;
+            const size_t small_bytes = 4 * (w_hist + nb1 + bdgpart::G_WORDS + w_fstart) + 8 * ((size_t)nb1 + 1) + 64;
+            if ((rc = bdg_reserve(ctx, ctx->g_sig, small_bytes))) return rc;            // (the sweep's signature buffer is free here)
+            auto* base = static_cast<unsigned long long*>(ctx->g_sig.p);
+            auto* hist = reinterpret_cast<uint32_t*>(base + nb1 + 1);
+            auto* tot = hist + w_hist;
+            auto* geom = tot + nb1;
+            auto* fstart = geom + bdgpart::G_WORDS;
+            if ((rc = bdg_reserve(ctx, ctx->g_qj, 4ull * 2ull * (cap_ent + 64)))) return rc;
+            auto* e_a = static_cast<uint32_t*>(ctx->g_qj.p);
+            auto* e_b = e_a + cap_ent + 64;
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_count" : "k_d2_count");
-                if (one_deletion) hipLaunchKernelGGL(k_d1_count, dim3((n + 255u) / 256u), dim3(256), 0, st, d_ranks, n, sub, nsub, count);
-                else hipLaunchKernelGGL(k_d2_count, dim3(grid), dim3(256), 0, st, d_ranks, n, sub, nsub, count);
-                BDG_HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(scan_temp, t_scan, count, offset, (long long)n + 1, st));
+                if (one_deletion) hipLaunchKernelGGL(k_d1_rows<false>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
+                else hipLaunchKernelGGL(k_d2_rows<false>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
             }
-            BDG_HIP_TRY(ctx, hipMemcpyAsync(&m32, offset + n, 4, hipMemcpyDeviceToHost, st));
-            BDG_HIP_TRY(ctx, hipStreamSynchronize(st));                           // (the sort needs the entry count on the host)
-            const unsigned long long m = m32;
-            if (m == 0) continue;
-            // an entry is one 64-bit word, 14-mer above row: sorted as keys on bits 32 .. 59 (a fifth faster than 32-bit keys with
-            // 32-bit values beside them, tools/ubench/sort_forms.hip)
-            size_t t_sort = 0;
-            unsigned long long* nul64 = nullptr;
-            const int key_end = one_deletion ? 62 : 60;                           // (15-mers: 30 bits)
-            // (sorting only the key's upper 24 bits - three radix passes instead of four - and letting the pair walk meet every pair
-            // of a bucket of keys was measured: 0.73 against 0.79 ms at 250 K rows, 2.19 against 1.78 at config 5: not kept)
-            const int key_begin = 32;
-            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, t_sort, nul64, nul64, (long long)m, key_begin, key_end, st));
-            if ((rc = bdg_reserve(ctx, ctx->g_qj, sizeof(unsigned long long) * 2ull * (m + 64) + t_sort + 512))) return rc;
-            auto* e_in = static_cast<unsigned long long*>(ctx->g_qj.p);
-            auto* e_out = e_in + m + 32;
-            void* temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(e_out + m + 32) + 255) & ~uintptr_t(255));
+            {
+                ScopedKernelTimer tm(ctx, "k_part_scan");
+                hipLaunchKernelGGL(bdgpart::k_part_colscan, dim3(nb1), dim3(256), 0, st, hist, ntiles, nb1, tot);
+                hipLaunchKernelGGL(bdgpart::k_part_bases, dim3(1), dim3(1024), 0, st, tot, nb1, target, l2_max, cap_ent, base, geom);
+            }
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_emit" : "k_d2_emit");
-                if (one_deletion) hipLaunchKernelGGL(k_d1_emit, dim3((n + 255u) / 256u), dim3(256), 0, st, d_ranks, n, sub, nsub, offset, e_in);
-                else hipLaunchKernelGGL(k_d2_emit, dim3(grid), dim3(256), 0, st, d_ranks, n, sub, nsub, offset, e_in);
+                if (one_deletion) hipLaunchKernelGGL(k_d1_rows<true>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
+                else hipLaunchKernelGGL(k_d2_rows<true>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
             }
             {
-                ScopedKernelTimer tm(ctx, "d2_sort");
-                size_t t = t_sort;
-                BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(temp, t, e_in, e_out, (long long)m, key_begin, key_end, st));
+                ScopedKernelTimer tm(ctx, "k_part_split");
+                hipLaunchKernelGGL(bdgpart::k_part_split<uint32_t>, dim3(nb1), dim3(1024), 0, st, e_a, e_b, base, geom, nb1, keybits - l1, fstart);
             }
-            ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_pairs" : "k_d2_pairs");
-            unsigned long long pgrid = (unsigned long long)ctx->g_cus * d2_pairs_blocks_per_cu();
-            if (pgrid > (m + 255) / 256) pgrid = (m + 255) / 256;
-            if (one_deletion) hipLaunchKernelGGL(k_d2_pairs<1>, dim3((uint32_t)pgrid), dim3(256), 0, st, e_out, m, d_ranks, row_begin, row_end,
-                                                 thr, qgram_T, d_out, cap, cnt);
-            else hipLaunchKernelGGL(k_d2_pairs<2>, dim3((uint32_t)pgrid), dim3(256), 0, st, e_out, m, d_ranks, row_begin, row_end,
-                                    thr, qgram_T, d_out, cap, cnt);
+            {
+                ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_pairs" : "k_d2_pairs");
+                const uint32_t pgrid = (uint32_t)ctx->g_cus * d2_pairs_blocks_per_cu();
+                if (one_deletion) hipLaunchKernelGGL((k_d2_pairs<1, DJ_THREADS, DJ_CAP, DJ_ECAPW>), dim3(pgrid), dim3(DJ_THREADS), 0, st, e_b, fstart, geom, l1,
+                                                     d_ranks, row_begin, row_end, thr, qgram_T, d_out, cap, cnt);
+                else hipLaunchKernelGGL((k_d2_pairs<2, DJ_THREADS, DJ_CAP, DJ_ECAPW>), dim3(pgrid), dim3(DJ_THREADS), 0, st, e_b, fstart, geom, l1,
+                                        d_ranks, row_begin, row_end, thr, qgram_T, d_out, cap, cnt);
+            }
             BDG_HIP_TRY(ctx, hipGetLastError());
+            ctx->g_dj_geom = geom;                                                // (bdg_graph_status: what the device reported)
+            if (may_overflow || rounds > 1u) {                                    // (the next round rewrites the report)
+                uint32_t flags = 0;
+                if ((rc = bdg_graph_join_flags(ctx, &flags))) return rc;
+                if (flags) return bdg_graph_flags_error(ctx, flags);
+            }
         }
         return BDG_OK;
     }

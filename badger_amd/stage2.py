@@ -167,6 +167,7 @@ class Stage2:
             d_tot = _native.DeviceArray(ctx, 1, np.uint64)
             ctx.graph_edges_dev(d_uniq, nu, self.threshold, T, d_edges, cap, d_tot)
             tot = int(d_tot.to_host()[0])
+            ctx.graph_status()
             if tot <= cap:
                 break
             cap = tot

@@ -96,6 +96,11 @@ const char* bdg_version(void);
 /* Number of devices this process may open (hipGetDeviceCount; 0 when there is none or the runtime fails).  What the
  * reference's "-t threads" sizing becomes for "--gpus N" (extract_raw_barcodes.py:366, :208-214). */
 int  bdg_device_count(void);
+/* The arithmetic of the deletion-variant joins' index entries (csrc/dj_codec.hpp: key mixing and its inverse, deleting and
+ * re-inserting letters, entry encode / decode), run on the HOST on `rounds` random barcodes from `seed`: 0 when every
+ * identity holds, else the number of the first check that failed.  The same functions are what the kernels compile; no GPU
+ * is needed (CPU test tier).  Nothing in the reference corresponds (its buckets are Python dicts, index.py:29-35). */
+int  bdg_selftest_dj_codec(uint64_t seed, uint32_t rounds);
 /* Plain device buffers on the context's device, for hosts that bring no allocator of their own (the command lines of
  * this package run without torch): zero-filled allocation, release, and copies to and from host memory on the
  * context's stream (both return when the copy is done).  Callers that do have one (torch tensors, hipMalloc of their own) pass those pointers to the
@@ -323,10 +328,15 @@ int  bdg_graph_edges_rows_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n,
  * 2 neighbourhood probes (thr = 1 only), 3 q-gram join (the device form of QGramIndex, index.py:29-35,77-93; any thr),
  * 4 the same with every candidate verified in closed form (the join's fallback for slices its table cannot take; for tests),
  * 5 deletion-variant join (thr <= 2: rows that share a 14-mer left by two deletions meet; same dmin and S tests; work linear
- * in n where the q-gram join's is quadratic; any n - a large input is taken in rounds over shares of the 14-mers; it reads
- * the number of its index entries back, i.e. synchronises once a round), 6 the same over the 15-mers left by one deletion
- * (thr <= 1).  All give identical edge lists. */
+ * in n where the q-gram join's is quadratic; any n - a large input is taken in rounds over shares of the 14-mers; a single
+ * round never waits for the host), 6 the same over the 15-mers left by one deletion (thr <= 1).  All give identical edge lists. */
 int  bdg_graph_set_algo(bdg_ctx* ctx, int algo);
+/* What the device-resident graph calls cannot return because they do not wait: waits for the context's stream, then
+ * BDG_OK, or BDG_E_CAPACITY when a deletion-variant join of the last call met an input it could not group (more index
+ * entries in one round than 32 bits address - only possible beyond 35 M rows; a bucket of variants beyond every split).
+ * The edge list of such a call is incomplete.  bdg_graph_edges asks by itself.  Same contract as bdg_extract_status for
+ * the extraction (the reference has no such state: compare_chunk, barcode_graph.py:75-111, raises where it fails). */
+int  bdg_graph_status(bdg_ctx* ctx);
 /* One of nparts disjoint shares of the edge list (compare_in_parallel's fan-out, barcode_graph.py:164-189, over GPUs: every
  * device holds the whole sorted array and calls this with its own part; the union over the parts is the list of
  * bdg_graph_edges_dev).  Which edges a part holds is the library's choice, made so that the parts cost the same: blocks of

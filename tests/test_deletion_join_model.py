@@ -200,3 +200,75 @@ def test_the_three_relations_cover_every_pair_within_distance_two():
             shared1 = set(entries1(a)) & set(entries1(b))
             assert shared1 and sum(1 for k in shared1 if reports1(a, b, k)) == 1, (s, t)
     assert edges > 60000 and used["none"] == 0 and min(used["letters"], used["indel"], used["shift"]) > 5000
+
+
+# ---- the grouping that replaced the radix sort (csrc/dj_codec.hpp, csrc/bdg_partition.hpp) --------------------------------
+MUL_A, MUL_B = 0x9E3779B1, 0x85EBCA6B
+
+
+def mix(k, kb):
+    m = (1 << kb) - 1
+    x = (k * MUL_A) & m
+    x ^= x >> 15
+    return (x * MUL_B) & m
+
+
+def test_entry_codec_of_the_shipped_library():
+    """dj_codec.hpp, the very functions the kernels compile, run on the host by the library (no GPU): mixing is one-to-one
+    and inverted by unmix, re-inserting the deleted letters gives the row back, encode -> decode returns (variant, row) for
+    every deletion (pair) and every coarse bucket width."""
+    from badger_amd import _native
+    lib = _native.load()
+    assert lib.bdg_selftest_dj_codec(1, 2000) == 0
+    assert lib.bdg_selftest_dj_codec(20250711, 500) == 0
+
+
+def test_mixed_keys_group_whole_variants_and_spread_them_evenly():
+    """The buckets of the two partition levels and the bins inside a fine bucket are bit fields of the MIXED key, so a group
+    (all entries of one variant) is never cut, and dense data - barcodes of a few thousand cells with errors, whose raw
+    variants crowd a few thousand places - still fills the 256 coarse buckets within a few percent of each other."""
+    rng = np.random.default_rng(3)
+    wl = synth.make_whitelist(4000)
+    cells = wl[rng.permutation(len(wl))[:300]].astype(np.uint64)
+    r = cells[rng.integers(0, len(cells), 12000)]
+    hit = rng.random(len(r)) < 0.5
+    r = np.where(hit, r ^ (rng.integers(1, 4, len(r)).astype(np.uint64) << (2 * rng.integers(0, 16, len(r)).astype(np.uint64))), r)
+    rows = np.unique(r.astype(np.uint32))
+    keys = np.array([k for x in rows for k in entries2(int(x))], dtype=np.uint64)
+    z = np.array([mix(int(k), 28) for k in keys], dtype=np.uint64)
+    # one-to-one: as many distinct mixed keys as variants
+    assert len(np.unique(z)) == len(np.unique(keys))
+    coarse = np.bincount((z >> np.uint64(20)).astype(np.int64), minlength=256)
+    raw = np.bincount((keys >> np.uint64(20)).astype(np.int64), minlength=256)
+    assert coarse.max() < 1.35 * coarse.mean() and coarse.min() > 0.7 * coarse.mean()
+    assert raw.max() > 2 * raw.mean() and raw.min() < 0.5 * raw.mean()    # (what the mixing is for)
+    # bucket and bin of an entry are functions of its variant alone
+    fine = (z >> np.uint64(14))
+    for k in np.unique(keys)[:500]:
+        assert len(np.unique(fine[keys == k])) == 1
+
+
+def test_counting_pass_places_are_exact():
+    """bdg_partition.hpp in numpy: per-tile histograms -> column scan -> bases give every (tile, bucket) run its own place;
+    scattering with per-tile cursors fills [0, m) exactly once and every bucket's range holds exactly its entries."""
+    rng = np.random.default_rng(5)
+    ntiles, nb1 = 37, 256
+    tiles = [rng.integers(0, 1 << 28, int(rng.integers(0, 900))).astype(np.uint64) for _ in range(ntiles)]
+    hist = np.stack([np.bincount((t >> np.uint64(20)).astype(np.int64), minlength=nb1) for t in tiles])
+    within = np.cumsum(hist, axis=0) - hist                               # k_part_colscan
+    tot = hist.sum(axis=0)
+    base = np.concatenate([[0], np.cumsum(tot)])                          # k_part_bases
+    m = int(base[-1])
+    out = np.full(m, -1, dtype=np.int64)
+    for t, ent in enumerate(tiles):
+        cur = base[:-1] + within[t]                                       # the tile's cursors
+        for e in ent:
+            b = int(e >> np.uint64(20))
+            assert out[cur[b]] == -1
+            out[cur[b]] = int(e)
+            cur[b] += 1
+    assert (out >= 0).all()
+    for b in range(nb1):
+        seg = out[base[b]:base[b + 1]]
+        assert ((seg >> 20) == b).all()
+    assert sorted(out.tolist()) == sorted(int(e) for t in tiles for e in t)
