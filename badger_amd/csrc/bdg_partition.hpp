@@ -25,7 +25,7 @@ constexpr uint32_t NB1_MAX = 1024;     // coarse buckets (the producer's LDS his
 constexpr uint32_t NB2_MAX = 1024;     // sub-buckets of one coarse bucket (k_part_split's LDS histogram)
 
 // geom[]: what the device decides and the later kernels read
-enum { G_L2 = 0, G_M_LO = 1, G_M_HI = 2, G_FLAGS = 3, G_WORDS = 8 };
+enum { G_L2 = 0, G_M_LO = 1, G_M_HI = 2, G_FLAGS = 3, G_OVF = 4 /* a consumer's list of buckets left to a second kernel */, G_WORDS = 8 };
 
 #if defined(__HIPCC__)
 
@@ -92,36 +92,77 @@ void k_part_bases(const uint32_t* __restrict__ tot, uint32_t nb1, uint32_t targe
         while (l2 < l2_max && (all >> l2) > (unsigned long long)nb1 * target) ++l2;
         geom[G_L2] = l2; geom[G_M_LO] = (uint32_t)all; geom[G_M_HI] = (uint32_t)(all >> 32);
         geom[G_FLAGS] = all > limit ? 1u : 0u;
+        geom[G_OVF] = 0u;
     }
 }
 
 // One block per coarse bucket: its entries grouped by sub-bucket (bits [sh_top - l2, sh_top) of an entry) into `out`,
-// the places of the fine buckets into fstart[b << l2 | j], fstart[nb1 << l2] = m.  Any bucket size (streamed twice).
+// the places of the fine buckets into fstart[b << l2 | j], fstart[nb1 << l2] = m.  Any bucket size: the bucket is streamed
+// twice, first for the sub-buckets' sizes, then in rounds of 64 KB that are grouped inside LDS before they leave, so that
+// what a wave stores is runs of neighbours (a store of 64 scattered words is 64 transactions at the L2, and 35 M of those
+// cost more than the rest of the pass: measured 0.31 ms against 0.10 at 35.6 M entries).
 template <class E>
 __global__ __launch_bounds__(1024)
 void k_part_split(const E* __restrict__ in, E* __restrict__ out, const unsigned long long* __restrict__ base,
                   const uint32_t* __restrict__ geom, uint32_t nb1, uint32_t sh_top, uint32_t* __restrict__ fstart)
 {
-    __shared__ uint32_t s_h[NB2_MAX];
+    constexpr uint32_t CHK = 65536u / sizeof(E), PT = CHK / 1024u;
+    __shared__ E s_stage[CHK];
+    __shared__ uint32_t s_g[NB2_MAX];                 // where each sub-bucket's next entry goes
+    __shared__ uint32_t s_c[NB2_MAX];                 // per round: the sub-bucket's count, then its start inside the round
     __shared__ uint32_t s_w[17];
     if (geom[G_FLAGS] & 1u) return;
     const uint32_t l2 = geom[G_L2], nb2 = 1u << l2, sh = sh_top - l2, mask = nb2 - 1u;
     for (uint32_t b = blockIdx.x; b < nb1; b += gridDim.x) {
         const unsigned long long s = base[b];
         const uint32_t c = (uint32_t)(base[b + 1] - s);
-        if (threadIdx.x < nb2) s_h[threadIdx.x] = 0u;
+        if (threadIdx.x < nb2) s_c[threadIdx.x] = 0u;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < c; i += 1024u) atomicAdd(&s_h[(uint32_t)(in[s + i] >> sh) & mask], 1u);
+        for (uint32_t i = threadIdx.x; i < c; i += 4096u) {
+            E e[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) e[u] = i + u * 1024u < c ? in[s + i + u * 1024u] : E(0);
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) if (i + u * 1024u < c) atomicAdd(&s_c[(uint32_t)(e[u] >> sh) & mask], 1u);
+        }
         __syncthreads();
-        const uint32_t v = threadIdx.x < nb2 ? s_h[threadIdx.x] : 0u;
-        uint32_t total;
-        const uint32_t at = (uint32_t)s + block_excl_scan<1024>(v, s_w, total);
-        if (threadIdx.x < nb2) { s_h[threadIdx.x] = at; fstart[(b << l2) + threadIdx.x] = at; }
-        if (b == nb1 - 1u && threadIdx.x == 0) fstart[nb1 << l2] = (uint32_t)base[nb1];
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < c; i += 1024u) {
-            const E e = in[s + i];
-            out[atomicAdd(&s_h[(uint32_t)(e >> sh) & mask], 1u)] = e;
+        {
+            const uint32_t v = threadIdx.x < nb2 ? s_c[threadIdx.x] : 0u;
+            uint32_t total;
+            const uint32_t at = (uint32_t)s + block_excl_scan<1024>(v, s_w, total);
+            if (threadIdx.x < nb2) { s_g[threadIdx.x] = at; fstart[(b << l2) + threadIdx.x] = at; }
+            if (b == nb1 - 1u && threadIdx.x == 0) fstart[nb1 << l2] = (uint32_t)base[nb1];
+        }
+        for (uint32_t c0 = 0; c0 < c; c0 += CHK) {
+            const uint32_t nc = c - c0 < CHK ? c - c0 : CHK;
+            if (threadIdx.x < nb2) s_c[threadIdx.x] = 0u;
+            __syncthreads();
+            E e[PT];
+            uint32_t rk[PT];
+#pragma unroll
+            for (uint32_t u = 0; u < PT; ++u) e[u] = u * 1024u + threadIdx.x < nc ? in[s + c0 + u * 1024u + threadIdx.x] : E(0);
+#pragma unroll
+            for (uint32_t u = 0; u < PT; ++u) rk[u] = u * 1024u + threadIdx.x < nc ? atomicAdd(&s_c[(uint32_t)(e[u] >> sh) & mask], 1u) : 0u;
+            __syncthreads();
+            const uint32_t v = threadIdx.x < nb2 ? s_c[threadIdx.x] : 0u;
+            uint32_t total;
+            const uint32_t cs = block_excl_scan<1024>(v, s_w, total);
+            if (threadIdx.x < nb2) s_c[threadIdx.x] = cs;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t u = 0; u < PT; ++u) if (u * 1024u + threadIdx.x < nc) s_stage[s_c[(uint32_t)(e[u] >> sh) & mask] + rk[u]] = e[u];
+            __syncthreads();
+#pragma unroll
+            for (uint32_t u = 0; u < PT; ++u) {
+                const uint32_t i = u * 1024u + threadIdx.x;
+                if (i < nc) {
+                    const E x = s_stage[i];
+                    const uint32_t j = (uint32_t)(x >> sh) & mask;
+                    out[s_g[j] + (i - s_c[j])] = x;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < nb2) s_g[threadIdx.x] += v;
         }
         __syncthreads();
     }

@@ -880,6 +880,14 @@ constexpr uint32_t DJ_ECAPW = 256;               // edges a wave stages before i
 
 struct D2Row { uint32_t k0, k1, z0, z1; bool keep0, keep1; };      // the lane's two 14-mers, their mixed keys, which stay
 
+__device__ __forceinline__ void d2_tab_init(uint32_t* __restrict__ tab, int lane)
+{
+    uint4* const tab4 = reinterpret_cast<uint4*>(tab);
+#pragma unroll
+    for (uint32_t i = 0; i < D2_SLOTS / 4u / 64u; ++i) tab4[i * 64u + (uint32_t)lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ D2Row d2_row(uint32_t r, int lane, uint32_t pq0, uint32_t pq1, uint32_t* __restrict__ tab,
                                         uint32_t part, uint32_t nparts)
 {
@@ -895,24 +903,26 @@ __device__ __forceinline__ D2Row d2_row(uint32_t r, int lane, uint32_t pq0, uint
         return fp && (fq || p + 1u == q);                                                // (p + 1 == q and q not first: same run)
     };
     bool keep0 = canonical(pq0), keep1 = has1 && canonical(pq1);
-    uint4* const tab4 = reinterpret_cast<uint4*>(tab);
-#pragma unroll
-    for (uint32_t i = 0; i < D2_SLOTS / 4u / 64u; ++i) tab4[i * 64u + (uint32_t)lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
-    __builtin_amdgcn_wave_barrier();
+    // (the table is all ones when a row begins: d2_tab_init once, then every row puts back what it took)
     // (a row's 14-mers agree in their low letters whenever both deletions lie behind them: the slot must come from all 28 bits)
     // (the same mixed key names the entry's bucket afterwards, dj_codec.hpp)
     const uint32_t x0 = djc::mix<28>(o.k0), x1 = djc::mix<28>(o.k1 & 0x0FFFFFFFu);
     o.z0 = x0; o.z1 = x1;
     const uint32_t mine0 = (uint32_t)lane << 18 | (x0 & 0x3FFFFu), mine1 = (uint32_t)(64 + lane) << 18 | (x1 & 0x3FFFFu);
-    if (keep0) atomicMin(&tab[x0 >> 18], mine0);
-    if (keep1) atomicMin(&tab[x1 >> 18], mine1);
+    const bool put0 = keep0, put1 = keep1;
+    if (put0) atomicMin(&tab[x0 >> 18], mine0);
+    if (put1) atomicMin(&tab[x1 >> 18], mine1);
     __builtin_amdgcn_wave_barrier();
     const uint32_t got0 = tab[x0 >> 18], got1 = tab[x1 >> 18];
+    __builtin_amdgcn_wave_barrier();
+    // the slots this row used, all ones again: two 4-byte stores per lane where clearing the table took four 16-byte ones -
+    // the LDS arrays were the busiest unit of both row passes (31 M cycles a pass, profiles/r04_d: 60 % of the pass)
+    if (put0) tab[x0 >> 18] = ~0u;
+    if (put1) tab[x1 >> 18] = ~0u;
     const bool same0 = ((got0 ^ mine0) & 0x3FFFFu) == 0u, same1 = ((got1 ^ mine1) & 0x3FFFFu) == 0u;
     const bool lost0 = keep0 && !same0, lost1 = keep1 && !same1;         // the slot went to another 14-mer
     keep0 = keep0 && (got0 == mine0 || !same0);
     keep1 = keep1 && (got1 == mine1 || !same1);
-    __builtin_amdgcn_wave_barrier();                                     // (the table is cleared again for the next row)
     const unsigned long long u0 = __ballot(lost0), u1 = __ballot(lost1);
     for (unsigned long long w = u0; w; w &= w - 1ull) {
         const int src = __builtin_ctzll(w);
@@ -1039,6 +1049,7 @@ void k_d2_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per
     for (uint32_t i = threadIdx.x; i < nb1; i += 256u) s_h[i] = EMIT ? (uint32_t)base[i] + hist[(size_t)blockIdx.x * nb1 + i] : 0u;
     __syncthreads();
     const uint32_t pq0 = d2_table.pq[lane], pq1 = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
+    d2_tab_init(s_tab[wv], lane);
     for (uint32_t chunk = row0 + (uint32_t)wv * 64u; chunk < row1; chunk += 256u) {
         const uint32_t rows = row1 - chunk < 64u ? row1 - chunk : 64u;
         const uint32_t mine = (uint32_t)lane < rows ? ranks[chunk + (uint32_t)lane] : 0u;
@@ -1095,9 +1106,199 @@ void k_d1_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per
     }
 }
 
-// ---- the consumer: one fine bucket at a time in LDS.
-// A fine bucket holds the entries whose mixed keys share their top l1 + l2 bits - whole groups, about a thousand entries.
-// The block finishes the grouping there: a counting pass over NBIN bins named by the next key bits (an LDS atomic gives an
+// ---- the consumer, first form: one fine bucket per WAVE, no block barrier anywhere.
+// A fine bucket holds the entries whose mixed keys share their top l1 + l2 bits - whole groups, about a hundred entries, at
+// most WCAP (a larger one is listed for the block kernel below).  The wave finishes the grouping in its own stretch of LDS:
+// a counting pass over WBIN bins named by the next key bits (the LDS atomic that counts also gives the entry its place inside
+// the bin; no order is needed), then every entry meets the entries behind it in its bin.  A bin is mostly one group; where
+// two variants share a bin the meeting ends at one compare.  Lanes stay full whatever the group sizes: the meetings of the
+// whole bucket are numbered through (entry p owns the slots [before_p, before_p + L_p)), the wave takes 64 slots at a time,
+// and a slot finds its owner without a search - every owner marks its FIRST slot with its place, and a running maximum
+// over the marks (six DPP steps and the carry of the step before) is the owner of every slot.  Which group reports a pair is
+// a function of the two barcodes (d2_reports / d1_reports); only meetings that would report are verified (the same Myers
+// dmin3 and the same S >= T as on every other path), 64 at a time out of a per-wave queue.  The next bucket's entries are
+// loaded into registers before this one is walked.
+template <int NDEL, uint32_t WCAP, uint32_t ECAPW>
+__global__ __launch_bounds__(256)
+void k_d2_pairs_w(const uint32_t* __restrict__ ent, const uint32_t* __restrict__ fstart, uint32_t* __restrict__ geom, uint32_t l1,
+                  const uint32_t* __restrict__ ranks, uint32_t row_begin, uint32_t row_end, uint32_t thr, int32_t T,
+                  bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges, uint32_t* __restrict__ ovf)
+{
+    constexpr int KB = NDEL == 2 ? 28 : 30;
+    constexpr uint32_t PER = WCAP / 64u, WBIN = WCAP, LBIN = 31u - (uint32_t)__builtin_clz(WCAP), CH = 256u;
+    static_assert(PER % 4u == 0u && (WCAP & (WCAP - 1u)) == 0u, "WCAP: 256, 512, ...");
+    __shared__ unsigned long long s_kv[4][WCAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_bin[4][WBIN + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_before[4][WCAP];
+    __shared__ uint32_t s_mark[4][CH];
+    __shared__ EdgeStageT<ECAPW> stages[4];
+    __shared__ uint32_t s_qa[4][128], s_qb[4][128];
+    __shared__ uint32_t s_ma[4][128], s_mb[4][128], s_mk[4][128];
+    __shared__ uint32_t s_cnt[4];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t ne = 0, qn = 0;
+    const uint32_t flags = geom[bdgpart::G_FLAGS];
+    const uint32_t l2 = geom[bdgpart::G_L2];
+    const uint32_t nfb = (flags & 1u) ? 0u : 1u << (l1 + l2);
+    const uint32_t zb = (uint32_t)KB - l1, rb = zb - l2;
+    const uint32_t lb = rb < LBIN ? rb : LBIN, bin_sh = rb - lb, bin_mask = (1u << lb) - 1u;
+    const uint32_t rank_lo = ranks[row_begin], rank_hi = ranks[row_end - 1u];       // (row_begin < row_end: the launcher's check)
+    auto verify = [&](uint32_t a, uint32_t b, bool act) {
+        const uint32_t d = act ? dmin3(a, b) : 99u;
+        bool edge = d <= thr;
+        if (__ballot(edge)) edge = edge && (int32_t)qgram_S(a, b) >= T;
+        edge_push(edge, a, b, d, stages[wv], ne, lane, out, cap, n_edges);
+    };
+    uint32_t mn = 0;                                                   // meetings waiting for the reporting rule
+    auto report = [&](uint32_t from, bool act) {
+        const uint32_t a = s_ma[wv][from + lane], b = s_mb[wv][from + lane], kk = s_mk[wv][from + lane];
+        const int rep = act ? (NDEL == 2 ? d2_reports(a, b, kk) : d1_reports(a, b, kk)) : 0;
+        const unsigned long long mq = __ballot(rep != 0);
+        if (rep != 0) {
+            const uint32_t at = qn + lanes_below_u64(mq, lane);
+            s_qa[wv][at] = a; s_qb[wv][at] = b;
+        }
+        qn += (uint32_t)__popcll(mq);
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64u) {
+            qn -= 64u;
+            verify(s_qa[wv][qn + lane], s_qb[wv][qn + lane], true);
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    const uint32_t GW = gridDim.x * 4u;
+    uint32_t fb = blockIdx.x * 4u + (uint32_t)wv;
+    uint32_t start = 0, cnt = 0, e[PER];
+    auto fetch = [&](uint32_t f, uint32_t& s, uint32_t& c, uint32_t (&ee)[PER]) {
+        s = 0; c = 0;
+        if (f < nfb) { s = fstart[f]; c = fstart[f + 1u] - s; }
+        s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s); c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) ee[j] = (c <= WCAP && j * 64u + (uint32_t)lane < c) ? ent[s + j * 64u + (uint32_t)lane] : 0u;
+    };
+    fetch(fb, start, cnt, e);
+    while (fb < nfb) {
+        uint32_t nstart, ncnt, nx[PER];
+        fetch(fb + GW, nstart, ncnt, nx);                               // (travels while this bucket is walked)
+        if (cnt > WCAP) {
+            if (lane == 0) ovf[1u + atomicAdd(&geom[bdgpart::G_OVF], 1u)] = fb;
+        } else if (cnt >= 2u) {
+            const uint32_t b1 = fb >> l2;
+            uint4* const bin4 = reinterpret_cast<uint4*>(s_bin[wv]);
+            uint4* const bef4 = reinterpret_cast<uint4*>(s_before[wv]);
+#pragma unroll
+            for (uint32_t i = 0; i < PER / 4u; ++i) bin4[i * 64u + (uint32_t)lane] = make_uint4(0u, 0u, 0u, 0u);
+            __builtin_amdgcn_wave_barrier();
+            uint32_t bn[PER], rk[PER];
+#pragma unroll
+            for (uint32_t j = 0; j < PER; ++j) {
+                bn[j] = (e[j] >> bin_sh) & bin_mask; rk[j] = 0;
+                if (j * 64u + (uint32_t)lane < cnt) rk[j] = atomicAdd(&s_bin[wv][bn[j]], 1u);
+            }
+            __builtin_amdgcn_wave_barrier();
+            {   // the bins' starts: a lane takes PER consecutive bins
+                uint4 c4[PER / 4u];
+                uint32_t sum = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < PER / 4u; ++i) { c4[i] = bin4[(uint32_t)lane * (PER / 4u) + i]; sum += c4[i].x + c4[i].y + c4[i].z + c4[i].w; }
+                uint32_t run = wave_incl_scan(sum) - sum;
+#pragma unroll
+                for (uint32_t i = 0; i < PER / 4u; ++i) {
+                    uint4 o;
+                    o.x = run; run += c4[i].x; o.y = run; run += c4[i].y; o.z = run; run += c4[i].z; o.w = run; run += c4[i].w;
+                    bin4[(uint32_t)lane * (PER / 4u) + i] = o;
+                }
+                if (lane == 63) s_bin[wv][WBIN] = run;                 // (= cnt)
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (uint32_t j = 0; j < PER; ++j) {
+                if (j * 64u + (uint32_t)lane >= cnt) continue;
+                const uint32_t pos = s_bin[wv][bn[j]] + rk[j], end = s_bin[wv][bn[j] + 1u];
+                uint32_t k, r;
+                if (NDEL == 2) djc::dec2(e[j], b1, zb, d2_table.pq[(e[j] >> zb) & 127u], k, r); else djc::dec1(e[j], b1, zb, k, r);
+                s_kv[wv][pos] = (unsigned long long)k << 32 | r;
+                s_before[wv][pos] = end - pos - 1u;                     // (for now: L, the entries behind this one in its bin)
+            }
+            __builtin_amdgcn_wave_barrier();
+            // the meetings numbered through: a lane takes PER consecutive places
+            uint32_t L[PER], bf[PER], sum = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < PER / 4u; ++i) {
+                const uint4 v = bef4[(uint32_t)lane * (PER / 4u) + i];
+                L[4u * i] = v.x; L[4u * i + 1u] = v.y; L[4u * i + 2u] = v.z; L[4u * i + 3u] = v.w;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < PER; ++i) { if ((uint32_t)lane * PER + i >= cnt) L[i] = 0u; sum += L[i]; }
+            const uint32_t incl = wave_incl_scan(sum);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (total) {
+                uint32_t run = incl - sum;
+#pragma unroll
+                for (uint32_t i = 0; i < PER; ++i) { bf[i] = run; run += L[i]; }
+#pragma unroll
+                for (uint32_t i = 0; i < PER / 4u; ++i) bef4[(uint32_t)lane * (PER / 4u) + i] = make_uint4(bf[4u * i], bf[4u * i + 1u], bf[4u * i + 2u], bf[4u * i + 3u]);
+                uint32_t carry = 0;
+                for (uint32_t cb = 0; cb < total; cb += CH) {
+#pragma unroll
+                    for (uint32_t i = 0; i < CH / 64u; ++i) s_mark[wv][i * 64u + (uint32_t)lane] = 0u;
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (uint32_t i = 0; i < PER; ++i) if (L[i] && bf[i] - cb < CH) s_mark[wv][bf[i] - cb] = (uint32_t)lane * PER + i + 1u;
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t x0 = 0; x0 < CH && cb + x0 < total; x0 += 64u) {
+                        const uint32_t x = cb + x0 + (uint32_t)lane;
+                        const bool act = x < total;
+                        uint32_t own = wave_incl_max(s_mark[wv][x0 + (uint32_t)lane]);
+                        own = own > carry ? own : carry;
+                        carry = (uint32_t)__builtin_amdgcn_readlane((int)own, 63);
+                        uint32_t a = 0, b = 0, kk = 0;
+                        bool on = false;
+                        if (act) {
+                            const uint32_t p1 = own - 1u, p2 = p1 + 1u + (x - s_before[wv][p1]);
+                            const unsigned long long kv1 = s_kv[wv][p1], kv2 = s_kv[wv][p2];
+                            kk = (uint32_t)(kv1 >> 32);
+                            if (kk == (uint32_t)(kv2 >> 32)) {         // (the same variant, not just the same bin)
+                                const uint32_t v1 = (uint32_t)kv1, v2 = (uint32_t)kv2;
+                                const bool lower = v1 < v2;            // (a row has one entry per variant: v1 != v2)
+                                a = lower ? v1 : v2; b = lower ? v2 : v1;
+                                on = a >= rank_lo && a <= rank_hi;
+                            }
+                        }
+                        // real meetings wait in a queue of their own, so that the reporting rule - the dearest part of a
+                        // meeting, and both of its branches run whenever a wave holds both kinds - always sees 64 of them
+                        // (a third of the slots are bin neighbours of another variant or the tail of a bucket's last step)
+                        const unsigned long long mm = __ballot(on);
+                        if (on) {
+                            const uint32_t at = mn + lanes_below_u64(mm, lane);
+                            s_ma[wv][at] = a; s_mb[wv][at] = b; s_mk[wv][at] = kk;
+                        }
+                        mn += (uint32_t)__popcll(mm);
+                        __builtin_amdgcn_wave_barrier();
+                        if (mn >= 64u) { mn -= 64u; report(mn, true); }
+                    }
+                    __builtin_amdgcn_wave_barrier();                     // (the marks are rewritten next)
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                             // (the bucket's arrays are rewritten next)
+        }
+        fb += GW; start = nstart; cnt = ncnt;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) e[j] = nx[j];
+    }
+    if (mn) { const uint32_t left = mn; mn = 0; report(0u, (uint32_t)lane < left); }
+    if (qn) {
+        const bool act = (uint32_t)lane < qn;
+        verify(act ? s_qa[wv][lane] : 0u, act ? s_qb[wv][lane] : 1u, act);
+    }
+    edge_finish<4>(stages, ne, s_cnt, &s_base, out, cap, n_edges);
+}
+
+// ---- the consumer, second form: one fine bucket per BLOCK, for the buckets the wave kernel listed as too large for a wave
+// (list != nullptr) or for all of them (list == nullptr: a cross-check).
+// The block finishes the grouping in LDS: a counting pass over NBIN bins named by the next key bits (an LDS atomic gives an
 // entry its place inside its bin, no order is needed), then every entry meets the entries behind it in its bin.  A bin is
 // mostly one group; where two variants share a bin the meeting ends at one compare.  The walk itself is round 3's: a wave
 // takes 64 consecutive places, lane l's entry meets the L_l entries behind it, and the wave walks the SUM of the meetings
@@ -1110,7 +1311,7 @@ template <int NDEL, int THREADS, uint32_t CAP, uint32_t ECAPW>
 __global__ __launch_bounds__(THREADS)
 void k_d2_pairs(const uint32_t* __restrict__ ent, const uint32_t* __restrict__ fstart, uint32_t* __restrict__ geom, uint32_t l1,
                 const uint32_t* __restrict__ ranks, uint32_t row_begin, uint32_t row_end, uint32_t thr, int32_t T,
-                bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges)
+                bdg_edge* __restrict__ out, uint64_t cap, unsigned long long* __restrict__ n_edges, const uint32_t* __restrict__ list)
 {
     constexpr int KB = NDEL == 2 ? 28 : 30;
     constexpr int NW = THREADS / 64;
@@ -1219,7 +1420,9 @@ void k_d2_pairs(const uint32_t* __restrict__ ent, const uint32_t* __restrict__ f
         }
         __syncthreads();                                                 // (the bucket's arrays are rewritten next)
     };
-    for (uint32_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
+    const uint32_t nwork = (flags & 1u) ? 0u : (list ? geom[bdgpart::G_OVF] : nfb);
+    for (uint32_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+        const uint32_t fb = list ? list[1u + w] : w;
         const uint32_t start = fstart[fb], cnt = fstart[fb + 1u] - start;
         if (cnt < 2u) continue;
         const uint32_t b1 = fb >> l2;
@@ -1253,8 +1456,8 @@ void k_d2_pairs(const uint32_t* __restrict__ ent, const uint32_t* __restrict__ f
 // ---------------------------------------------------------------------------
 static uint32_t d2_pairs_blocks_per_cu()
 {
-    static const uint32_t v = [] { const char* e = getenv("BADGER_AMD_D2_PAIRS_BLOCKS"); const int x = e ? atoi(e) : 3; return (uint32_t)(x < 1 ? 1 : (x > 8 ? 8 : x)); }();
-    return v;                                                          // (53 KB of LDS a block of 8 waves: three fit a compute unit)
+    static const uint32_t v = [] { const char* e = getenv("BADGER_AMD_D2_PAIRS_BLOCKS"); const int x = e ? atoi(e) : 4; return (uint32_t)(x < 1 ? 1 : (x > 8 ? 8 : x)); }();
+    return v;                                                          // (k_d2_pairs_w: 34 KB of LDS a block of 4 waves at 256 entries a wave)
 }
 
 // once per context: the device's compute units and how many blocks of the join kernels a unit holds (resident grids are sized from these)
@@ -1312,6 +1515,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
                      uint32_t thr, int32_t qgram_T, bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges, uint32_t part, uint32_t nparts)
 {
     hipStream_t st = ctx->stream;
+    ctx->g_dj_geom = nullptr;                                          // (bdg_graph_status speaks about this call)
     BDG_HIP_TRY(ctx, hipMemsetAsync(d_n_edges, 0, 8, st));
     if (n < 2 || row_begin >= row_end) return BDG_OK;
     if (thr > 16) return bdg_fail(ctx, BDG_E_ARG, "thr must be <= 16");
@@ -1348,7 +1552,6 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
         const uint32_t keybits = one_deletion ? 30u : 28u;
         const unsigned long long cap_ent = std::min((unsigned long long)n * per_row_max, 0xFFFFFFF0ull);
         const bool may_overflow = (unsigned long long)n * per_row_max > cap_ent;
-        ctx->g_dj_geom = nullptr;
         for (uint32_t round = 0; round < rounds; ++round) {
             const uint32_t sub = part * rounds + round, nsub = nparts * rounds;
             const unsigned long long est = (unsigned long long)n * per_row_est / nsub + 1ull;
@@ -1357,7 +1560,9 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             if (const char* e = getenv("BADGER_AMD_DJ_L1")) l1 = (uint32_t)std::min(10, std::max(8, atoi(e)));      // (for measurements)
             const uint32_t nb1 = 1u << l1;
             uint32_t l2_max = std::min(10u, keybits - l1 - 4u);
-            uint32_t target = DJ_CAP / 2u;                                          // entries a fine bucket should hold
+            // the pair walk: a wave per fine bucket of at most wcap entries (1: the block kernel for every bucket, a cross-check)
+            static const int pairs_form = [] { const char* e = getenv("BADGER_AMD_DJ_WCAP"); const int x = e ? atoi(e) : 256; return x == 1 || x == 512 ? x : 256; }();
+            uint32_t target = pairs_form == 1 ? DJ_CAP / 2u : (uint32_t)pairs_form / 2u;      // entries a fine bucket should hold
             if (const char* e = getenv("BADGER_AMD_DJ_TARGET")) target = (uint32_t)std::max(1, atoi(e));          // (for tests: oversize buckets)
             if (const char* e = getenv("BADGER_AMD_DJ_L2MAX")) l2_max = (uint32_t)std::min((int)l2_max, std::max(0, atoi(e)));
             uint32_t tiles_want = (uint32_t)ctx->g_cus * 8u;
@@ -1366,13 +1571,14 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             const uint32_t ntiles = (n + rows_per_tile - 1u) / rows_per_tile;
             // workspace: hist [ntiles][nb1] | tot [nb1] | geom | base u64 [nb1 + 1] | fstart [(nb1 << l2_max) + 1]; entries twice
             const size_t w_hist = (size_t)ntiles * nb1, w_fstart = ((size_t)nb1 << l2_max) + 1;
-            const size_t small_bytes = 4 * (w_hist + nb1 + bdgpart::G_WORDS + w_fstart) + 8 * ((size_t)nb1 + 1) + 64;
+            const size_t small_bytes = 4 * (w_hist + nb1 + bdgpart::G_WORDS + 2 * w_fstart) + 8 * ((size_t)nb1 + 1) + 64;
             if ((rc = bdg_reserve(ctx, ctx->g_sig, small_bytes))) return rc;            // (the sweep's signature buffer is free here)
             auto* base = static_cast<unsigned long long*>(ctx->g_sig.p);
             auto* hist = reinterpret_cast<uint32_t*>(base + nb1 + 1);
             auto* tot = hist + w_hist;
             auto* geom = tot + nb1;
             auto* fstart = geom + bdgpart::G_WORDS;
+            auto* ovf = fstart + w_fstart;                                          // [0] unused, then the buckets left to the block kernel
             if ((rc = bdg_reserve(ctx, ctx->g_qj, 4ull * 2ull * (cap_ent + 64)))) return rc;
             auto* e_a = static_cast<uint32_t*>(ctx->g_qj.p);
             auto* e_b = e_a + cap_ent + 64;
@@ -1397,11 +1603,22 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             }
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_pairs" : "k_d2_pairs");
-                const uint32_t pgrid = (uint32_t)ctx->g_cus * d2_pairs_blocks_per_cu();
-                if (one_deletion) hipLaunchKernelGGL((k_d2_pairs<1, DJ_THREADS, DJ_CAP, DJ_ECAPW>), dim3(pgrid), dim3(DJ_THREADS), 0, st, e_b, fstart, geom, l1,
-                                                     d_ranks, row_begin, row_end, thr, qgram_T, d_out, cap, cnt);
-                else hipLaunchKernelGGL((k_d2_pairs<2, DJ_THREADS, DJ_CAP, DJ_ECAPW>), dim3(pgrid), dim3(DJ_THREADS), 0, st, e_b, fstart, geom, l1,
-                                        d_ranks, row_begin, row_end, thr, qgram_T, d_out, cap, cnt);
+#define BDG_PAIRS_W(NDEL, WCAP) hipLaunchKernelGGL((k_d2_pairs_w<NDEL, WCAP, DJ_ECAPW>), dim3(wgrid), dim3(256), 0, st, e_b, fstart, geom, l1, \
+                                                   d_ranks, row_begin, row_end, thr, qgram_T, d_out, cap, cnt, ovf)
+#define BDG_PAIRS_B(NDEL, GRID, LIST) hipLaunchKernelGGL((k_d2_pairs<NDEL, DJ_THREADS, DJ_CAP, DJ_ECAPW>), dim3(GRID), dim3(DJ_THREADS), 0, st, e_b, fstart, geom, l1, \
+                                                         d_ranks, row_begin, row_end, thr, qgram_T, d_out, cap, cnt, LIST)
+                const uint32_t bgrid = (uint32_t)ctx->g_cus * 3u;                   // (53 KB of LDS a block of 8 waves: three fit a compute unit)
+                if (pairs_form == 1) {
+                    if (one_deletion) BDG_PAIRS_B(1, bgrid, (const uint32_t*)nullptr); else BDG_PAIRS_B(2, bgrid, (const uint32_t*)nullptr);
+                } else {
+                    const uint32_t wgrid = (uint32_t)ctx->g_cus * d2_pairs_blocks_per_cu();
+                    if (pairs_form == 512) { if (one_deletion) BDG_PAIRS_W(1, 512); else BDG_PAIRS_W(2, 512); }
+                    else { if (one_deletion) BDG_PAIRS_W(1, 256); else BDG_PAIRS_W(2, 256); }
+                    // what the waves left: buckets beyond their capacity (none on any data met so far; the launch is a few microseconds)
+                    if (one_deletion) BDG_PAIRS_B(1, (uint32_t)ctx->g_cus, ovf); else BDG_PAIRS_B(2, (uint32_t)ctx->g_cus, ovf);
+                }
+#undef BDG_PAIRS_W
+#undef BDG_PAIRS_B
             }
             BDG_HIP_TRY(ctx, hipGetLastError());
             ctx->g_dj_geom = geom;                                                // (bdg_graph_status: what the device reported)
