@@ -16,9 +16,10 @@
 
 namespace {
 
-constexpr uint32_t DS_CAP = 2048;                // pairs a block sorts in LDS at a time
+constexpr uint32_t DS_SLOTS = 2048;              // slots of the hash table a block counts one bucket's ranks in,
+constexpr uint32_t DS_DCAP = 1536;               // different ranks it may hold,
+constexpr uint32_t DS_CAP = 1024;                // pairs a fine bucket should hold on average (about 600 different ranks on bench data)
 constexpr int DS_THREADS = 256;
-constexpr uint32_t DS_PER = DS_CAP / DS_THREADS;
 
 // level 1 (bdg_partition.hpp), run twice over tiles of records: counts per coarse bucket (the rank's top l1 bits), then the
 // pairs at their places.  Records without a usable barcode take no part; out_n[1] counts the 16-base barcodes with a non-ACGT base.
@@ -49,20 +50,29 @@ void k_distinct_rows(const bdg_extract_rec* __restrict__ recs, uint32_t n, uint3
     }
 }
 
-// One fine bucket per block at a time: its pairs sorted in LDS, the runs (rank, length, first index) written to the
-// bucket's own stretch of the temporary arrays, their number to nuniq[bucket].
+// One fine bucket per block at a time: the runs (rank, how often, first index) of its pairs, written in ascending order
+// to the bucket's own stretch of the temporary arrays, their number to nuniq[bucket].
+// Neither a comparison network (a bitonic sort of a thousand pairs is 55 phases with a block barrier each) nor anything
+// quadratic in how often a barcode repeats (a cell's exact barcode comes a thousand times in a million reads): the pairs
+// stream through a hash table in LDS - one atomic compare-and-swap finds or claims the rank's slot, an add counts, a minimum
+// keeps the first index - so that a bucket may hold any number of pairs as long as its DIFFERENT ranks fit the table.
+// The different ranks are then put in order: a counting pass over bins named by the rank's next bits (order-preserving,
+// about one rank per bin), and inside a bin a rank's place is the number of smaller ones.  A bucket with more different
+// ranks than the table takes (a device-side choice of the bucket count from the number of pairs normally prevents it) is
+// taken apart by the next two key bits, each part through the same code.
 __global__ __launch_bounds__(DS_THREADS)
 void k_distinct_buckets(const unsigned long long* __restrict__ ent, const uint32_t* __restrict__ fstart,
                         const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom, uint32_t l1,
                         uint32_t* __restrict__ t_uniq, uint32_t* __restrict__ t_count, uint32_t* __restrict__ t_first,
                         uint32_t* __restrict__ nuniq)
 {
-    __shared__ unsigned long long s_e[DS_CAP];
-    __shared__ uint32_t s_head[DS_CAP];
-    __shared__ uint32_t s_hist[4][256];
+    constexpr uint32_t SLOTS = DS_SLOTS, NBIN = DS_SLOTS, LBIN = 31u - (uint32_t)__builtin_clz(DS_SLOTS), SPER = SLOTS / DS_THREADS;
+    __shared__ uint32_t s_hk[SLOTS], s_hc[SLOTS], s_hf[SLOTS];      // the table: rank, how often, first index
+    __shared__ uint32_t s_bin[NBIN + 1];
+    __shared__ unsigned long long s_e[DS_DCAP + DS_THREADS];         // rank << 32 | slot, grouped by bin
+    __shared__ uint32_t st_bits[14], st_val[14], st_next[14];
     __shared__ uint32_t s_w[DS_THREADS / 64 + 1];
-    __shared__ unsigned long long s_r[4][DS_THREADS / 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ uint32_t s_new;
     if (geom[bdgpart::G_FLAGS] & 1u) return;
     const uint32_t l2 = fstart ? geom[bdgpart::G_L2] : 0u;
     const uint32_t nfb = 1u << (l1 + l2);
@@ -70,106 +80,92 @@ void k_distinct_buckets(const unsigned long long* __restrict__ ent, const uint32
         const uint32_t start = fstart ? fstart[fb] : (uint32_t)base[fb];
         const uint32_t cnt = (fstart ? fstart[fb + 1u] : (uint32_t)base[fb + 1u]) - start;
         uint32_t emitted = 0;
-        // the pairs of [start, start + cnt) whose rank has the top `bits` bits `val` (at most DS_CAP of them): sorted, their runs written
-        auto sort_emit = [&](uint32_t bits, uint32_t val) {
-            if (threadIdx.x == 0) s_w[DS_THREADS / 64] = 0u;
+        // the pairs of [start, start + cnt) whose rank has the top `bits` bits `val`: their runs, ascending - unless they hold
+        // more than DS_DCAP different ranks (returns false, nothing written)
+        auto group_emit = [&](uint32_t bits, uint32_t val) -> bool {
+            const uint32_t EMPTY = val == (uint32_t)((1ull << bits) - 1ull) ? 0u : 0xFFFFFFFFu;      // (a rank that does not have this prefix)
+#pragma unroll
+            for (uint32_t j = 0; j < SPER; ++j) { const uint32_t i = j * DS_THREADS + threadIdx.x; s_hk[i] = EMPTY; s_hc[i] = 0u; s_hf[i] = 0xFFFFFFFFu; }
+            if (threadIdx.x == 0) s_new = 0u;
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < cnt; i += DS_THREADS) {
-                const unsigned long long e = ent[start + i];
-                if ((uint32_t)(e >> (64u - bits)) == val) s_e[atomicAdd(&s_w[DS_THREADS / 64], 1u)] = e;
-            }
-            __syncthreads();
-            const uint32_t held = s_w[DS_THREADS / 64];
-            uint32_t N = 64;
-            while (N < held) N <<= 1;
-            for (uint32_t i = held + threadIdx.x; i < N; i += DS_THREADS) s_e[i] = ~0ull;
-            __syncthreads();
-            for (uint32_t k = 2; k <= N; k <<= 1)
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    for (uint32_t t = threadIdx.x; t < N / 2u; t += DS_THREADS) {
-                        const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
-                        const unsigned long long x = s_e[i], y = s_e[l];
-                        if ((x > y) == ((i & k) == 0u)) { s_e[i] = y; s_e[l] = x; }
+            for (uint32_t i0 = threadIdx.x; i0 < cnt; i0 += 4u * DS_THREADS) {
+                unsigned long long e[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) e[u] = i0 + u * DS_THREADS < cnt ? ent[start + i0 + u * DS_THREADS] : 0ull;
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    if (i0 + u * DS_THREADS >= cnt || (uint32_t)(e[u] >> (64u - bits)) != val) continue;
+                    if (*(volatile uint32_t*)&s_new > DS_DCAP) continue;           // (too many different ranks: the attempt is void)
+                    const uint32_t k = (uint32_t)(e[u] >> 32);
+                    uint32_t h = (k * 0x9E3779B1u) >> (32u - LBIN);
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&s_hk[h], EMPTY, k);
+                        if (old == EMPTY) atomicAdd(&s_new, 1u);
+                        if (old == EMPTY || old == k) { atomicAdd(&s_hc[h], 1u); atomicMin(&s_hf[h], (uint32_t)e[u]); break; }
+                        h = (h + 1u) & (SLOTS - 1u);                                // (never full: at most DS_DCAP + a block's threads claim a slot)
                     }
-                    __syncthreads();
                 }
-            // runs: a thread looks at DS_PER consecutive places
-            uint32_t heads = 0;
-            const uint32_t i0 = threadIdx.x * DS_PER;
-#pragma unroll
-            for (uint32_t j = 0; j < DS_PER; ++j) {
-                const uint32_t i = i0 + j;
-                if (i < held && (i == 0u || (uint32_t)(s_e[i] >> 32) != (uint32_t)(s_e[i - 1u] >> 32))) heads |= 1u << j;
             }
-            uint32_t nrun;
-            uint32_t at = bdgpart::block_excl_scan<DS_THREADS>((uint32_t)__popc(heads), s_w, nrun);
+            __syncthreads();
+            const uint32_t D = s_new;
+            if (D > DS_DCAP) { __syncthreads(); return false; }
+            // the different ranks in order: bins by the next key bits, then by comparison inside a bin
+            const uint32_t rb = 32u - bits, lb = rb < LBIN ? rb : LBIN, bsh = rb - lb, bmask = (1u << lb) - 1u;
 #pragma unroll
-            for (uint32_t j = 0; j < DS_PER; ++j) if (heads >> j & 1u) s_head[at++] = i0 + j;
+            for (uint32_t j = 0; j < SPER; ++j) s_bin[threadIdx.x * SPER + j] = 0u;
             __syncthreads();
-            for (uint32_t j = threadIdx.x; j < nrun; j += DS_THREADS) {
-                const uint32_t i = s_head[j], nxt = j + 1u < nrun ? s_head[j + 1u] : held;
-                const unsigned long long e = s_e[i];
-                const size_t o = (size_t)start + emitted + j;
-                t_uniq[o] = (uint32_t)(e >> 32); t_count[o] = nxt - i; t_first[o] = (uint32_t)e;
+            uint32_t key[SPER], rk[SPER];
+#pragma unroll
+            for (uint32_t j = 0; j < SPER; ++j) {
+                key[j] = s_hk[j * DS_THREADS + threadIdx.x]; rk[j] = 0;
+                if (key[j] != EMPTY) rk[j] = atomicAdd(&s_bin[(key[j] >> bsh) & bmask], 1u);
             }
-            emitted += nrun;
             __syncthreads();
+            uint32_t c[SPER], sum = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < SPER; ++j) { c[j] = s_bin[threadIdx.x * SPER + j]; sum += c[j]; }
+            uint32_t held;
+            uint32_t run = bdgpart::block_excl_scan<DS_THREADS>(sum, s_w, held);
+#pragma unroll
+            for (uint32_t j = 0; j < SPER; ++j) { s_bin[threadIdx.x * SPER + j] = run; run += c[j]; }
+            if (threadIdx.x == 0) s_bin[NBIN] = held;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < SPER; ++j)
+                if (key[j] != EMPTY) s_e[s_bin[(key[j] >> bsh) & bmask] + rk[j]] = (unsigned long long)key[j] << 32 | (j * DS_THREADS + threadIdx.x);
+            __syncthreads();
+            for (uint32_t pos = threadIdx.x; pos < D; pos += DS_THREADS) {
+                const unsigned long long e = s_e[pos];
+                const uint32_t k = (uint32_t)(e >> 32), slot = (uint32_t)e, b = (k >> bsh) & bmask;
+                const uint32_t bs = s_bin[b], be = s_bin[b + 1u];
+                uint32_t smaller = 0;
+                for (uint32_t i = bs; i < be; ++i) smaller += (uint32_t)(s_e[i] >> 32) < k ? 1u : 0u;
+                const size_t o = (size_t)start + emitted + bs + smaller;
+                t_uniq[o] = k; t_count[o] = s_hc[slot]; t_first[o] = s_hf[slot];
+            }
+            emitted += D;
+            __syncthreads();
+            return true;
         };
         if (cnt == 0u) { if (threadIdx.x == 0) nuniq[fb] = 0u; continue; }
-        if (cnt <= DS_CAP) { sort_emit(l1 + l2, fb); if (threadIdx.x == 0) nuniq[fb] = emitted; continue; }
-        // cold path: the bucket is taken apart by the next key bits, eight at a time (ascending, so the output stays in order)
-        uint32_t st_bits[5], st_val[5], st_next[5], st_w[5];
+        if (group_emit(l1 + l2, fb)) { if (threadIdx.x == 0) nuniq[fb] = emitted; continue; }
+        // cold path: the bucket is taken apart by the next key bits, two at a time (ascending, so the output stays in order).
+        // The stack lives in LDS (indexing a private array by the depth would put it into scratch memory); thread 0 writes it
+        // between two barriers, everybody reads it behind them.
         int sp = 0;
-        st_bits[0] = l1 + l2; st_val[0] = fb; st_next[0] = 0xFFFFFFFFu; st_w[0] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) { st_bits[0] = l1 + l2; st_val[0] = fb; st_next[0] = 0u; }
         while (sp >= 0) {
-            const uint32_t bits = st_bits[sp], val = st_val[sp];
-            if (st_next[sp] == 0xFFFFFFFFu) {
-                // how many pairs this prefix holds, their smallest and largest rank, the smallest index
-                unsigned long long c = 0, kmin = ~0ull, kmax = 0, imin = ~0ull;
-                for (uint32_t i = threadIdx.x; i < cnt; i += DS_THREADS) {
-                    const unsigned long long e = ent[start + i];
-                    if ((uint32_t)(e >> (64u - bits)) != val) continue;
-                    const unsigned long long k = e >> 32, ix = e & 0xFFFFFFFFull;
-                    ++c; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; imin = ix < imin ? ix : imin;
-                }
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    c += __shfl_xor(c, d);
-                    const unsigned long long a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d), m = __shfl_xor(imin, d);
-                    kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; imin = m < imin ? m : imin;
-                }
-                if (lane == 0) { s_r[0][wv] = c; s_r[1][wv] = kmin; s_r[2][wv] = kmax; s_r[3][wv] = imin; }
-                __syncthreads();
-                c = 0; kmin = ~0ull; kmax = 0; imin = ~0ull;
-#pragma unroll
-                for (int w = 0; w < DS_THREADS / 64; ++w) {
-                    c += s_r[0][w]; kmin = s_r[1][w] < kmin ? s_r[1][w] : kmin; kmax = s_r[2][w] > kmax ? s_r[2][w] : kmax;
-                    imin = s_r[3][w] < imin ? s_r[3][w] : imin;
-                }
-                __syncthreads();
-                if (c == 0ull) { --sp; continue; }
-                if (kmin == kmax) {                                          // one rank, however often: a run
-                    if (threadIdx.x == 0) { const size_t o = (size_t)start + emitted; t_uniq[o] = (uint32_t)kmin; t_count[o] = (uint32_t)c; t_first[o] = (uint32_t)imin; }
-                    ++emitted; --sp; continue;
-                }
-                if (c <= DS_CAP) { sort_emit(bits, val); --sp; continue; }
-                const uint32_t w = 32u - bits < 8u ? 32u - bits : 8u;            // (bits < 32: two different ranks share this prefix)
-                s_hist[sp][threadIdx.x] = 0u;
-                __syncthreads();
-                for (uint32_t i = threadIdx.x; i < cnt; i += DS_THREADS) {
-                    const unsigned long long e = ent[start + i];
-                    if ((uint32_t)(e >> (64u - bits)) == val) atomicAdd(&s_hist[sp][(uint32_t)(e >> (64u - bits - w)) & ((1u << w) - 1u)], 1u);
-                }
-                __syncthreads();
-                st_next[sp] = 0; st_w[sp] = w;
-            }
-            const uint32_t w = st_w[sp];
-            uint32_t ch = st_next[sp];
-            while (ch < (1u << w) && s_hist[sp][ch] == 0u) ++ch;
-            if (ch == (1u << w)) { --sp; continue; }
-            st_next[sp] = ch + 1u;
+            __syncthreads();
+            const uint32_t bits = st_bits[sp], val = st_val[sp], ch = st_next[sp];
+            __syncthreads();
+            const uint32_t w = 32u - bits < 2u ? 32u - bits : 2u;             // (bits < 32: more than one rank shares this prefix)
+            if (ch >= (1u << w)) { --sp; continue; }
+            if (threadIdx.x == 0) st_next[sp] = ch + 1u;
+            const uint32_t cb = bits + w, cv = (val << w) | ch;
+            if (group_emit(cb, cv)) continue;
+            if (threadIdx.x == 0) { st_bits[sp + 1] = cb; st_val[sp + 1] = cv; st_next[sp + 1] = 0u; }
             ++sp;
-            st_bits[sp] = bits + w; st_val[sp] = (val << w) | ch; st_next[sp] = 0xFFFFFFFFu; st_w[sp] = 0;
         }
         if (threadIdx.x == 0) nuniq[fb] = emitted;
     }
@@ -284,8 +280,8 @@ int bdg_distinct_launch(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
     // geometry: coarse buckets by the rank's top l1 bits; below about a million records they are the fine buckets already
     // (no second level), beyond that the device picks the sub-bucket count from the number of usable records
     uint32_t l1 = 8;
-    while (l1 < 10u && (n >> l1) > DS_CAP / 2u) ++l1;
-    const bool two_levels = (n >> l1) > DS_CAP / 2u;
+    while (l1 < 10u && (n >> l1) > DS_CAP) ++l1;
+    const bool two_levels = (n >> l1) > DS_CAP;
     const uint32_t nb1 = 1u << l1, l2_max = two_levels ? 10u : 0u;
     uint32_t per_tile = ((n + cus * 8u - 1u) / (cus * 8u) + 255u) & ~255u;
     const uint32_t ntiles = (n + per_tile - 1u) / per_tile;
@@ -311,7 +307,7 @@ int bdg_distinct_launch(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
         ScopedKernelTimer tm(ctx, "k_distinct_rows");
         hipLaunchKernelGGL(k_distinct_rows<false>, dim3(ntiles), dim3(256), 0, st, d_recs, n, per_tile, l1, hist, base, geom, e_a, d_n);
         hipLaunchKernelGGL(bdgpart::k_part_colscan, dim3(nb1), dim3(256), 0, st, hist, ntiles, nb1, tot);
-        hipLaunchKernelGGL(bdgpart::k_part_bases, dim3(1), dim3(1024), 0, st, tot, nb1, DS_CAP / 2u, l2_max, (unsigned long long)n, base, geom);
+        hipLaunchKernelGGL(bdgpart::k_part_bases, dim3(1), dim3(1024), 0, st, tot, nb1, DS_CAP, l2_max, (unsigned long long)n, base, geom);
         hipLaunchKernelGGL(k_distinct_rows<true>, dim3(ntiles), dim3(256), 0, st, d_recs, n, per_tile, l1, hist, base, geom, e_a, d_n);
         if (two_levels) hipLaunchKernelGGL(bdgpart::k_part_split<unsigned long long>, dim3(nb1), dim3(1024), 0, st, e_a, e_b, base, geom, nb1, 64u - l1, fstart);
     }

@@ -1588,7 +1588,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
                 else hipLaunchKernelGGL(k_d2_rows<false>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
             }
             {
-                ScopedKernelTimer tm(ctx, "k_part_scan");
+                ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_scan" : "k_d2_scan");
                 hipLaunchKernelGGL(bdgpart::k_part_colscan, dim3(nb1), dim3(256), 0, st, hist, ntiles, nb1, tot);
                 hipLaunchKernelGGL(bdgpart::k_part_bases, dim3(1), dim3(1024), 0, st, tot, nb1, target, l2_max, cap_ent, base, geom);
             }
@@ -1598,7 +1598,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
                 else hipLaunchKernelGGL(k_d2_rows<true>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
             }
             {
-                ScopedKernelTimer tm(ctx, "k_part_split");
+                ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_split" : "k_d2_split");
                 hipLaunchKernelGGL(bdgpart::k_part_split<uint32_t>, dim3(nb1), dim3(1024), 0, st, e_a, e_b, base, geom, nb1, keybits - l1, fstart);
             }
             {

@@ -43,8 +43,23 @@ from badger_amd import dist as bdist  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def host_cores():
+def cores_visible():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def host_cores():
+    """CPUs this job may actually use: the cgroup's quota (a GPU box shows 256 CPUs and gives a job 16), else the affinity mask.
+    The CPU legs run this many OpenMP threads and report this number as `cores`."""
+    vis = cores_visible()
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ("max", "-1") and int(period) > 0:
+                return max(1, min(vis, int(round(int(quota) / int(period)))))
+        except Exception:
+            continue
+    return vis
 
 
 def cpu_baseline(bases_dev, off_dev, wl, device_out=None):
@@ -98,9 +113,10 @@ def cpu_baseline(bases_dev, off_dev, wl, device_out=None):
     t0 = time.perf_counter()
     orc.nearest16(qe, wl, 2, threads=cores)
     near_exh = len(qe) / (time.perf_counter() - t0)
-    return {"value": 1.0 / (1.0 / ext_all + 1.0 / near_all), "unit": "calls/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / (1.0 / ext_all + 1.0 / near_all), "unit": "calls/s", "cores": cores, "cores_usable": cores,
+            "cores_visible": cores_visible(), "kind": "port",
             "sample": "%d reads through the oracle's extract_batch + their %d barcodes through the oracle's neighbourhood-probe "
-                      "nearest16 against the %d-entry whitelist, OpenMP over all %d cores; 1-core legs on %d reads / %d barcodes; "
+                      "nearest16 against the %d-entry whitelist, OpenMP over the %d CPUs of the job's quota; 1-core legs on %d reads / %d barcodes; "
                       "exhaustive-scan leg on %d barcodes" % (n_all, len(q), len(wl), cores, n_one, len(q1), len(qe)),
             "extract_reads_per_s": ext_all, "extract_reads_per_s_1core": ext_one,
             "nearest_probe_calls_per_s": near_all, "nearest_probe_calls_per_s_1core": near_one,
@@ -220,37 +236,42 @@ def clock_ramp(step, dev, seconds=RAMP_S):
     return k
 
 
-def bench_graph(args, rank, world, dev, local_dev):
-    """BASELINE configs 3 / 5 (graph part): K3 over 500K distinct barcodes, thr 1 (one-deletion join) or thr 2
-    (deletion-variant join).  Every rank holds the whole sorted array and builds its share of the edge list, no collective."""
+GRAPH_PATHS = {"k_graph_probe": ("neighbourhood probes", "blocks of equal rows"),
+               "k_d1_pairs": ("one-deletion join", "shares of the 15-mer groups"),
+               "k_d1_emit": ("one-deletion join", "shares of the 15-mer groups"),
+               "k_graph_qjoin_w": ("q-gram join", "row blocks of equal pair counts"),
+               "k_graph_qjoin": ("q-gram join, closed form", "row blocks of equal pair counts"),
+               "k_graph_scan": ("all-pairs sweep", "row blocks of equal pair counts")}
+
+
+def measure_graph(args, rank, world, dev, ctx, thr, n, wl, steps, warmup, ramp, cpu_check):
+    """One graph configuration of BASELINE.json (config 3: thr 1, config 5: thr 2): K3 over n distinct observed barcodes,
+    every rank its share of the edge list (bdg_graph_edges_part_dev, no collective).  Returns the block of figures rank 0
+    prints: time per pass, rows/s, edges, every kernel of the pass (whatever its name: nothing on this path is a library
+    call any more), the roofline block of the one that takes longest, the whole pass against the HBM roofline, and - at one
+    GPU - the CPU oracle on the same rows, whose whole edge list is the checker."""
     from oracle import pyoracle as orc
-    thr = 1 if args.config == 3 else 2
-    n = args.rows
-    wl = synth.make_whitelist(args.whitelist)
+    from badger_amd.barcode_graph import qgram_threshold
     ranks = observed_barcodes(n, wl)
-    T = orc.qgram_threshold(thr)
-    # one of `world` shares of the edge list per rank, cut by the library (bdg_graph_edges_part_dev): thr 1 / 2 - shares of the
-    # 15-mer / 14-mer groups of the deletion-variant joins (--graph-algo 2, the probes: blocks of equal rows); the q-gram join
-    # (thr >= 3, or --graph-algo 3) - blocks of equal pair counts (a row walks its bucket tails behind it, ~ n - i)
+    T = qgram_threshold(thr, 16)                       # (the product path's own: index.py:22-24)
     d_ranks = torch.from_numpy(ranks.view(np.int32)).to(dev)
     cap = 32 * n
     d_edges = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
     d_n = torch.zeros(1, dtype=torch.int64, device=dev)
-    ctx = _native.Context(local_dev)
-    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     ctx.graph_set_algo(args.graph_algo)
 
     def step():
         ctx.graph_edges_part_dev(d_ranks, n, rank, world, thr, T, d_edges, cap, d_n)
 
-    ramp_steps = clock_ramp(step, dev) if not args.no_ramp else 0
-    for _ in range(max(1, args.warmup)):
+    ramp_steps = clock_ramp(step, dev) if ramp else 0
+    for _ in range(max(1, warmup)):
         step()
     ctx.profile(True)
     ctx.profile_reset()
-    elapsed = bdist.timed(step, args.steps, dev)
+    elapsed = bdist.timed(step, steps, dev)
     prof = ctx.profile_read()
     ctx.profile(False)
+    ctx.graph_status()                                 # (what the asynchronous calls could not return)
     ne = int(d_n[0])
     if ne > cap:
         raise SystemExit("edge capacity too small: %d > %d" % (ne, cap))
@@ -267,70 +288,105 @@ def bench_graph(args, rank, world, dev, local_dev):
             status = "edge (%d, %d, %d) is not an edge by the oracle" % (int(a), int(b), int(d))
     ne_all = int(bdist.all_sum(ne, dev))
     fails = bdist.all_max(0.0 if status == "ok" else 1.0, dev)
+    if fails:
+        if status != "ok":
+            sys.stderr.write("rank %d: %s\n" % (rank, status))
+        raise SystemExit("parity sample failed (graph, threshold %d)" % thr)
+    if rank != 0:
+        return None
+    per_launch_ms = {k: v[1] / max(1, v[0]) for k, v in prof.items() if v[0]}
+    dom = max(per_launch_ms, key=per_launch_ms.get)    # the kernel that takes longest, whatever it is called
+    path, share = GRAPH_PATHS.get(dom, ("deletion-variant join", "shares of the 14-mer groups"))
+    ms_per_pass = elapsed / steps * 1e3
+    alg = 4 * n + 9 * ne                               # 4n in + 9E out (rank's own edges)
+    achieved = alg / (per_launch_ms[dom] * 1e-3) / 1e9
+    pc = profile_counters(dom)
+    # HBM is not what binds these kernels (L2-resident gathers, LDS counters, integer issue): say how close they are to the
+    # ceilings that could - vector-instruction issue (1024 SIMDs, one wave64 instruction per 4 clocks) and the LDS arrays
+    # (one cycle per lane group and CU, MI355X_MICROARCH.md "LDS") - from the committed counter passes of this build
+    t_dom = per_launch_ms[dom] * 1e-3
+    issue_peak, lds_peak = 1024 * 2.4e9 / 4.0, 256 * 2.4e9
+    int_issue = None if pc["valu"] is None else {"valu_insts_per_launch": pc["valu"], "achieved": pc["valu"] / t_dom, "peak": issue_peak,
+                                                 "unit": "wave-instr/s", "frac": pc["valu"] / t_dom / issue_peak}
+    lds_use = None if pc["lds"] is None else {"lds_cycles_per_launch": pc["lds"]["cycles"], "bank_conflict_cycles": pc["lds"]["conflict_cycles"],
+                                              "achieved": pc["lds"]["cycles"] / t_dom, "peak": lds_peak, "unit": "LDS-array cycles/s (256 CUs)",
+                                              "frac": pc["lds"]["cycles"] / t_dom / lds_peak}
+    whole = alg / (ms_per_pass * 1e-3) / 1e9
+    block = {
+        "threshold": thr, "rows": n, "qgram_T": T, "path": path, "ms_per_pass": ms_per_pass, "rows_per_s": n / (elapsed / steps),
+        "steps": steps, "warmup": warmup, "edges_rank0": ne, "edges_all_ranks": ne_all,
+        "parallelism": "one share of the edge list per GPU (bdg_graph_edges_part_dev: %s), no collectives" % share,
+        "clock_ramp": "%d untimed passes before the %d warm-up passes" % (ramp_steps, warmup),
+        "kernels_ms_per_pass": {k: round(v, 4) for k, v in sorted(per_launch_ms.items())},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pc["traffic"], "traffic_source": pc["source"],
+                     "algorithmic_bytes_per_launch": alg, "kernel_ms": per_launch_ms[dom], "int_issue": int_issue, "lds": lds_use},
+        "whole_pass": {"algorithmic_bytes": alg, "achieved": whole, "unit": "GB/s", "frac_of_hbm_peak": whole / HBM_PEAK_GBS,
+                       "traffic_all_kernels": profile_counters_sum(per_launch_ms)},
+        "parity_sample": "ok",
+    }
+    if cpu_check and world == 1:
+        # the whole job on the host cores: same rows, same index, and its edge list is the checker for the device's
+        cores = host_cores()
+        t0 = time.perf_counter()
+        want, t_index, t_rows = orc.graph_edges_sampled(ranks, thr, 1, T, threads=cores, cap=ne + 1)
+        t_all = time.perf_counter() - t0
+        got = e[np.lexsort((e[:, 1], e[:, 0]))]
+        same = len(want) == ne and np.array_equal(got[:, 0], want["a"]) and np.array_equal(got[:, 1], want["b"]) \
+            and np.array_equal(got[:, 2], want["dist"])
+        if not same:
+            raise SystemExit("parity failed: the device's edge list differs from the oracle's (%d against %d edges)" % (ne, len(want)))
+        block["parity_sample"] = "ok (all %d edges equal the oracle's)" % ne
+        block["cpu_baseline"] = {"value": n / (t_index + t_rows), "unit": "rows/s", "cores": cores, "cores_usable": cores,
+                                 "cores_visible": cores_visible(), "kind": "port",
+                                 "sample": "oracle graph_edges (QGramIndex buckets + 3 Levenshtein per candidate, "
+                                           "barcode_graph.py:207-249) on the same %d rows, OpenMP over %d CPUs: index %.2f s, "
+                                           "rows %.2f s (sorting the edge list for the comparison, %.2f s more, is not counted)"
+                                           % (n, cores, t_index, t_rows, t_all - t_index - t_rows)}
+    elif cpu_check:
+        # several GPUs: the shares must add up to the oracle's list (each rank checked its own for repeats and soundness)
+        want, _, _ = orc.graph_edges_sampled(ranks, thr, 1, T, threads=host_cores(), cap=ne_all + 1)
+        if len(want) != ne_all:
+            raise SystemExit("parity failed: the ranks' shares hold %d edges, the oracle's list %d" % (ne_all, len(want)))
+        block["parity_sample"] = "ok (the %d shares hold the oracle's %d edges; every rank: no repeats, 3000 sampled edges sound)" % (world, ne_all)
+    return block
+
+
+def profile_counters_sum(per_launch_ms):
+    """HBM bytes of all the kernels of a pass together (committed counter passes of this very build), or None"""
+    total = 0.0
+    for k in per_launch_ms:
+        t = profile_counters(k)["traffic"]
+        if t is None:
+            return None
+        total += t if not isinstance(t, (list, tuple)) else t[-1]
+    return total
+
+
+def bench_graph(args, rank, world, dev, local_dev):
+    """`--config 3` / `--config 5`: the graph configuration alone, as a line of the headline's shape."""
+    thr = 1 if args.config == 3 else 2
+    n = args.rows
+    wl = synth.make_whitelist(args.whitelist)
+    ctx = _native.Context(local_dev)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    blk = measure_graph(args, rank, world, dev, ctx, thr, n, wl, args.steps, args.warmup, not args.no_ramp, not args.no_cpu_baseline)
     if rank == 0:
-        if fails:
-            raise SystemExit("parity sample failed: " + status)
-        per_launch_ms = {k: v[1] / max(1, v[0]) for k, v in prof.items() if v[0]}
-        own = {k: v for k, v in per_launch_ms.items() if k.startswith("k_")}          # (d2_sort is hipCUB's radix sort: listed, not analysed)
-        dom = max(own, key=own.get)
-        path, share = {"k_graph_probe": ("neighbourhood probes", "blocks of equal rows"),
-                       "k_d1_pairs": ("one-deletion join", "shares of the 15-mer groups"),
-                       "k_graph_qjoin_w": ("q-gram join", "row blocks of equal pair counts"),
-                       "k_graph_qjoin": ("q-gram join, closed form", "row blocks of equal pair counts"),
-                       "k_graph_scan": ("all-pairs sweep", "row blocks of equal pair counts")}.get(
-                           dom, ("deletion-variant join", "shares of the 14-mer groups"))
-        alg = 4 * n + 9 * ne                           # 4n in + 9E out (rank's own edges)
-        achieved = alg / (per_launch_ms[dom] * 1e-3) / 1e9
-        pc = profile_counters(dom)
-        # HBM is not what binds these kernels (L2-resident gathers, LDS counters, integer issue): say how close they are to the
-        # ceilings that could - vector-instruction issue (1024 SIMDs, one wave64 instruction per 4 clocks) and the LDS arrays
-        # (one cycle per lane group and CU, MI355X_MICROARCH.md "LDS") - from the committed counter passes of this build
-        t_dom = per_launch_ms[dom] * 1e-3
-        issue_peak, lds_peak = 1024 * 2.4e9 / 4.0, 256 * 2.4e9
-        int_issue = None if pc["valu"] is None else {"valu_insts_per_launch": pc["valu"], "achieved": pc["valu"] / t_dom, "peak": issue_peak,
-                                                     "unit": "wave-instr/s", "frac": pc["valu"] / t_dom / issue_peak}
-        lds_use = None if pc["lds"] is None else {"lds_cycles_per_launch": pc["lds"]["cycles"], "bank_conflict_cycles": pc["lds"]["conflict_cycles"],
-                                                  "achieved": pc["lds"]["cycles"] / t_dom, "peak": lds_peak, "unit": "LDS-array cycles/s (256 CUs)",
-                                                  "frac": pc["lds"]["cycles"] / t_dom / lds_peak}
         line = {
-            "metric": "graph rows/sec, threshold=%d, %d distinct barcodes" % (thr, n), "value": n / (elapsed / args.steps),
+            "metric": "graph rows/sec, threshold=%d, %d distinct barcodes" % (thr, n), "value": blk["rows_per_s"],
             "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": blk["ms_per_pass"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BASELINE config %d: barcode_graph edges, threshold %d, %d distinct observed barcodes (%s)"
-                                   % (args.config, thr, n, path),
-                       "rows": n, "edges_rank0": ne, "edges_all_ranks": ne_all, "qgram_T": T,
-                       "parallelism": "one share of the edge list per GPU (bdg_graph_edges_part_dev: %s), no collectives" % share,
-                       "clock_ramp": "%d untimed steps (%.2f s) before the %d warm-up steps" % (ramp_steps, RAMP_S, args.warmup)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pc["traffic"], "traffic_source": pc["source"],
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": per_launch_ms[dom], "int_issue": int_issue, "lds": lds_use},
-            "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(per_launch_ms.items())},
-            "parity_sample": "ok",
+                                   % (args.config, thr, n, blk["path"]),
+                       "rows": n, "edges_rank0": blk["edges_rank0"], "edges_all_ranks": blk["edges_all_ranks"], "qgram_T": blk["qgram_T"],
+                       "parallelism": blk["parallelism"], "clock_ramp": blk["clock_ramp"]},
+            "roofline": blk["roofline"], "whole_pass": blk["whole_pass"],
+            "kernels_ms_per_step": blk["kernels_ms_per_pass"],
+            "parity_sample": blk["parity_sample"],
         }
-        if not args.no_cpu_baseline and world == 1:
-            # the whole job on the host cores: same rows, same index, and its edge list is the checker for the device's
-            cores = host_cores()
-            t0 = time.perf_counter()
-            want, t_index, t_rows = orc.graph_edges_sampled(ranks, thr, 1, T, threads=cores, cap=ne + 1)
-            t_all = time.perf_counter() - t0
-            got = e[np.lexsort((e[:, 1], e[:, 0]))]
-            same = len(want) == ne and np.array_equal(got[:, 0], want["a"]) and np.array_equal(got[:, 1], want["b"]) \
-                and np.array_equal(got[:, 2], want["dist"])
-            if not same:
-                raise SystemExit("parity failed: the device's edge list differs from the oracle's (%d against %d edges)" % (ne, len(want)))
-            line["parity_sample"] = "ok (all %d edges equal the oracle's)" % ne
-            line["cpu_baseline"] = {"value": n / (t_index + t_rows), "unit": "rows/s", "cores": cores, "kind": "port",
-                                    "sample": "oracle graph_edges (QGramIndex buckets + 3 Levenshtein per candidate, "
-                                              "barcode_graph.py:207-249) on the same %d rows, OpenMP over %d cores: index %.2f s, "
-                                              "rows %.2f s (sorting the edge list for the comparison, %.2f s more, is not counted)"
-                                              % (n, cores, t_index, t_rows, t_all - t_index - t_rows)}
-        elif not args.no_cpu_baseline:
-            # several GPUs: the shares must add up to the oracle's list (each rank checked its own for repeats and soundness)
-            want, _, _ = orc.graph_edges_sampled(ranks, thr, 1, T, threads=host_cores(), cap=ne_all + 1)
-            if len(want) != ne_all:
-                raise SystemExit("parity failed: the ranks' shares hold %d edges, the oracle's list %d" % (ne_all, len(want)))
-            line["parity_sample"] = "ok (the %d shares hold the oracle's %d edges; every rank: no repeats, 3000 sampled edges sound)" % (world, ne_all)
+        if "cpu_baseline" in blk:
+            line["cpu_baseline"] = blk["cpu_baseline"]
         print(json.dumps(line))
 
 
@@ -346,6 +402,7 @@ def main():
                     help="BASELINE.json config: 2 = the headline (K1 + K2), 3 = graph thr 1, 5 = graph thr 2")
     ap.add_argument("--rows", type=int, default=500000, help="distinct barcodes for --config 3 / 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="headline only: skip the graph passes (configs 3 and 5) behind the config-2 measurement")
     ap.add_argument("--graph-algo", type=int, default=0, help="--config 3 / 5: bdg_graph_set_algo (0: the library's choice)")
     ap.add_argument("--overlap", action="store_true",
                     help="batch pipelining: K2 of batch i on a second stream beside K1 of batch i+1 (bdg_set_overlap; about +7 %% calls/s, "
@@ -524,9 +581,16 @@ def bench_calls(args, rank, world, dev, local_dev):
                                           "kernel's mean over the timed region itself, where only it carries events" % table_steps,
             "parity_sample": "ok",
         }
-        if not args.no_cpu_baseline and world == 1:       # the CPU leg runs at N = 1 only (256 host threads would fight the other ranks)
+        if not args.no_cpu_baseline and world == 1:       # the CPU leg runs at N = 1 only (the host threads would fight the other ranks)
             line["cpu_baseline"] = cpu_baseline(bases, off_u, wl, (recs, best_idx, best_ed, n_ties))
             line["parity_sample"] = "ok (3 x 1000 records and calls after the timed region; " + line["cpu_baseline"].pop("checked") + ")"
+    # BASELINE configs 3 and 5 in the same line (one GPU): the graph passes at 500 K rows, thr 1 and thr 2, each with its
+    # kernel table, roofline block, CPU oracle on the same rows and the whole edge list compared
+    if world == 1 and not args.no_graph:
+        for key, thr in (("graph_thr1", 1), ("graph_thr2", 2)):
+            blk = measure_graph(args, rank, world, dev, ctx, thr, args.rows, wl, args.steps, args.warmup, not args.no_ramp, not args.no_cpu_baseline)
+            line[key] = blk
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
         bdist.barrier(dev)

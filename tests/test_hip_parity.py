@@ -773,6 +773,58 @@ def test_nearest16_and_graph_fuzz_clustered(ctx, orc, seed):
     ctx.graph_set_algo(0)
 
 
+def _records_of(ranks, usable=None):
+    recs = np.zeros(len(ranks), dtype=_native.REC_DTYPE)
+    recs["bc_rank"] = ranks
+    ok = np.ones(len(ranks), bool) if usable is None else usable
+    recs["valid"] = ok
+    recs["flags"] = np.where(ok, _native.FLAG_RANK_OK | _native.FLAG_BC16, 0)
+    return recs
+
+
+@pytest.mark.parametrize("case", ["one_rank", "two_ranks_low_bit", "dense_range", "hot_among_random", "two_levels", "narrow_prefix"])
+def test_distinct_dev_on_adversarial_counts(ctx, case):
+    """bdg_distinct_dev where the bucket a block groups in LDS overflows: one barcode seen 300,000 times, two that differ in
+    their last bit, 40,000 consecutive ranks, hot barcodes among random ones, an input large enough for the second bucket
+    level, and ranks that share their top 20 bits - always numpy's unique / first index / counts
+    (index_bc_single_thread, barcode_graph.py:192-204)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(hash(case) % 1000)
+    if case == "one_rank":
+        ranks = np.full(300000, 0x9ABCDEF1, dtype=np.uint32)
+    elif case == "two_ranks_low_bit":
+        ranks = (np.uint32(0x12345678) ^ rng.integers(0, 2, 70000).astype(np.uint32))
+    elif case == "dense_range":
+        ranks = (np.uint32(0x40000000) + rng.permutation(40000).astype(np.uint32))
+        ranks = np.concatenate([ranks, ranks[:5000]])
+    elif case == "hot_among_random":
+        hot = rng.integers(0, 1 << 32, 5, dtype=np.uint64).astype(np.uint32)
+        ranks = np.concatenate([rng.integers(0, 1 << 32, 200000, dtype=np.uint64).astype(np.uint32), np.repeat(hot, 9000)])
+        rng.shuffle(ranks)
+    elif case == "two_levels":
+        ranks = rng.integers(0, 1 << 32, 2500000, dtype=np.uint64).astype(np.uint32)
+        ranks[::7] = ranks[3::7][:len(ranks[::7])]
+    else:
+        ranks = (np.uint32(0xABCDE000) | rng.integers(0, 1 << 12, 30000).astype(np.uint32))
+    usable = rng.random(len(ranks)) < 0.97
+    recs = _records_of(ranks, usable)
+    n = len(recs)
+    d_recs = torch.from_numpy(recs.view(np.int32).reshape(-1, 8).copy()).to(dev)
+    uniq, cnt, first = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3))
+    dn = torch.zeros(2, dtype=torch.int32, device=dev)
+    ctx.set_stream(0)
+    ctx.distinct_dev(d_recs, n, uniq, cnt, first, dn)
+    torch.cuda.synchronize()
+    wu, wf, wc = np.unique(ranks[usable], return_index=True, return_counts=True)
+    nu = int(dn[0])
+    assert nu == len(wu)
+    assert (uniq[:nu].cpu().numpy().view(np.uint32) == wu).all()
+    assert (cnt[:nu].cpu().numpy() == wc).all()
+    assert (first[:nu].cpu().numpy() == np.nonzero(usable)[0][wf]).all()
+    assert int(dn[1]) == 0
+
+
 def test_distinct_dev_small_and_edge_cases(ctx, orc):
     import torch
     dev = torch.device("cuda", 0)

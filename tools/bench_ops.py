@@ -89,16 +89,23 @@ def main():
     ctx.distinct_dev(recs, n, uq, ct, fi, dn)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    for _ in range(20):
+        ctx.distinct_dev(recs, n, uq, ct, fi, dn)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    ctx.profile(True)
+    ctx.profile_reset()
     for _ in range(5):
         ctx.distinct_dev(recs, n, uq, ct, fi, dn)
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 5 * 1e3
+    kernels = {k: round(v[1] / max(1, v[0]), 4) for k, v in ctx.profile_read().items() if v[0]}
+    ctx.profile(False)
     h = recs.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
     ok = (h["valid"] == 1) & ((h["flags"] & 2) != 0)
     wu, wc = np.unique(h["bc_rank"][ok], return_counts=True)
     nu = int(dn[0])
     same = nu == len(wu) and bool((uq[:nu].cpu().numpy().view(np.uint32) == wu).all()) and bool((ct[:nu].cpu().numpy() == wc).all())
-    print(json.dumps({"op": "distinct_dev", "records": n, "distinct": nu, "ms": round(ms, 3), "records_per_s": n / ms * 1e3, "checks_ok": same}))
+    print(json.dumps({"op": "distinct_dev", "records": n, "distinct": nu, "ms": round(ms, 3), "records_per_s": n / ms * 1e3, "kernels_ms": kernels, "checks_ok": same}))
 
 
 if __name__ == "__main__":

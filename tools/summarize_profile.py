@@ -19,11 +19,22 @@ more = sys.argv[3:]              # further pass directories (--config 3 / 5 runs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def kname(full):
+# kernels -> the names the library times them under (ScopedKernelTimer; bench.py's kernels_ms tables use those).  Several
+# kernels under one timer are one entry here: their per-launch figures add up (each runs once per pass).
+TIMERS = (("k_d2_pairs_w<1", "k_d1_pairs"), ("k_d2_pairs<1", "k_d1_pairs"), ("k_d2_pairs_w<2", "k_d2_pairs"), ("k_d2_pairs<2", "k_d2_pairs"),
+          ("k_d2_rows<false", "k_d2_count"), ("k_d2_rows<true", "k_d2_emit"), ("k_d1_rows<false", "k_d1_count"), ("k_d1_rows<true", "k_d1_emit"),
+          ("k_part_colscan", "k_%s_scan"), ("k_part_bases", "k_%s_scan"), ("k_part_split<unsigned int>", "k_%s_split"),
+          ("k_distinct_rows", "k_distinct_rows"), ("k_part_split<unsigned long", "k_distinct_rows"),
+          ("k_distinct_offsets", "k_distinct_finish"), ("k_distinct_compact", "k_distinct_finish"))
+SUB = {"": "d2"}                               # which join the shared partition kernels of a pass directory belong to
+
+
+def kname(full, sub=""):
     i = full.find("k_")
-    name = full[i:full.find("(", i)]
-    if name.startswith("k_d2_pairs<1"):       # the pair walk of the one-deletion join: bench.py times it as k_d1_pairs
-        return "k_d1_pairs"
+    name = full[i:full.find("(", i)] if "(" in full[i:] else full[i:]
+    for prefix, timer in TIMERS:
+        if name.startswith(prefix):
+            return timer % ("d1" if sub == "_c3" else "d2") if "%s" in timer else timer
     return name.split("<", 1)[0]              # (template arguments of a kernel are not part of its name here)
 
 
@@ -32,15 +43,17 @@ summary = collections.defaultdict(dict)
 
 def take_dir(one, sub):
     """one pmc_profile.sh output directory; a kernel that an earlier directory named keeps that directory's figures"""
+    known = {k for k in summary if "calls" in summary[k]}
     for f in glob.glob(os.path.join(one, "stats", "*", "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
-            k = kname(r["Name"])
-            if "calls" in summary[k]:
+            k = kname(r["Name"], sub)
+            if k in known:
                 continue
-            summary[k]["calls"] = int(r["Calls"])
-            summary[k]["avg_ns"] = float(r["AverageNs"])
-            summary[k]["min_ns"] = float(r["MinNs"])
-            summary[k]["max_ns"] = float(r["MaxNs"])
+            s = summary[k]
+            s["calls"] = max(s.get("calls", 0), int(r["Calls"]))
+            s["avg_ns"] = s.get("avg_ns", 0.0) + float(r["AverageNs"])     # (kernels under one timer: one after the other)
+            s["min_ns"] = s.get("min_ns", 0.0) + float(r["MinNs"])
+            s["max_ns"] = s.get("max_ns", 0.0) + float(r["MaxNs"])
     for d in sorted(glob.glob(os.path.join(one, "pmc*"))):
         if not os.path.isdir(d):
             continue
@@ -48,18 +61,23 @@ def take_dir(one, sub):
         if len(files) != 1:          # (one process per pass; more means leftovers of an earlier run in the same directory)
             sys.exit("%s holds %d counter files, expected 1" % (d, len(files)))
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        raw = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in files:
             for r in csv.DictReader(open(f)):
-                agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                raw[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # per timer name: the sum over its kernels of each kernel's mean per launch (kept as a one-element list per kernel)
+        for full, cs in raw.items():
+            for c, v in cs.items():
+                agg[kname(full, sub)][c].append((len(v), sum(v) / len(v)))
         # the pass as committed: per kernel and counter, launches and mean per launch
         with open(os.path.join(ROOT, "profiles", "%s%s_%s.csv" % (tag, sub, os.path.basename(d))), "w") as out:
             out.write("kernel,counter,launches,mean_per_launch\n")
             for k in sorted(agg):
                 for c in sorted(agg[k]):
-                    out.write("%s,%s,%d,%.1f\n" % (k, c, len(agg[k][c]), sum(agg[k][c]) / len(agg[k][c])))
+                    out.write("%s,%s,%d,%.1f\n" % (k, c, max(n for n, _ in agg[k][c]), sum(m for _, m in agg[k][c])))
         for k, cs in agg.items():
             for c, v in cs.items():
-                summary[k].setdefault(c, sum(v) / len(v))
+                summary[k].setdefault(c, sum(m for _, m in v))
 
 
 take_dir(src, "")
