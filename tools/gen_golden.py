@@ -3,7 +3,18 @@
 
 Runs ONLY in the build container (needs /root/reference).  Nothing from the
 reference is copied: this script imports its modules in place, feeds them
-seeded synthetic inputs and stores inputs + outputs as data fixtures.
+inputs and stores inputs + outputs as data fixtures.
+
+    python3 tools/gen_golden.py                 the INPUTS are what the committed fixtures hold (the sequences of
+                                                primitives.json / extract_rows.json, c1_reads.fa.gz, c1_whitelist.*, the
+                                                barcode lists of graph.json); every output is recomputed by the reference and
+                                                written back.  On an unchanged reference `git diff --exit-code tests/golden`
+                                                stays clean: the recipe reproduces the fixtures (tools/check_golden.py asserts
+                                                exactly that without writing).
+    python3 tools/gen_golden.py --redraw-inputs draws NEW inputs from badger_amd/synth.py and numpy generators first (what made
+                                                the fixtures originally; synth.py has changed since, so this REPLACES the
+                                                config-1 reads and every expectation - commit the whole directory together).
+    python3 tools/gen_golden.py --out DIR       writes to DIR instead of tests/golden (inputs still read from tests/golden).
 
 The reference imports two third-party native packages that are absent from the
 image (and from /root/reference): `ssw` (ssw-py) and `editdistance`.  They are
@@ -167,14 +178,15 @@ def edge_case_reads(rng):
     return reads
 
 
-def gen_no_polya():
+def gen_no_polya(out_dir=None):
     """The reference's second strand rule (TenXBarcodeExtractor.find_barcode_umi_no_polya, barcode_callers.py:231-248:
     forward result if valid, else reverse if valid, else the more informative one) on the reads of extract_rows.json.
     Reads whose reverse complement cannot be formed raise KeyError there only when the forward result is invalid; the
     fixture records the row or the exception's class name."""
     install_shims()
+    out_dir = out_dir or OUT
     from barcode_extraction import barcode_callers
-    ext = json.load(open(os.path.join(OUT, "extract_rows.json")))
+    ext = json.load(open(os.path.join(out_dir, "extract_rows.json")))
     d3, d2 = barcode_callers.TenXBarcodeExtractorV3(), barcode_callers.TenXBarcodeExtractorV2()
     rows = []
     for r in ext["reads"]:
@@ -187,49 +199,26 @@ def gen_no_polya():
             except KeyError:
                 row["row_" + tag] = "KeyError"
         rows.append(row)
-    json.dump({"of": "extract_rows.json", "reads": rows}, open(os.path.join(OUT, "extract_rows_no_polya.json"), "w"))
+    json.dump({"of": "extract_rows.json", "reads": rows}, open(os.path.join(out_dir, "extract_rows_no_polya.json"), "w"))
     print("extract_rows_no_polya.json:", len(rows), "reads,",
           sum(1 for a, b in zip(rows, ext["reads"]) if a["row_v3"] != b["row_v3"]), "rows differ from find_barcode_umi")
 
 
-def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "--no-polya-only":
-        return gen_no_polya()
-    install_shims()
-    os.makedirs(OUT, exist_ok=True)
+def draw_inputs():
+    """NEW inputs from the generators (--redraw-inputs): what the fixtures were first made from.  badger_amd/synth.py draws
+    differently since its counter-based rewrite, so the result differs from the committed fixtures."""
     from badger_amd import synth
-
-    from barcode_extraction import barcode_callers, common as bx_common, kmer_indexer
-    import common as ref_common
-    import index as ref_index
-    import barcode_graph as ref_graph
-    import extract_raw_barcodes as ref_extract
-
     rng = np.random.default_rng(12345)
-
-    # ---- 1. primitives (KATs) --------------------------------------
-    prim = {"find_polyt_start": [], "find_polyt_start_w5": [], "reverese_complement": [],
-            "get_occurrences": [], "align_pattern_ssw": [], "detect_exact_positions": [],
-            "rank": [], "qgram_threshold": [], "editdistance": []}
+    R1 = "CTACACGACGCTCTTCCGATCT"
+    inp = {}
     seqs = [s for _, s in edge_case_reads(rng)]
     for _ in range(60):
         n = int(rng.integers(0, 120))
         p = rng.random()
         alpha = "ACGT" if p < 0.5 else "TTTA" if p < 0.8 else "TTTTTTC"
         seqs.append("".join(alpha[i] for i in rng.integers(0, len(alpha), n)))
-    idx = kmer_indexer.KmerIndexer([barcode_callers.TenXBarcodeExtractor.R1], kmer_size=6)
-    R1 = barcode_callers.TenXBarcodeExtractor.R1
-    for s in seqs:
-        prim["find_polyt_start"].append([s, bx_common.find_polyt_start(s)])
-        prim["find_polyt_start_w5"].append([s[:14], bx_common.find_polyt_start(s[:14], window_size=5, polya_fraction=1.0)])
-        if "N" not in s or True:
-            prim["reverese_complement"].append([s, bx_common.reverese_complement(s)])
-        occ = idx.get_occurrences(s)
-        prim["get_occurrences"].append([s, occ[R1][2] if occ else []])
-        if occ:
-            for (ms, sd, ed_) in ((9, -1, 4), (17, 1, 1), (0, -1, -1)):
-                r = bx_common.detect_exact_positions(s, 0, len(s), 6, R1, occ, min_score=ms, start_delta=sd, end_delta=ed_)
-                prim["detect_exact_positions"].append([s, 0, len(s), occ[R1][2], ms, sd, ed_, list(r)])
+    inp["prim_seqs"] = seqs
+    windows = []
     for _ in range(300):
         n = int(rng.integers(6, 40))
         w = "".join("ACGT"[i] for i in rng.integers(0, 4, n))
@@ -244,58 +233,27 @@ def main():
             piece = "".join(piece)
             at = int(rng.integers(0, max(1, n - len(piece))))
             w = (w[:at] + piece + w[at + len(piece):])[:39]
-        prim["align_pattern_ssw"].append([w, list(bx_common.align_pattern_ssw(w, 0, len(w), R1, 0))])
-    for _ in range(50):
-        s = "".join("ACGT"[i] for i in rng.integers(0, 4, 16))
-        rk = ref_common.rank(s, 16)
-        assert ref_common.unrank(rk, 16) == s
-        prim["rank"].append([s, rk])
-    for t in (0, 1, 2, 3):
-        import contextlib
-        with contextlib.redirect_stdout(io.StringIO()):
-            prim["qgram_threshold"].append([t, ref_index.QGramIndex(t, 16, 6).threshold])
+        windows.append(w)
+    inp["prim_windows"] = windows
+    inp["prim_rank"] = ["".join("ACGT"[i] for i in rng.integers(0, 4, 16)) for _ in range(50)]
+    pairs = []
     for _ in range(200):
         la, lb = int(rng.integers(0, 17)), int(rng.integers(0, 17))
         a = "".join("ACGT"[i] for i in rng.integers(0, 4, la))
         b = list(a[:lb]) if rng.random() < 0.6 else ["ACGT"[i] for i in rng.integers(0, 4, lb)]
         for k in range(len(b)):
             if rng.random() < 0.15: b[k] = "ACGT"[int(rng.integers(0, 4))]
-        b = "".join(b)
-        prim["editdistance"].append([a, b, lev(a, b)])
-    json.dump(prim, open(os.path.join(OUT, "primitives.json"), "w"))
-
-    # ---- 2. per-read extraction rows (both protocol versions) ------
+        pairs.append([a, "".join(b)])
+    inp["prim_pairs"] = pairs
     wl = synth.make_whitelist(1000)
     bases, off = synth.make_reads(300, wl, seed=7)
     reads = edge_case_reads(rng) + [("syn_%d" % i, s) for i, s in enumerate(synth.reads_to_list(bases, off))]
     bases0, off0 = synth.make_reads(40, wl, seed=8, p_sub=0.0, p_ins=0.0, p_del=0.0)
     reads += [("clean_%d" % i, s) for i, s in enumerate(synth.reads_to_list(bases0, off0))]
-    ext = {"header": barcode_callers.TenXBarcodeDetectionResult.header(), "reads": []}
-    d3, d2 = barcode_callers.TenXBarcodeExtractorV3(), barcode_callers.TenXBarcodeExtractorV2()
-    for rid, s in reads:
-        r3, r2 = d3.find_barcode_umi(rid, s), d2.find_barcode_umi(rid, s)
-        ext["reads"].append({"id": rid, "seq": s, "row_v3": str(r3), "row_v2": str(r2),
-                             "r1_score_v3": r3.r1_score, "r1_score_v2": r2.r1_score})
-    json.dump(ext, open(os.path.join(OUT, "extract_rows.json"), "w"))
-
-    # ---- 3. config 1: 1K reads through BarcodeCaller.process_chunk --
+    inp["reads"] = reads
     bases, off = synth.make_reads(1000, wl, seed=1)
-    c1 = synth.reads_to_list(bases, off)
-    with gzip.open(os.path.join(OUT, "c1_reads.fa.gz"), "wt", compresslevel=9) as f:
-        for i, s in enumerate(c1):
-            f.write(">read_%d\n%s\n" % (i, s))
-    np.save(os.path.join(OUT, "c1_whitelist.npy"), wl)
-    tsv = os.path.join(OUT, "c1_expected.tsv")
-    handler = ref_extract.FileReadHandler(tsv)
-    caller = ref_extract.BarcodeCaller(barcode_callers.TenXBarcodeExtractorV3(), handler)
-    caller.process_chunk([("read_%d" % i, s) for i, s in enumerate(c1)])
-    handler.dump_stats(caller.read_stat)            # -> c1_expected.tsv.stats
-    handler.output_file.close()
-
-    # ---- 4. graph: counts / edges / dists / q-gram candidates ------
-    graph = {}
-    rows = [l.rstrip("\n").split("\t") for l in open(tsv) if not l.startswith("#")]
-    c1_barcodes = [r[1] for r in rows if r[1] != "*"]
+    inp["c1"] = synth.reads_to_list(bases, off)
+    inp["wl"] = wl
     cells = [synth.rank_to_str(x) for x in wl[:60]]
     obs = []
     g7 = np.random.default_rng(7)
@@ -312,9 +270,116 @@ def main():
         if len(s) >= 16:
             s = s[:16] if g7.random() < 0.8 else s[:17]      # 17-char inputs are trimmed (barcode_graph.py:196-197)
         obs.append(s)
-    for name, bcs in (("c1", c1_barcodes), ("cells60", obs)):
+    inp["cells60"] = obs
+    return inp
+
+
+def stored_inputs(src):
+    """The inputs the committed fixtures hold (the default): nothing is drawn, so the outputs written are the reference's
+    answers to exactly the stored questions."""
+    inp = {}
+    prim = json.load(open(os.path.join(src, "primitives.json")))
+    inp["prim_seqs"] = [x[0] for x in prim["find_polyt_start"]]
+    assert inp["prim_seqs"] == [x[0] for x in prim["reverese_complement"]] == [x[0] for x in prim["get_occurrences"]]
+    inp["prim_windows"] = [x[0] for x in prim["align_pattern_ssw"]]
+    inp["prim_rank"] = [x[0] for x in prim["rank"]]
+    inp["prim_pairs"] = [[x[0], x[1]] for x in prim["editdistance"]]
+    ext = json.load(open(os.path.join(src, "extract_rows.json")))
+    inp["reads"] = [(r["id"], r["seq"]) for r in ext["reads"]]
+    c1, cur = [], None
+    with gzip.open(os.path.join(src, "c1_reads.fa.gz"), "rt") as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if line.startswith(">"):
+                assert line == ">read_%d" % len(c1), line
+            else:
+                c1.append(line)
+    inp["c1"] = c1
+    inp["wl"] = np.load(os.path.join(src, "c1_whitelist.npy"))
+    graph = json.load(open(os.path.join(src, "graph.json")))
+    assert graph["cells60_thr1"]["barcodes"] == graph["cells60_thr2"]["barcodes"]
+    inp["cells60"] = graph["cells60_thr1"]["barcodes"]
+    return inp
+
+
+def main():
+    argv = sys.argv[1:]
+    if argv[:1] == ["--no-polya-only"]:
+        return gen_no_polya()
+    redraw = "--redraw-inputs" in argv
+    out = argv[argv.index("--out") + 1] if "--out" in argv else OUT
+    install_shims()
+    os.makedirs(out, exist_ok=True)
+    from badger_amd import synth
+
+    from barcode_extraction import barcode_callers, common as bx_common, kmer_indexer
+    import common as ref_common
+    import index as ref_index
+    import barcode_graph as ref_graph
+    import extract_raw_barcodes as ref_extract
+
+    inp = draw_inputs() if redraw else stored_inputs(OUT)
+
+    # ---- 1. primitives (KATs) --------------------------------------
+    prim = {"find_polyt_start": [], "find_polyt_start_w5": [], "reverese_complement": [],
+            "get_occurrences": [], "align_pattern_ssw": [], "detect_exact_positions": [],
+            "rank": [], "qgram_threshold": [], "editdistance": []}
+    idx = kmer_indexer.KmerIndexer([barcode_callers.TenXBarcodeExtractor.R1], kmer_size=6)
+    R1 = barcode_callers.TenXBarcodeExtractor.R1
+    for s in inp["prim_seqs"]:
+        prim["find_polyt_start"].append([s, bx_common.find_polyt_start(s)])
+        prim["find_polyt_start_w5"].append([s[:14], bx_common.find_polyt_start(s[:14], window_size=5, polya_fraction=1.0)])
+        prim["reverese_complement"].append([s, bx_common.reverese_complement(s)])
+        occ = idx.get_occurrences(s)
+        prim["get_occurrences"].append([s, occ[R1][2] if occ else []])
+        if occ:
+            for (ms, sd, ed_) in ((9, -1, 4), (17, 1, 1), (0, -1, -1)):
+                r = bx_common.detect_exact_positions(s, 0, len(s), 6, R1, occ, min_score=ms, start_delta=sd, end_delta=ed_)
+                prim["detect_exact_positions"].append([s, 0, len(s), occ[R1][2], ms, sd, ed_, list(r)])
+    for w in inp["prim_windows"]:
+        prim["align_pattern_ssw"].append([w, list(bx_common.align_pattern_ssw(w, 0, len(w), R1, 0))])
+    for s in inp["prim_rank"]:
+        rk = ref_common.rank(s, 16)
+        assert ref_common.unrank(rk, 16) == s
+        prim["rank"].append([s, rk])
+    import contextlib
+    for t in (0, 1, 2, 3):
+        with contextlib.redirect_stdout(io.StringIO()):
+            prim["qgram_threshold"].append([t, ref_index.QGramIndex(t, 16, 6).threshold])
+    for a, b in inp["prim_pairs"]:
+        prim["editdistance"].append([a, b, lev(a, b)])
+    json.dump(prim, open(os.path.join(out, "primitives.json"), "w"))
+
+    # ---- 2. per-read extraction rows (both protocol versions) ------
+    wl = inp["wl"]
+    ext = {"header": barcode_callers.TenXBarcodeDetectionResult.header(), "reads": []}
+    d3, d2 = barcode_callers.TenXBarcodeExtractorV3(), barcode_callers.TenXBarcodeExtractorV2()
+    for rid, s in inp["reads"]:
+        r3, r2 = d3.find_barcode_umi(rid, s), d2.find_barcode_umi(rid, s)
+        ext["reads"].append({"id": rid, "seq": s, "row_v3": str(r3), "row_v2": str(r2),
+                             "r1_score_v3": r3.r1_score, "r1_score_v2": r2.r1_score})
+    json.dump(ext, open(os.path.join(out, "extract_rows.json"), "w"))
+
+    # ---- 3. config 1: 1K reads through BarcodeCaller.process_chunk --
+    c1 = inp["c1"]
+    if redraw:                                       # (inputs: written only when they were drawn anew; mtime 0 keeps the bytes stable)
+        with open(os.path.join(out, "c1_reads.fa.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", compresslevel=9, mtime=0) as f:
+            for i, s in enumerate(c1):
+                f.write((">read_%d\n%s\n" % (i, s)).encode())
+        np.save(os.path.join(out, "c1_whitelist.npy"), wl)
+    tsv = os.path.join(out, "c1_expected.tsv")
+    handler = ref_extract.FileReadHandler(tsv)
+    caller = ref_extract.BarcodeCaller(barcode_callers.TenXBarcodeExtractorV3(), handler)
+    caller.process_chunk([("read_%d" % i, s) for i, s in enumerate(c1)])
+    handler.dump_stats(caller.read_stat)            # -> c1_expected.tsv.stats
+    handler.output_file.close()
+
+    # ---- 4. graph: counts / edges / dists / q-gram candidates ------
+    graph = {}
+    rows = [l.rstrip("\n").split("\t") for l in open(tsv) if not l.startswith("#")]
+    c1_barcodes = [r[1] for r in rows if r[1] != "*"]
+    for name, bcs in (("c1", c1_barcodes), ("cells60", inp["cells60"])):
         for thr in (1, 2):
-            import contextlib
             with contextlib.redirect_stdout(io.StringIO()):
                 g = ref_graph.BarcodeGraph(thr)
                 g.graph_construction(bcs, 16, 1)
@@ -330,26 +395,26 @@ def main():
                 for rk in ranks:
                     cl.append([int(rk), sorted(int(x) for x in g.index.get_close(ref_common.unrank(rk, 16), rk))])
                 graph["cells60_get_close_thr1"] = cl
-    json.dump(graph, open(os.path.join(OUT, "graph.json"), "w"))
+    json.dump(graph, open(os.path.join(out, "graph.json"), "w"))
 
     # ---- 5. stage 2 end to end: badger.py main on the c1 TSV -------
-    import contextlib
     import badger as ref_badger
-    wl_file = os.path.join(OUT, "c1_whitelist.txt")
+    wl_file = os.path.join(out, "c1_whitelist.txt")
     # whitelist for stage 2: the cells that actually occur, so cluster centers exist
-    with open(wl_file, "w") as f:
-        f.write("\n".join(synth.rank_to_str(x) for x in wl))
+    if redraw or not os.path.exists(wl_file):
+        with open(wl_file, "w") as f:
+            f.write("\n".join(synth.rank_to_str(x) for x in wl))
     for hs in (False, True):
-        prefix = os.path.join(OUT, "c1_stage2%s" % ("_hs" if hs else ""))
-        argv = ["-r", tsv, "-d", "tenX_v3", "-l", wl_file, "-c", "50", "-o", prefix]
+        prefix = os.path.join(out, "c1_stage2%s" % ("_hs" if hs else ""))
+        argv2 = ["-r", tsv, "-d", "tenX_v3", "-l", wl_file, "-c", "50", "-o", prefix]
         if hs:
-            argv.append("-hs")
+            argv2.append("-hs")
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
-            ref_badger.main(argv)
+            ref_badger.main(argv2)
         open(prefix + "_stdout_tail.txt", "w").write(buf.getvalue().strip().split("\n")[-1] + "\n")
-    gen_no_polya()
-    print("golden fixtures written to", OUT)
+    gen_no_polya(out)
+    print("golden fixtures written to", out, "(inputs drawn anew)" if redraw else "(inputs: the committed ones)")
 
 
 if __name__ == "__main__":
