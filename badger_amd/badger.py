@@ -44,7 +44,22 @@ def parse_args(args):
     p.add_argument("--high_sens", "-hs", action="store_true", default=False,
                    help="if set, Badger is run in high sensitivity mode. This increases recall but decreases precision")
     p.add_argument("--device", type=int, default=0, help="MI355X device index")
+    p.add_argument("--gpus", type=int, default=0,
+                   help="devices the edge build is shared over (one share of the edge list each, no exchange between them); "
+                        "default: as many as --threads asks for and the node has (the reference's -tr N fans compare_chunk "
+                        "out over N processes, barcode_graph.py:164-189), at least 1")
     return p.parse_args(args)
+
+
+def edge_build_gpus(args):
+    """--gpus N, or -tr N mapped onto the devices that exist"""
+    if args.gpus > 0:
+        return args.gpus
+    if args.threads > 1:
+        if os.environ.get("BADGER_AMD_CONTEXTS_ON_ONE_DEVICE") == "1":
+            return args.threads
+        return max(1, min(args.threads, _native.device_count()))
+    return 1
 
 
 def set_logger(logger_instance):
@@ -134,7 +149,7 @@ def main(args):
         mark("import")
         st2.count_device(ctx)
         mark("count")
-        st2.build_edges(ctx, on_device=True)
+        st2.build_edges(ctx, on_device=True, gpus=edge_build_gpus(args))
         from_device = ctx
     elif is_native_input(args.reads):
         # FASTA / FASTQ / SAM / BAM: the records of every chunk stay on the device (stage 1 -> stage 2 hand-off without host
@@ -146,7 +161,9 @@ def main(args):
         read_ids = _native.IdStore()
         umi_len = BARCODE_CALLING_MODES[args.data_type](device=args.device).UMI_LEN_10X
         try:
-            _native.stage1_collect(ctx, args.reads, umi_len, read_ids, threads=args.threads if args.threads > 1 else 0,
+            # (-tr 1 is one sequential reader, compressed input as one gzip stream - the reference's single-thread shape,
+            # as extract_raw_barcodes.process_single_thread asks for it)
+            _native.stage1_collect(ctx, args.reads, umi_len, read_ids, threads=args.threads,
                                    skip_secondary=args.threads != 1)
         except BaseException:
             ctx.extract_keep_records(False)
@@ -156,7 +173,7 @@ def main(args):
         logger.info("Initializing Graph")
         st2.count_device(ctx)
         mark("count")
-        st2.build_edges(ctx, on_device=True)
+        st2.build_edges(ctx, on_device=True, gpus=edge_build_gpus(args))
         from_device = ctx
     else:
         logger.error("Unknown file format " + args.reads)

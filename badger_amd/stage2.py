@@ -60,6 +60,21 @@ def observed_from_strings(barcodes_per_read, bc_len=16):
     return ranks, usable
 
 
+def graph_contexts(gpus, first):
+    """the contexts a --gpus N edge build runs on: `first` (where the distinct barcodes already are) and one per further
+    device; BADGER_AMD_CONTEXTS_ON_ONE_DEVICE=1 rehearses N on a one-GPU box with N independent contexts of device 0"""
+    import os
+    if gpus <= 1:
+        return [first]
+    if os.environ.get("BADGER_AMD_CONTEXTS_ON_ONE_DEVICE") == "1":
+        return [first] + [_native.default_context(0, instance=100 + g) for g in range(1, gpus)]
+    have = _native.device_count()
+    if gpus > have:
+        raise SystemExit("--gpus %d: this node shows %d device(s)" % (gpus, have))
+    others = [d for d in range(have) if d != first.device][:gpus - 1]
+    return [first] + [_native.default_context(d) for d in others]
+
+
 class Stage2:
     def __init__(self, threshold, device=0):
         self.threshold = threshold
@@ -150,10 +165,14 @@ class Stage2:
         return nu
 
     # ------------------------------------------------------------------ graph
-    def build_edges(self, ctx=None, on_device=False):
+    def build_edges(self, ctx=None, on_device=False, gpus=1):
         """edges as pairs of positions in uniq.  The distinct barcodes are on the device already after count_device();
         after count_host() they are sent there.  Either way the edge list is built there (bdg_graph_edges_dev), its ranks
-        are turned into positions there (bdg_rows_of_dev) and only the positions come back."""
+        are turned into positions there (bdg_rows_of_dev) and only the positions come back.
+        gpus > 1: the reference's `-tr N` fan-out of compare_chunk (barcode_graph.py:164-189) over devices - every context
+        holds the distinct barcodes and builds part g of N of the edge list (bdg_graph_edges_part_dev: disjoint shares whose
+        union is the list, cut by the library), the shares' positions are put side by side on the first device, where the
+        clustering runs.  No exchange between the devices."""
         nu = len(self.uniq)
         T = qgram_threshold(self.threshold, 16)
         if nu < 2:
@@ -161,6 +180,8 @@ class Stage2:
             return
         ctx = ctx or self._ctx()
         d_uniq = self._d_uniq if on_device else _native.DeviceArray.from_host(ctx, self.uniq)
+        if gpus > 1:
+            return self._build_edges_parts(ctx, d_uniq, nu, T, gpus)
         cap = max(1024, 8 * nu)
         while True:
             d_edges = _native.DeviceArray(ctx, (cap, 3), np.uint32)
@@ -181,6 +202,45 @@ class Stage2:
         # per-read assignment run there (50 M edges are 400 MB that the host would only hold)
         self._ea = self._eb = None
         self._dev = {"ctx": ctx, "rows": d_rows, "m": tot, "uniq": d_uniq}
+
+    def _build_edges_parts(self, ctx, d_uniq, nu, T, gpus):
+        ctxs = [ctx] + [c for c in graph_contexts(gpus, ctx) if c is not ctx][:gpus - 1]
+        n = len(ctxs)
+        cap = max(1024, 8 * nu // n + 4096)
+        work = []
+        for g, c in enumerate(ctxs):                         # every device starts on its share before anybody waits
+            du = d_uniq if c is ctx else _native.DeviceArray.from_host(c, self.uniq)
+            d_edges = _native.DeviceArray(c, (cap, 3), np.uint32)
+            d_tot = _native.DeviceArray(c, 1, np.uint64)
+            c.graph_edges_part_dev(du, nu, g, n, self.threshold, T, d_edges, cap, d_tot)
+            work.append([c, du, d_edges, d_tot, cap])
+        shares = []
+        for g, w in enumerate(work):
+            c, du, d_edges, d_tot, cp = w
+            tot = int(d_tot.to_host()[0])
+            c.graph_status()
+            while tot > cp:                                      # (a share larger than its room: once more with room)
+                d_edges.free()
+                cp = tot
+                d_edges = _native.DeviceArray(c, (cp, 3), np.uint32)
+                c.graph_edges_part_dev(du, nu, g, n, self.threshold, T, d_edges, cp, d_tot)
+                tot = int(d_tot.to_host()[0])
+                c.graph_status()
+            d_rows = _native.DeviceArray(c, (2, max(tot, 1)), np.uint32)
+            c.rows_of_dev(du, nu, d_edges, tot, 3, d_rows.data_ptr(), 0)
+            c.rows_of_dev(du, nu, d_edges, tot, 3, d_rows.data_ptr() + 4 * max(tot, 1), 1)
+            rows = d_rows.to_host()
+            shares.append((rows[0, :tot], rows[1, :tot]))
+            for d in (d_edges, d_tot, d_rows) + (() if c is ctx else (du,)):
+                d.free()
+        tot = sum(len(a) for a, _ in shares)
+        both = np.zeros((2, max(tot, 1)), np.uint32)
+        if tot:
+            both[0, :tot] = np.concatenate([a for a, _ in shares])
+            both[1, :tot] = np.concatenate([b for _, b in shares])
+        self._ea = self._eb = None
+        self._dev = {"ctx": ctx, "rows": _native.DeviceArray.from_host(ctx, both), "m": tot, "uniq": d_uniq}
+        self.edge_shares = [len(a) for a, _ in shares]          # (for logs and tests: how the list was cut)
 
     # ------------------------------------------------------------------ centres
     def get_cluster_centers(self, true_barcodes, bc_len, barcode_list, n_cells, interval):

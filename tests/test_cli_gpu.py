@@ -401,3 +401,49 @@ def test_stage1_gpus_flag_over_contexts_of_one_device(tmp_path, monkeypatch):
     assert outs[("1", "1")] == outs[("3", "1")] and outs[("1", "5")] == outs[("3", "5")]
     assert outs[("3", "1")][0] == "\n".join([header] + rows) + "\n"
     assert outs[("3", "5")][0] == "\n".join([header] + rows) + "\n"       # 40,000 reads: one chunk of the reference's 100,000, one header
+
+
+@pytest.mark.gpu
+def test_stage2_gpus_flag_shares_the_edge_build(tmp_path, golden_dir, monkeypatch):
+    """badger.py --gpus N (and -tr N mapped onto it): every context builds its share of the edge list
+    (bdg_graph_edges_part_dev, the reference's compare_in_parallel fan-out, barcode_graph.py:164-189), the shares are put
+    side by side before the clustering.  Rehearsed on one device with N independent contexts: the output file is that of
+    one context and the reference's own, at both thresholds, from the TSV and from the reads; the shares are all non-empty
+    on an input large enough to have edges in every part."""
+    from badger_amd import stage2
+    monkeypatch.setenv("BADGER_AMD_CONTEXTS_ON_ONE_DEVICE", "1")
+    want = open(os.path.join(golden_dir, "c1_stage2_output_file.tsv")).read()
+    for flags in (["--gpus", "3"], ["-tr", "2"]):
+        for reads in ("c1_expected.tsv", "c1_reads.fa.gz"):
+            prefix = str(tmp_path / ("mg_%s_%s" % (flags[1], reads[:5])))
+            buf = io.StringIO()
+            with redirect_stdout(buf):
+                badger.main(["-r", os.path.join(golden_dir, reads), "-d", "tenX_v3", "-l", os.path.join(golden_dir, "c1_whitelist.txt"),
+                             "-c", "50", "-o", prefix] + flags)
+            assert open(prefix + "_output_file.tsv").read() == want, (flags, reads)
+            assert buf.getvalue().strip().split("\n")[-1] == open(os.path.join(golden_dir, "c1_stage2_stdout_tail.txt")).read().strip()
+    # a larger input, both thresholds: N = 1 against N = 4, and the cut itself
+    path, rows, recs = _fastq_of(tmp_path, 30000, 29)
+    from badger_amd import synth
+    wl = str(tmp_path / "wl.txt")
+    with open(wl, "w") as f:
+        f.write("\n".join(synth.rank_to_str(r) for r in synth.make_whitelist(2000)) + "\n")
+    for thr in ("1", "2"):
+        outs, shares = [], []
+        orig = stage2.Stage2._build_edges_parts
+
+        def spy(self, *a, _orig=orig, _shares=shares, **k):
+            r = _orig(self, *a, **k)
+            _shares.append(list(self.edge_shares))
+            return r
+        stage2.Stage2._build_edges_parts = spy
+        try:
+            for gpus in ("1", "4"):
+                prefix = str(tmp_path / ("mg%s_%s" % (thr, gpus)))
+                with redirect_stdout(io.StringIO()):
+                    badger.main(["-r", path, "-d", "tenX_v3", "-l", wl, "-c", "300", "-t", thr, "-o", prefix, "--gpus", gpus])
+                outs.append(open(prefix + "_output_file.tsv").read())
+        finally:
+            stage2.Stage2._build_edges_parts = orig
+        assert outs[0] == outs[1] and outs[0].count("\n") == 30001
+        assert len(shares) == 1 and len(shares[0]) == 4 and min(shares[0]) > 0, shares

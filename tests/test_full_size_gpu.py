@@ -125,6 +125,11 @@ def test_config2_nearest_properties_and_samples(world):
     wi, we, wt = orc.nearest16(qh[sel[:24]], wl, 2, threads=8)
     assert (wi == idx[sel[:24]]).all() and (we == ed[sel[:24]]).all() and (wt == ties[sel[:24]]).all()
     ctx.nearest16_set_algo(0)
+    # the oracle on 150,000 of the million calls (its neighbourhood-probe form, pinned to the exhaustive scan by
+    # test_nearest16_probe_form_equals_exhaustive_scan): index, distance and tie count of every one
+    big = np.random.default_rng(1).choice(N_READS, 150000, replace=False)
+    wi, we, wt = orc.nearest16(qh[big], wl, 2, threads=16, probe=True)
+    assert (wi == idx[big]).all() and (we == ed[big]).all() and (wt == ties[big]).all()
 
 
 def test_config3_graph_probe_equals_scan_and_oracle_rows(world):
@@ -262,6 +267,10 @@ def test_config5_visium_scale_whitelist_and_thr2_graph(world):
     ctx.nearest16_set_algo(0)
     wi, we, wt = orc.nearest16(q[sel[:12]], wl, 2, threads=8)
     assert (wi == idx[sel[:12]]).all() and (we == ed[sel[:12]]).all() and (wt == ties[sel[:12]]).all()
+    # ... and ALL 200,000 answers against the oracle's neighbourhood-probe form on the 4.9 M-entry list (postprocessing's
+    # argmin, barcode_graph.py:370-385; the form is pinned to the exhaustive one by test_nearest16_probe_form_equals_exhaustive_scan)
+    wi, we, wt = orc.nearest16(q, wl, 2, threads=16, probe=True)
+    assert (wi == idx).all() and (we == ed).all() and (wt == ties).all()
 
     # thr = 2 graph at SURVEY 8d's config-5 size: 500K observed barcodes.  The deletion-variant join (what thr 2 runs on)
     # must give the all-pairs sweep's edge list and the q-gram join's, its 8 shares (as 8 GPUs would take them) and the

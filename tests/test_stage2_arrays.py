@@ -327,3 +327,20 @@ def test_output_writer_in_ranges(tmp_path, monkeypatch):
         out = str(tmp_path / ("o%s.tsv" % threads))
         _native.write_assignments(ids, rank, has, out)
         assert open(out).read() == want, threads
+
+
+def test_edge_build_gpus_from_the_flags(monkeypatch):
+    """badger.py: --gpus N as given; otherwise -tr N (the reference's compare_in_parallel process count) mapped onto the
+    devices the node has, at least one"""
+    from badger_amd import badger, _native
+    monkeypatch.setattr(_native, "device_count", lambda: 8)
+    monkeypatch.delenv("BADGER_AMD_CONTEXTS_ON_ONE_DEVICE", raising=False)
+    base = ["-r", "x.tsv", "-d", "tenX_v3"]
+    assert badger.edge_build_gpus(badger.parse_args(base)) == 1
+    assert badger.edge_build_gpus(badger.parse_args(base + ["-tr", "4"])) == 4
+    assert badger.edge_build_gpus(badger.parse_args(base + ["-tr", "32"])) == 8
+    assert badger.edge_build_gpus(badger.parse_args(base + ["-tr", "32", "--gpus", "2"])) == 2
+    monkeypatch.setattr(_native, "device_count", lambda: 1)
+    assert badger.edge_build_gpus(badger.parse_args(base + ["-tr", "16"])) == 1
+    monkeypatch.setenv("BADGER_AMD_CONTEXTS_ON_ONE_DEVICE", "1")
+    assert badger.edge_build_gpus(badger.parse_args(base + ["-tr", "3"])) == 3
