@@ -606,10 +606,15 @@ def import_stage1_tsv(path, bc_len=16):
     if rc == E_BADBASE:
         raise KeyError("the barcode in line %d of %s holds a letter outside ACGT" % (bad.value, path))
     if rc == E_FORMAT:
-        raise ValueError("%s has no '#read_id' / 'barcode' column" % path)
+        raise ValueError("%s is empty or has no '#read_id' / 'barcode' column" % path)
     if rc != 0:
         raise BadgerHipError(rc, "cannot read %s" % path)
     k = int(n.value)
+    if k == 0 or not pr.value or not pu.value:                # (a header and no rows)
+        for q in (pr, pu):
+            if q.value:
+                L.bdg_host_free(q)
+        return ids, np.zeros(0, np.uint32), np.zeros(0, bool)
     rank = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_uint32)), shape=(max(k, 1),))[:k].copy()
     usable = np.ctypeslib.as_array(C.cast(pu, C.POINTER(C.c_uint8)), shape=(max(k, 1),))[:k].astype(bool)
     L.bdg_host_free(pr)

@@ -72,22 +72,35 @@ def set_logger(logger_instance):
     logger_instance.info("Starting")
 
 
+_PANDAS_NA = ("", "NA", "NaN", "nan", "N/A", "NULL", "null", "None")
+
+
 def import_tsv(path, bc_len):
-    """Stage-1 TSV -> (read_assignment, barcodes) the way reference badger.py:91-111 reads it:
-    repeated header rows are skipped, an empty barcode field counts as '*', 17-character
-    barcodes lose their last base in read_assignment (graph_construction trims its own copy)."""
+    """Stage-1 TSV -> (read_assignment, barcodes) the way reference badger.py:91-111 reads it with pandas.read_csv:
+    repeated header rows are skipped, a missing or empty barcode field counts as '*' (a row that ends before the barcode
+    column stays a read), blank lines are skipped, a field in double quotes loses them, an id pandas takes for a missing
+    value becomes the empty string its to_csv writes; 17-character barcodes lose their last base in read_assignment
+    (graph_construction trims its own copy).  The command line uses the native form (bdg_import_stage1_tsv); this is its
+    checker and the host-side API."""
     read_assignment, barcodes = [], []
     with open(path) as f:
-        header = f.readline().rstrip("\n").split("\t")
+        first = f.readline()
+        if not first:
+            raise ValueError("%s is empty" % path)
+        header = first.rstrip("\n").rstrip("\r").split("\t")
         ci, cb = header.index("#read_id"), header.index("barcode")
         for line in f:
-            fields = line.rstrip("\n").split("\t")
-            if len(fields) <= max(ci, cb):
+            line = line.rstrip("\n").rstrip("\r")
+            if not line:
                 continue
-            rid, bc = fields[ci], fields[cb]
+            fields = [x[1:-1] if len(x) >= 2 and x[0] == x[-1] == '"' else x for x in line.split("\t")]
+            rid = fields[ci] if ci < len(fields) else ""
+            bc = fields[cb] if cb < len(fields) else "*"
+            if rid in _PANDAS_NA:
+                rid = ""
             if rid == "#read_id" or bc == "barcode":
                 continue
-            if bc in ("", "NA", "NaN", "nan", "N/A", "NULL", "null", "None"):   # pandas reads these as missing
+            if bc in _PANDAS_NA:                          # pandas reads these as missing
                 bc = "*"
             if bc != "*":
                 barcodes.append(bc)

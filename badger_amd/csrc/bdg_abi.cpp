@@ -6,6 +6,7 @@
 #include <cstddef>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <mutex>
@@ -419,8 +420,11 @@ static int slot_enqueue(bdg_ctx* ctx, bdg_ctx::Slot& sl)
     return BDG_OK;
 }
 
-// where bdg_extract_submit's time goes (BADGER_AMD_INGEST_DEBUG; printed by bdg_stage1_run)
-double g_submit_t[6] = { 0, 0, 0, 0, 0, 0 };
+// where bdg_extract_submit's time goes (BADGER_AMD_INGEST_DEBUG; printed by bdg_stage1_run).  Summed only when that variable is
+// set, and atomically: the ABI lets different host threads drive different contexts, and they all pass here.
+std::atomic<double> g_submit_t[6];
+static const bool g_submit_debug = getenv("BADGER_AMD_INGEST_DEBUG") != nullptr;
+static inline void submit_add(int i, double v) { double o = g_submit_t[i].load(std::memory_order_relaxed); while (!g_submit_t[i].compare_exchange_weak(o, o + v, std::memory_order_relaxed)) {} }
 static inline double submit_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int bdg_extract_submit(bdg_ctx* ctx, uint32_t slot, const uint8_t* bases, const uint64_t* off, uint32_t n, uint32_t umi_len)
@@ -465,7 +469,7 @@ int bdg_extract_submit(bdg_ctx* ctx, uint32_t slot, const uint8_t* bases, const 
     if ((rc = slot_enqueue(ctx, sl))) return rc;
     sl.busy = true;
     const double T4 = submit_now();
-    g_submit_t[0] += T1 - T0; g_submit_t[1] += T2 - T1; g_submit_t[2] += T3 - T2; g_submit_t[3] += T4 - T3; g_submit_t[4] += 1;
+    if (g_submit_debug) { submit_add(0, T1 - T0); submit_add(1, T2 - T1); submit_add(2, T3 - T2); submit_add(3, T4 - T3); submit_add(4, 1.0); }
     return BDG_OK;
 }
 

@@ -25,7 +25,7 @@ constexpr uint32_t WIN = 32768;
 constexpr uint16_t MARK = 256;              // symbol >= MARK: the byte at place (symbol - MARK) of the 32 KiB before the chunk
 constexpr int FAST = 10;                    // codes of up to FAST bits are decoded by one table look-up
 
-enum { PG_OK = 0, PG_FINAL = 1, PG_DATA = -1, PG_EOF = -2, PG_NOTTEXT = -3, PG_NOMEM = -4 };
+enum { PG_OK = 0, PG_FINAL = 1, PG_LIMIT = 2, PG_DATA = -1, PG_EOF = -2, PG_NOTTEXT = -3, PG_NOMEM = -4 };
 
 // ---- bits, least significant first ---------------------------------------------------------------------------------------
 struct Bits {
@@ -380,6 +380,9 @@ size_t gzip_header(const uint8_t* p, size_t n)
     return at > n ? (size_t)-1 : at;
 }
 
+// symbols a speculative chunk may hold: 64 MB of 16-bit symbols (BADGER_AMD_GUNZIP_MAX_CHUNK_KSYM: thousands, for tests)
+static const size_t MAX_CHUNK_SYMBOLS = [] { const char* e = getenv("BADGER_AMD_GUNZIP_MAX_CHUNK_KSYM"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v << 10 : size_t(32) << 20; }();
+
 struct Chunk {
     size_t lo_bit = 0, hi_bit = 0;           // where its search starts / where it stops taking new blocks
     bool exact = false;                      // lo_bit is the start of the stream: no search, no unknown window
@@ -537,6 +540,11 @@ struct PGunzipImpl {
             if (rc < 0) { c.out.n = n0; c.stop = rc; return; }          // (the chain goes on from end_bit by itself and reports what is wrong)
             c.end_bit = b.bit_pos();
             if (rc == PG_FINAL) { c.final = true; return; }
+            // a chunk's output is bounded: FASTQ inflates 4 : 1 (8 M symbols a chunk), but a crafted or very repetitive stream
+            // can reach 1000 : 1, and 2 * threads + 2 chunks plus as many pieces are alive at once.  Beyond the bound the chunk
+            // stops short; the chain takes what it has and inflates the rest of its range block by block in constant memory,
+            // as it does behind any chunk that stopped early
+            if (c.out.n - WIN > MAX_CHUNK_SYMBOLS) { c.stop = PG_LIMIT; return; }
         }
     }
 

@@ -307,9 +307,9 @@ int bdg_stage1_run(bdg_ctx* const* ctxs, uint32_t n_ctx, const char* in_path, co
     const double t_close0 = now_s();
     bdg_ingest_close(P.ing);
     if (getenv("BADGER_AMD_INGEST_DEBUG")) {
-        extern double g_submit_t[6];
+        extern std::atomic<double> g_submit_t[6];
         fprintf(stderr, "stage1: reader closed in %.3f s; %d submits: reserve %.3f s, offsets %.3f s, copies %.3f s, launches + D2H %.3f s\n", now_s() - t_close0,
-                (int)g_submit_t[4], g_submit_t[0], g_submit_t[1], g_submit_t[2], g_submit_t[3]);
+                (int)g_submit_t[4].load(), g_submit_t[0].load(), g_submit_t[1].load(), g_submit_t[2].load(), g_submit_t[3].load());
     }
     res->reads = P.total.reads; res->barcodes = P.total.bc; res->polyt = P.total.pt; res->r1 = P.total.r1;
     res->first_polyt = P.total.first_pt; res->first_r1 = P.total.first_r1; res->bad_read = bad_read;
@@ -425,7 +425,7 @@ int bdg_import_stage1_tsv(const char* path, uint32_t bc_len, bdg_idstore* ids, u
     struct stat sb;
     if (fstat(fd, &sb) != 0) { ::close(fd); return BDG_E_ARG; }
     const size_t size = (size_t)sb.st_size;
-    if (size == 0) { ::close(fd); return BDG_OK; }
+    if (size == 0) { ::close(fd); return BDG_E_FORMAT; }                       // (pandas: EmptyDataError "No columns to parse from file")
     void* const map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);
     if (map == MAP_FAILED) return BDG_E_ARG;
@@ -494,8 +494,18 @@ int bdg_import_stage1_tsv(const char* path, uint32_t bc_len, bdg_idstore* ids, u
                 if (!t || (fs[0] && fs[1])) break;
                 q = t + 1;
             }
+            const bool blank = le == p;
             p = next;
-            if (!fs[0] || !fs[1]) continue;                                        // fewer fields than the columns need
+            // pandas.read_csv as badger.py:92 calls it: a blank line is skipped; a row that ends before the barcode column
+            // has no barcode (NaN -> '*', :95) and stays a read; one that ends before the id column has the id NaN, which
+            // to_csv writes as an empty field; a field in double quotes loses them; an id spelled like a missing value
+            // ("NA", "NaN", ...) is NaN as well
+            if (blank) continue;
+            static const char none_field[] = "*";
+            if (!fs[1]) { fs[1] = none_field; fl[1] = 1; }
+            if (!fs[0]) { fs[0] = none_field; fl[0] = 0; }
+            for (int f = 0; f < 2; ++f) if (fl[f] >= 2 && fs[f][0] == '"' && fs[f][fl[f] - 1] == '"') { ++fs[f]; fl[f] -= 2; }
+            if (fl[0] <= 4) for (const char* t : na) if (strlen(t) == fl[0] && memcmp(t, fs[0], fl[0]) == 0) { fl[0] = 0; break; }
             if ((fl[0] == 8 && memcmp(fs[0], "#read_id", 8) == 0) || (fl[1] == 7 && memcmp(fs[1], "barcode", 7) == 0)) continue;
             size_t L = fl[1];
             bool none = L == 1 && fs[1][0] == '*';

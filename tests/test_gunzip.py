@@ -207,3 +207,28 @@ def test_streams_of_another_compressor(text):
                     rc, out, err = gunzip(z, th, chunk)
                     assert rc == 0 and out == data, (level, len(data), chunk, th, err)
         ld.libdeflate_free_compressor(comp)
+
+
+def test_a_chunks_output_is_bounded(text):
+    """A speculative chunk stops when it has produced more symbols than its bound (a very compressible stream would
+    otherwise hold gigabytes in flight); the chain takes what it has and goes on block by block.  Forced here with a bound
+    of 64 K symbols on text that inflates 1000 : 1 and on FASTQ: the bytes, the CRC and the length stay right.  (The bound
+    is read once per process: this runs in a child.)"""
+    import subprocess
+    import sys
+    code = r"""
+import gzip, sys, zlib
+sys.path.insert(0, %r)
+from tests.test_gunzip import gunzip, _fastq
+rep = (b"ACGTACGTAAAACCCC" * 64 + b"\n") * 40000            # 41 MB, compresses ~1000 : 1
+for data in (rep, _fastq(12000, 1)):
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    z = b"".join(co.compress(data[i:i + (1 << 20)]) + co.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(data), 1 << 20)) + co.flush()
+    for chunk in (4 << 10, 64 << 10):
+        rc, out, err = gunzip(z, 4, chunk)
+        assert rc == 0 and out == data, (len(data), chunk, err)
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BADGER_AMD_GUNZIP_MAX_CHUNK_KSYM="64")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

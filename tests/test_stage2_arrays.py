@@ -344,3 +344,47 @@ def test_edge_build_gpus_from_the_flags(monkeypatch):
     assert badger.edge_build_gpus(badger.parse_args(base + ["-tr", "16"])) == 1
     monkeypatch.setenv("BADGER_AMD_CONTEXTS_ON_ONE_DEVICE", "1")
     assert badger.edge_build_gpus(badger.parse_args(base + ["-tr", "3"])) == 3
+
+
+def test_native_tsv_import_on_rows_pandas_reads_its_own_way(tmp_path):
+    """badger.py:91-111 reads the stage-1 TSV with pandas.read_csv: a row that ends before the barcode column stays a read
+    without a barcode, a blank line is skipped, a quoted field loses its quotes, an id spelled like a missing value is
+    written as an empty field, repeated headers are dropped; an empty file is an error (pandas: EmptyDataError), a header
+    without rows is no reads."""
+    import pandas as pd
+    from badger_amd import _native
+    p = tmp_path / "edge.tsv"
+    p.write_text("#read_id\tbarcode\tUMI\n"
+                 "r1\tACGTACGTACGTACGT\tx\n"
+                 "r2\n"
+                 "NA\tCCCCCCCCCCCCCCCC\ty\n"
+                 "\"q1\"\tGGGGGGGGGGGGGGGG\tz\n"
+                 "\n"
+                 "r5\t\tw\n"
+                 "#read_id\tbarcode\tUMI\n"
+                 "r6\tNA\tw\n"
+                 "r7\tTTTTTTTTTTTTTTTTA\tw\n")
+    ids, rank, usable = _native.import_stage1_tsv(str(p), 16)
+    # what the reference's own statements make of the file
+    reads = pd.read_csv(str(p), sep="\t")
+    rid = reads["#read_id"].tolist()
+    observed = reads["barcode"].fillna("*").tolist()
+    want = []
+    for i in range(len(rid)):
+        if rid[i] != "#read_id" and observed[i] != "barcode":
+            o = observed[i]
+            want.append((rid[i], o[:-1] if len(o) == 17 else o))
+    assert len(ids) == len(want) == 7
+    got_ids = [ids[i] for i in range(len(ids))]
+    assert got_ids == ["" if isinstance(r, float) else r for r, _ in want]          # (NaN -> to_csv writes an empty field)
+    assert usable.tolist() == [o != "*" for _, o in want]
+    from badger_amd import synth
+    assert [synth.rank_to_str(int(r)) for r, u in zip(rank, usable) if u] == [o for _, o in want if o != "*"]
+    empty = tmp_path / "empty.tsv"
+    empty.write_text("")
+    with pytest.raises(ValueError):
+        _native.import_stage1_tsv(str(empty), 16)
+    header_only = tmp_path / "header_only.tsv"
+    header_only.write_text("#read_id\tbarcode\tUMI\n")
+    ids, rank, usable = _native.import_stage1_tsv(str(header_only), 16)
+    assert len(ids) == 0 and len(rank) == 0 and len(usable) == 0
