@@ -876,7 +876,7 @@ constexpr uint32_t D2_SLOTS = 1024;
 constexpr unsigned long long D2_ROUND_ENTRIES = 1000000000ull;      // index entries (estimated at 72 / 12 a row) per round of the join
 constexpr int DJ_THREADS = 512;                  // k_d2_pairs: threads of a block,
 constexpr uint32_t DJ_CAP = 2048;                // entries of a fine bucket it holds in LDS at a time (>= the largest group: 1920),
-constexpr uint32_t DJ_ECAPW = 256;               // edges a wave stages before it reserves output
+constexpr uint32_t DJ_ECAPW = 256;               // edges a wave stages before it reserves output (128: 39 K reservations on one address, the pair walk 0.64 ms instead of 0.55)
 
 struct D2Row { uint32_t k0, k1, z0, z1; bool keep0, keep1; };      // the lane's two 14-mers, their mixed keys, which stay
 
@@ -1037,9 +1037,9 @@ template <bool EMIT>
 __global__ __launch_bounds__(256)
 void k_d2_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per_tile, uint32_t part, uint32_t nparts, uint32_t l1,
                uint32_t* __restrict__ hist, const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
-               uint32_t* __restrict__ ent)
+               uint32_t* __restrict__ ent, ulonglong2* __restrict__ kept /* per row: which of its 120 deletion pairs stay */)
 {
-    __shared__ uint32_t s_tab[4][D2_SLOTS];
+    __shared__ uint32_t s_tab[EMIT ? 1 : 4][D2_SLOTS];
     __shared__ uint32_t s_h[bdgpart::NB1_MAX];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nb1 = 1u << l1, zb = 28u - l1;
@@ -1049,20 +1049,38 @@ void k_d2_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per
     for (uint32_t i = threadIdx.x; i < nb1; i += 256u) s_h[i] = EMIT ? (uint32_t)base[i] + hist[(size_t)blockIdx.x * nb1 + i] : 0u;
     __syncthreads();
     const uint32_t pq0 = d2_table.pq[lane], pq1 = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
-    d2_tab_init(s_tab[wv], lane);
+    if (!EMIT) d2_tab_init(s_tab[wv], lane);
     for (uint32_t chunk = row0 + (uint32_t)wv * 64u; chunk < row1; chunk += 256u) {
         const uint32_t rows = row1 - chunk < 64u ? row1 - chunk : 64u;
         const uint32_t mine = (uint32_t)lane < rows ? ranks[chunk + (uint32_t)lane] : 0u;
-        for (uint32_t i = 0; i < rows; ++i) {
-            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)i);
-            const D2Row o = d2_row(r, lane, pq0, pq1, s_tab[wv], part, nparts);
-            if (EMIT) {
-                if (o.keep0) ent[atomicAdd(&s_h[o.z0 >> zb], 1u)] = djc::enc2(o.z0, zb, (uint32_t)lane, r, pq0);
-                if (o.keep1) ent[atomicAdd(&s_h[o.z1 >> zb], 1u)] = djc::enc2(o.z1, zb, 64u + (uint32_t)lane, r, pq1);
-            } else {
+        if (EMIT) {
+            // the second run does not settle the repeats again: the first left every row's two 64-bit masks of the pairs that stay
+            const ulonglong2 km = (uint32_t)lane < rows ? kept[chunk + (uint32_t)lane] : make_ulonglong2(0ull, 0ull);
+            for (uint32_t i = 0; i < rows; ++i) {
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)i);
+                const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)km.x, (int)i), a1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(km.x >> 32), (int)i);
+                const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)km.y, (int)i), b1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(km.y >> 32), (int)i);
+                const bool keep0 = ((lane < 32 ? a0 : a1) >> (lane & 31)) & 1u, keep1 = ((lane < 32 ? b0 : b1) >> (lane & 31)) & 1u;
+                if (keep0) {
+                    const uint32_t z = djc::mix<28>(d2_key(r, pq0 >> 4, pq0 & 15u));
+                    ent[atomicAdd(&s_h[z >> zb], 1u)] = djc::enc2(z, zb, (uint32_t)lane, r, pq0);
+                }
+                if (keep1) {
+                    const uint32_t z = djc::mix<28>(d2_key(r, pq1 >> 4, pq1 & 15u));
+                    ent[atomicAdd(&s_h[z >> zb], 1u)] = djc::enc2(z, zb, 64u + (uint32_t)lane, r, pq1);
+                }
+            }
+        } else {
+            unsigned long long m0 = 0, m1 = 0;
+            for (uint32_t i = 0; i < rows; ++i) {
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)i);
+                const D2Row o = d2_row(r, lane, pq0, pq1, s_tab[wv], part, nparts);
                 if (o.keep0) atomicAdd(&s_h[o.z0 >> zb], 1u);
                 if (o.keep1) atomicAdd(&s_h[o.z1 >> zb], 1u);
+                const unsigned long long k0 = __ballot(o.keep0), k1 = __ballot(o.keep1);
+                if ((uint32_t)lane == i) { m0 = k0; m1 = k1; }
             }
+            if ((uint32_t)lane < rows) kept[chunk + (uint32_t)lane] = make_ulonglong2(m0, m1);
         }
     }
     if (!EMIT) {
@@ -1129,8 +1147,9 @@ void k_d2_pairs_w(const uint32_t* __restrict__ ent, const uint32_t* __restrict__
     static_assert(PER % 4u == 0u && (WCAP & (WCAP - 1u)) == 0u, "WCAP: 256, 512, ...");
     __shared__ unsigned long long s_kv[4][WCAP];
     __shared__ __attribute__((aligned(16))) uint32_t s_bin[4][WBIN + 4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_before[4][WCAP];
-    __shared__ uint32_t s_mark[4][CH];
+    __shared__ __attribute__((aligned(16))) uint16_t s_before[4][WCAP];      // (a bucket of 256 has fewer than 2^15 meeting slots)
+    __shared__ uint16_t s_mark[4][CH];
+    static_assert(WCAP <= 256u, "16-bit slot numbers");
     __shared__ EdgeStageT<ECAPW> stages[4];
     __shared__ uint32_t s_qa[4][128], s_qb[4][128];
     __shared__ uint32_t s_ma[4][128], s_mb[4][128], s_mk[4][128];
@@ -1187,7 +1206,7 @@ void k_d2_pairs_w(const uint32_t* __restrict__ ent, const uint32_t* __restrict__
         } else if (cnt >= 2u) {
             const uint32_t b1 = fb >> l2;
             uint4* const bin4 = reinterpret_cast<uint4*>(s_bin[wv]);
-            uint4* const bef4 = reinterpret_cast<uint4*>(s_before[wv]);
+            uint2* const bef4 = reinterpret_cast<uint2*>(s_before[wv]);        // (four 16-bit words)
 #pragma unroll
             for (uint32_t i = 0; i < PER / 4u; ++i) bin4[i * 64u + (uint32_t)lane] = make_uint4(0u, 0u, 0u, 0u);
             __builtin_amdgcn_wave_barrier();
@@ -1220,15 +1239,15 @@ void k_d2_pairs_w(const uint32_t* __restrict__ ent, const uint32_t* __restrict__
                 uint32_t k, r;
                 if (NDEL == 2) djc::dec2(e[j], b1, zb, d2_table.pq[(e[j] >> zb) & 127u], k, r); else djc::dec1(e[j], b1, zb, k, r);
                 s_kv[wv][pos] = (unsigned long long)k << 32 | r;
-                s_before[wv][pos] = end - pos - 1u;                     // (for now: L, the entries behind this one in its bin)
+                s_before[wv][pos] = (uint16_t)(end - pos - 1u);         // (for now: L, the entries behind this one in its bin)
             }
             __builtin_amdgcn_wave_barrier();
             // the meetings numbered through: a lane takes PER consecutive places
             uint32_t L[PER], bf[PER], sum = 0;
 #pragma unroll
             for (uint32_t i = 0; i < PER / 4u; ++i) {
-                const uint4 v = bef4[(uint32_t)lane * (PER / 4u) + i];
-                L[4u * i] = v.x; L[4u * i + 1u] = v.y; L[4u * i + 2u] = v.z; L[4u * i + 3u] = v.w;
+                const uint2 v = bef4[(uint32_t)lane * (PER / 4u) + i];
+                L[4u * i] = v.x & 0xFFFFu; L[4u * i + 1u] = v.x >> 16; L[4u * i + 2u] = v.y & 0xFFFFu; L[4u * i + 3u] = v.y >> 16;
             }
 #pragma unroll
             for (uint32_t i = 0; i < PER; ++i) { if ((uint32_t)lane * PER + i >= cnt) L[i] = 0u; sum += L[i]; }
@@ -1239,25 +1258,25 @@ void k_d2_pairs_w(const uint32_t* __restrict__ ent, const uint32_t* __restrict__
 #pragma unroll
                 for (uint32_t i = 0; i < PER; ++i) { bf[i] = run; run += L[i]; }
 #pragma unroll
-                for (uint32_t i = 0; i < PER / 4u; ++i) bef4[(uint32_t)lane * (PER / 4u) + i] = make_uint4(bf[4u * i], bf[4u * i + 1u], bf[4u * i + 2u], bf[4u * i + 3u]);
+                for (uint32_t i = 0; i < PER / 4u; ++i) bef4[(uint32_t)lane * (PER / 4u) + i] = make_uint2(bf[4u * i] | bf[4u * i + 1u] << 16, bf[4u * i + 2u] | bf[4u * i + 3u] << 16);
                 uint32_t carry = 0;
                 for (uint32_t cb = 0; cb < total; cb += CH) {
 #pragma unroll
-                    for (uint32_t i = 0; i < CH / 64u; ++i) s_mark[wv][i * 64u + (uint32_t)lane] = 0u;
+                    for (uint32_t i = 0; i < CH / 128u; ++i) reinterpret_cast<uint32_t*>(s_mark[wv])[i * 64u + (uint32_t)lane] = 0u;
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (uint32_t i = 0; i < PER; ++i) if (L[i] && bf[i] - cb < CH) s_mark[wv][bf[i] - cb] = (uint32_t)lane * PER + i + 1u;
+                    for (uint32_t i = 0; i < PER; ++i) if (L[i] && bf[i] - cb < CH) s_mark[wv][bf[i] - cb] = (uint16_t)((uint32_t)lane * PER + i + 1u);
                     __builtin_amdgcn_wave_barrier();
                     for (uint32_t x0 = 0; x0 < CH && cb + x0 < total; x0 += 64u) {
                         const uint32_t x = cb + x0 + (uint32_t)lane;
                         const bool act = x < total;
-                        uint32_t own = wave_incl_max(s_mark[wv][x0 + (uint32_t)lane]);
+                        uint32_t own = wave_incl_max((uint32_t)s_mark[wv][x0 + (uint32_t)lane]);
                         own = own > carry ? own : carry;
                         carry = (uint32_t)__builtin_amdgcn_readlane((int)own, 63);
                         uint32_t a = 0, b = 0, kk = 0;
                         bool on = false;
                         if (act) {
-                            const uint32_t p1 = own - 1u, p2 = p1 + 1u + (x - s_before[wv][p1]);
+                            const uint32_t p1 = own - 1u, p2 = p1 + 1u + (x - (uint32_t)s_before[wv][p1]);
                             const unsigned long long kv1 = s_kv[wv][p1], kv2 = s_kv[wv][p2];
                             kk = (uint32_t)(kv1 >> 32);
                             if (kk == (uint32_t)(kv2 >> 32)) {         // (the same variant, not just the same bin)
@@ -1457,7 +1476,7 @@ void k_d2_pairs(const uint32_t* __restrict__ ent, const uint32_t* __restrict__ f
 static uint32_t d2_pairs_blocks_per_cu()
 {
     static const uint32_t v = [] { const char* e = getenv("BADGER_AMD_D2_PAIRS_BLOCKS"); const int x = e ? atoi(e) : 4; return (uint32_t)(x < 1 ? 1 : (x > 8 ? 8 : x)); }();
-    return v;                                                          // (k_d2_pairs_w: 34 KB of LDS a block of 4 waves at 256 entries a wave)
+    return v;                                                          // (k_d2_pairs_w: 36 KB of LDS a block of 4 waves at 256 entries a wave)
 }
 
 // once per context: the device's compute units and how many blocks of the join kernels a unit holds (resident grids are sized from these)
@@ -1561,7 +1580,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             const uint32_t nb1 = 1u << l1;
             uint32_t l2_max = std::min(10u, keybits - l1 - 4u);
             // the pair walk: a wave per fine bucket of at most wcap entries (1: the block kernel for every bucket, a cross-check)
-            static const int pairs_form = [] { const char* e = getenv("BADGER_AMD_DJ_WCAP"); const int x = e ? atoi(e) : 256; return x == 1 || x == 512 ? x : 256; }();
+            static const int pairs_form = [] { const char* e = getenv("BADGER_AMD_DJ_WCAP"); const int x = e ? atoi(e) : 256; return x == 1 ? 1 : 256; }();
             uint32_t target = pairs_form == 1 ? DJ_CAP / 2u : (uint32_t)pairs_form / 2u;      // entries a fine bucket should hold
             if (const char* e = getenv("BADGER_AMD_DJ_TARGET")) target = (uint32_t)std::max(1, atoi(e));          // (for tests: oversize buckets)
             if (const char* e = getenv("BADGER_AMD_DJ_L2MAX")) l2_max = (uint32_t)std::min((int)l2_max, std::max(0, atoi(e)));
@@ -1579,13 +1598,14 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             auto* geom = tot + nb1;
             auto* fstart = geom + bdgpart::G_WORDS;
             auto* ovf = fstart + w_fstart;                                          // [0] unused, then the buckets left to the block kernel
-            if ((rc = bdg_reserve(ctx, ctx->g_qj, 4ull * 2ull * (cap_ent + 64)))) return rc;
+            if ((rc = bdg_reserve(ctx, ctx->g_qj, 4ull * 2ull * (cap_ent + 64) + (one_deletion ? 0ull : 16ull * n)))) return rc;
             auto* e_a = static_cast<uint32_t*>(ctx->g_qj.p);
             auto* e_b = e_a + cap_ent + 64;
+            auto* kept = reinterpret_cast<ulonglong2*>(e_b + cap_ent + 64);                 // (thr 2: the pairs each row keeps, from the first run to the second)
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_count" : "k_d2_count");
                 if (one_deletion) hipLaunchKernelGGL(k_d1_rows<false>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
-                else hipLaunchKernelGGL(k_d2_rows<false>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
+                else hipLaunchKernelGGL(k_d2_rows<false>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a, kept);
             }
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_scan" : "k_d2_scan");
@@ -1595,7 +1615,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_emit" : "k_d2_emit");
                 if (one_deletion) hipLaunchKernelGGL(k_d1_rows<true>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
-                else hipLaunchKernelGGL(k_d2_rows<true>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
+                else hipLaunchKernelGGL(k_d2_rows<true>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a, kept);
             }
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_split" : "k_d2_split");
@@ -1612,8 +1632,7 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
                     if (one_deletion) BDG_PAIRS_B(1, bgrid, (const uint32_t*)nullptr); else BDG_PAIRS_B(2, bgrid, (const uint32_t*)nullptr);
                 } else {
                     const uint32_t wgrid = (uint32_t)ctx->g_cus * d2_pairs_blocks_per_cu();
-                    if (pairs_form == 512) { if (one_deletion) BDG_PAIRS_W(1, 512); else BDG_PAIRS_W(2, 512); }
-                    else { if (one_deletion) BDG_PAIRS_W(1, 256); else BDG_PAIRS_W(2, 256); }
+                    if (one_deletion) BDG_PAIRS_W(1, 256); else BDG_PAIRS_W(2, 256);
                     // what the waves left: buckets beyond their capacity (none on any data met so far; the launch is a few microseconds)
                     if (one_deletion) BDG_PAIRS_B(1, (uint32_t)ctx->g_cus, ovf); else BDG_PAIRS_B(2, (uint32_t)ctx->g_cus, ovf);
                 }
