@@ -21,8 +21,8 @@
 
 namespace bdgpart {
 
-constexpr uint32_t NB1_MAX = 1024;     // coarse buckets (the producer's LDS histogram)
-constexpr uint32_t NB2_MAX = 1024;     // sub-buckets of one coarse bucket (k_part_split's LDS histogram)
+constexpr uint32_t NB1_MAX = 4096;     // coarse buckets (the producer's LDS histogram)
+constexpr uint32_t NB2_MAX = 4096;     // sub-buckets of one coarse bucket (k_part_split's LDS histograms)
 
 // geom[]: what the device decides and the later kernels read
 enum { G_L2 = 0, G_M_LO = 1, G_M_HI = 2, G_FLAGS = 3, G_OVF = 4 /* a consumer's list of buckets left to a second kernel */, G_WORDS = 8 };
@@ -75,8 +75,11 @@ void k_part_bases(const uint32_t* __restrict__ tot, uint32_t nb1, uint32_t targe
                   unsigned long long* __restrict__ base, uint32_t* __restrict__ geom)
 {
     __shared__ unsigned long long s_w[17];
+    constexpr uint32_t PT = NB1_MAX / 1024u;           // consecutive buckets per thread
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned long long v = threadIdx.x < nb1 ? tot[threadIdx.x] : 0ull;
+    unsigned long long c[PT], v = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PT; ++j) { const uint32_t b = threadIdx.x * PT + j; c[j] = b < nb1 ? tot[b] : 0ull; v += c[j]; }
     unsigned long long incl = v;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) { const unsigned long long o = __shfl_up(incl, s); if (lane >= s) incl += o; }
@@ -85,7 +88,9 @@ void k_part_bases(const uint32_t* __restrict__ tot, uint32_t nb1, uint32_t targe
     unsigned long long before = 0, all = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) { const unsigned long long x = s_w[w]; all += x; if (w < wv) before += x; }
-    if (threadIdx.x < nb1) base[threadIdx.x] = before + incl - v;
+    unsigned long long run = before + incl - v;
+#pragma unroll
+    for (uint32_t j = 0; j < PT; ++j) { const uint32_t b = threadIdx.x * PT + j; if (b < nb1) base[b] = run; run += c[j]; }
     if (threadIdx.x == 0) {
         base[nb1] = all;
         uint32_t l2 = 0;
@@ -106,18 +111,26 @@ __global__ __launch_bounds__(1024)
 void k_part_split(const E* __restrict__ in, E* __restrict__ out, const unsigned long long* __restrict__ base,
                   const uint32_t* __restrict__ geom, uint32_t nb1, uint32_t sh_top, uint32_t* __restrict__ fstart)
 {
-    constexpr uint32_t CHK = 65536u / sizeof(E), PT = CHK / 1024u;
+    constexpr uint32_t CHK = 65536u / sizeof(E), PT = CHK / 1024u, PB = NB2_MAX / 1024u;
     __shared__ E s_stage[CHK];
     __shared__ uint32_t s_g[NB2_MAX];                 // where each sub-bucket's next entry goes
     __shared__ uint32_t s_c[NB2_MAX];                 // per round: the sub-bucket's count, then its start inside the round
     __shared__ uint32_t s_w[17];
     if (geom[G_FLAGS] & 1u) return;
     const uint32_t l2 = geom[G_L2], nb2 = 1u << l2, sh = sh_top - l2, mask = nb2 - 1u;
+    // a thread owns PB consecutive sub-buckets (all of them beyond nb2 stay empty)
+    auto scan_counts = [&](uint32_t (&v)[PB], uint32_t& total) -> uint32_t {
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PB; ++j) { const uint32_t b = threadIdx.x * PB + j; v[j] = b < nb2 ? s_c[b] : 0u; sum += v[j]; }
+        return block_excl_scan<1024>(sum, s_w, total);
+    };
     for (uint32_t b = blockIdx.x; b < nb1; b += gridDim.x) {
         const unsigned long long s = base[b];
         const uint32_t c = (uint32_t)(base[b + 1] - s);
-        if (threadIdx.x < nb2) s_c[threadIdx.x] = 0u;
+        for (uint32_t j = threadIdx.x; j < nb2; j += 1024u) s_c[j] = 0u;
         __syncthreads();
+        // (four loads in flight per thread: a block streams its bucket alone on its compute unit)
         for (uint32_t i = threadIdx.x; i < c; i += 4096u) {
             E e[4];
 #pragma unroll
@@ -127,15 +140,19 @@ void k_part_split(const E* __restrict__ in, E* __restrict__ out, const unsigned 
         }
         __syncthreads();
         {
-            const uint32_t v = threadIdx.x < nb2 ? s_c[threadIdx.x] : 0u;
-            uint32_t total;
-            const uint32_t at = (uint32_t)s + block_excl_scan<1024>(v, s_w, total);
-            if (threadIdx.x < nb2) { s_g[threadIdx.x] = at; fstart[(b << l2) + threadIdx.x] = at; }
-            if (b == nb1 - 1u && threadIdx.x == 0) fstart[nb1 << l2] = (uint32_t)base[nb1];
+            uint32_t v[PB], total;
+            uint32_t at = (uint32_t)s + scan_counts(v, total);
+#pragma unroll
+            for (uint32_t j = 0; j < PB; ++j) {
+                const uint32_t sb = threadIdx.x * PB + j;
+                if (sb < nb2) { s_g[sb] = at; fstart[((size_t)b << l2) + sb] = at; }
+                at += v[j];
+            }
+            if (b == nb1 - 1u && threadIdx.x == 0) fstart[(size_t)nb1 << l2] = (uint32_t)base[nb1];
         }
         for (uint32_t c0 = 0; c0 < c; c0 += CHK) {
             const uint32_t nc = c - c0 < CHK ? c - c0 : CHK;
-            if (threadIdx.x < nb2) s_c[threadIdx.x] = 0u;
+            for (uint32_t j = threadIdx.x; j < nb2; j += 1024u) s_c[j] = 0u;
             __syncthreads();
             E e[PT];
             uint32_t rk[PT];
@@ -144,10 +161,10 @@ void k_part_split(const E* __restrict__ in, E* __restrict__ out, const unsigned 
 #pragma unroll
             for (uint32_t u = 0; u < PT; ++u) rk[u] = u * 1024u + threadIdx.x < nc ? atomicAdd(&s_c[(uint32_t)(e[u] >> sh) & mask], 1u) : 0u;
             __syncthreads();
-            const uint32_t v = threadIdx.x < nb2 ? s_c[threadIdx.x] : 0u;
-            uint32_t total;
-            const uint32_t cs = block_excl_scan<1024>(v, s_w, total);
-            if (threadIdx.x < nb2) s_c[threadIdx.x] = cs;
+            uint32_t v[PB], total;
+            uint32_t cs = scan_counts(v, total);
+#pragma unroll
+            for (uint32_t j = 0; j < PB; ++j) { const uint32_t sb = threadIdx.x * PB + j; if (sb < nb2) s_c[sb] = cs; cs += v[j]; }
             __syncthreads();
 #pragma unroll
             for (uint32_t u = 0; u < PT; ++u) if (u * 1024u + threadIdx.x < nc) s_stage[s_c[(uint32_t)(e[u] >> sh) & mask] + rk[u]] = e[u];
@@ -162,7 +179,8 @@ void k_part_split(const E* __restrict__ in, E* __restrict__ out, const unsigned 
                 }
             }
             __syncthreads();
-            if (threadIdx.x < nb2) s_g[threadIdx.x] += v;
+#pragma unroll
+            for (uint32_t j = 0; j < PB; ++j) { const uint32_t sb = threadIdx.x * PB + j; if (sb < nb2) s_g[sb] += v[j]; }
         }
         __syncthreads();
     }

@@ -1033,14 +1033,14 @@ __device__ __forceinline__ int d1_reports(uint32_t a, uint32_t b, uint32_t k)
 // bucket's cursor (the tile's place inside the bucket, from the counts of all tiles).  The two runs see the same rows and
 // drop the same repeats, so the places are exact: no atomic on global memory, nothing to size by guessing.
 // thr <= 2: one wave per row at a time (d2_row), up to 64 consecutive rows per coalesced load of their barcodes.
-template <bool EMIT>
+template <bool EMIT, uint32_t NB1CAP>
 __global__ __launch_bounds__(256)
 void k_d2_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per_tile, uint32_t part, uint32_t nparts, uint32_t l1,
                uint32_t* __restrict__ hist, const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
                uint32_t* __restrict__ ent, ulonglong2* __restrict__ kept /* per row: which of its 120 deletion pairs stay */)
 {
     __shared__ uint32_t s_tab[EMIT ? 1 : 4][D2_SLOTS];
-    __shared__ uint32_t s_h[bdgpart::NB1_MAX];
+    __shared__ uint32_t s_h[NB1CAP];                                   // (1024: eight blocks a compute unit; 4096 for inputs of millions of rows)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nb1 = 1u << l1, zb = 28u - l1;
     const uint32_t row0 = blockIdx.x * rows_per_tile;
@@ -1091,13 +1091,13 @@ void k_d2_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per
 
 // thr <= 1: the one-deletion 15-mers of a row.  Deleting any letter of a run gives the same 15-mer, so the first letter of
 // every run is deleted - exactly the distinct ones (about 12 of 16 on random barcodes).  One thread a row.
-template <bool EMIT>
+template <bool EMIT, uint32_t NB1CAP>
 __global__ __launch_bounds__(256)
 void k_d1_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per_tile, uint32_t part, uint32_t nparts, uint32_t l1,
                uint32_t* __restrict__ hist, const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
                uint32_t* __restrict__ ent)
 {
-    __shared__ uint32_t s_h[bdgpart::NB1_MAX];
+    __shared__ uint32_t s_h[NB1CAP];
     const uint32_t nb1 = 1u << l1, zb = 30u - l1;
     const uint32_t row0 = blockIdx.x * rows_per_tile;
     const uint32_t row1 = n - row0 < rows_per_tile ? n : row0 + rows_per_tile;
@@ -1575,13 +1575,16 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             const uint32_t sub = part * rounds + round, nsub = nparts * rounds;
             const unsigned long long est = (unsigned long long)n * per_row_est / nsub + 1ull;
             uint32_t l1 = 8;
-            while (l1 < 10u && (est >> l1) > (1ull << 18)) ++l1;                    // coarse buckets of at most ~256 K entries
-            if (const char* e = getenv("BADGER_AMD_DJ_L1")) l1 = (uint32_t)std::min(10, std::max(8, atoi(e)));      // (for measurements)
+            while (l1 < 12u && (est >> l1) > (1ull << 18)) ++l1;                    // coarse buckets of at most ~256 K entries
+            if (const char* e = getenv("BADGER_AMD_DJ_L1")) l1 = (uint32_t)std::min(12, std::max(8, atoi(e)));      // (for measurements)
             const uint32_t nb1 = 1u << l1;
-            uint32_t l2_max = std::min(10u, keybits - l1 - 4u);
+            // sub-buckets: as many as bring a fine bucket to `target` entries if the round emitted every row's maximum, at most
+            // 4096 (what k_part_split counts in LDS) and at most what the key has bits for
+            uint32_t l2_max = 0;
+            while (l2_max < 12u && l2_max < keybits - l1 && ((cap_ent / nsub + 1ull) >> (l1 + l2_max)) > 64ull) ++l2_max;
             // the pair walk: a wave per fine bucket of at most wcap entries (1: the block kernel for every bucket, a cross-check)
             static const int pairs_form = [] { const char* e = getenv("BADGER_AMD_DJ_WCAP"); const int x = e ? atoi(e) : 256; return x == 1 ? 1 : 256; }();
-            uint32_t target = pairs_form == 1 ? DJ_CAP / 2u : (uint32_t)pairs_form / 2u;      // entries a fine bucket should hold
+            uint32_t target = pairs_form == 1 ? DJ_CAP / 2u : (uint32_t)pairs_form * 5u / 8u;      // entries a fine bucket should hold at most on average (80 .. 160 of a wave's 256)
             if (const char* e = getenv("BADGER_AMD_DJ_TARGET")) target = (uint32_t)std::max(1, atoi(e));          // (for tests: oversize buckets)
             if (const char* e = getenv("BADGER_AMD_DJ_L2MAX")) l2_max = (uint32_t)std::min((int)l2_max, std::max(0, atoi(e)));
             uint32_t tiles_want = (uint32_t)ctx->g_cus * 8u;
@@ -1604,8 +1607,12 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             auto* kept = reinterpret_cast<ulonglong2*>(e_b + cap_ent + 64);                 // (thr 2: the pairs each row keeps, from the first run to the second)
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_count" : "k_d2_count");
-                if (one_deletion) hipLaunchKernelGGL(k_d1_rows<false>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
-                else hipLaunchKernelGGL(k_d2_rows<false>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a, kept);
+#define BDG_ROWS(EMIT) do { \
+                    if (one_deletion) { if (l1 <= 10u) hipLaunchKernelGGL((k_d1_rows<EMIT, 1024>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a); \
+                                        else hipLaunchKernelGGL((k_d1_rows<EMIT, 4096>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a); } \
+                    else { if (l1 <= 10u) hipLaunchKernelGGL((k_d2_rows<EMIT, 1024>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a, kept); \
+                           else hipLaunchKernelGGL((k_d2_rows<EMIT, 4096>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a, kept); } } while (0)
+                BDG_ROWS(false);
             }
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_scan" : "k_d2_scan");
@@ -1614,8 +1621,8 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             }
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_emit" : "k_d2_emit");
-                if (one_deletion) hipLaunchKernelGGL(k_d1_rows<true>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a);
-                else hipLaunchKernelGGL(k_d2_rows<true>, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a, kept);
+                BDG_ROWS(true);
+#undef BDG_ROWS
             }
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_split" : "k_d2_split");

@@ -882,3 +882,34 @@ def test_rows_of_dev_and_device_arrays(ctx):
         assert (d_vals.to_host(min(m, 5)) == vals[:5]).all()
         for d in (d_srt, d_vals, d_rows):
             d.free()
+
+
+@pytest.mark.parametrize("thr", [1, 2])
+def test_deletion_variant_join_with_oversize_buckets(ctx, orc, monkeypatch, thr):
+    """The joins' cold paths, forced: without the second bucket level (BADGER_AMD_DJ_L2MAX=0) a fine bucket is a whole coarse
+    one - thousands of entries - so every bucket is beyond a wave's 256 entries and goes to the block kernel through the
+    overflow list, and the larger ones beyond the block's 2048 are taken in shares of the low key bits.  Same edge lists as
+    the oracle's, alone and in parts."""
+    import torch
+    for ranks in (_observed_barcodes(300, 16000, 41), _low_complexity_barcodes(6000, 46)):
+        n = len(ranks)
+        T = orc.qgram_threshold(thr)
+        want = orc.graph_edges(ranks, thr, T, threads=8)
+        d_ranks = torch.from_numpy(ranks.view(np.int32)).cuda()
+        cap = len(want) + 1024
+        d_out = torch.zeros((cap, 3), dtype=torch.int32, device="cuda")
+        d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ctx.graph_set_algo(5 if thr == 2 else 6)
+        monkeypatch.setenv("BADGER_AMD_DJ_L2MAX", "0")
+        for nparts in (1, 3):
+            got = []
+            for part in range(nparts):
+                ctx.graph_edges_part_dev(d_ranks, n, part, nparts, thr, T, d_out, cap, d_cnt)
+                ctx.synchronize()
+                ctx.graph_status()
+                got.append(d_out[:int(d_cnt[0])].cpu().numpy().view(np.uint32).copy())
+            e = np.concatenate(got)
+            e = e[np.lexsort((e[:, 1], e[:, 0]))]
+            assert len(e) == len(want) and (e[:, 0] == want["a"]).all() and (e[:, 1] == want["b"]).all() and (e[:, 2] == want["dist"]).all(), nparts
+        monkeypatch.delenv("BADGER_AMD_DJ_L2MAX")
+        ctx.graph_set_algo(0)

@@ -62,8 +62,9 @@ def test_deletion_variant_join_kernels_budget(tmp_path):
                     "-Wno-inline-asm", "-Wno-unused-command-line-argument", "-I", os.path.join(ROOT, "include"), "-o", out, src],
                    check=True, timeout=900)
     text = open(out).read()
-    for name, max_vgpr, max_lds in (("k_d2_rowsILb0", 64, 20 * 1024), ("k_d2_rowsILb1", 64, 20 * 1024), ("k_d1_rowsILb1", 64, 4 * 1024),
-                                    ("k_part_splitIj", 64, 76 * 1024), ("k_d2_pairsILi2", 128, 53 * 1024 + 512), ("k_d2_pairsILi1", 128, 53 * 1024 + 512)):
+    for name, max_vgpr, max_lds in (("k_d2_rowsILb0ELj1024", 64, 20 * 1024), ("k_d2_rowsILb1ELj1024", 64, 8 * 1024), ("k_d1_rowsILb1ELj1024", 64, 4 * 1024),
+                                    ("k_part_splitIj", 128, 100 * 1024), ("k_d2_pairs_wILi2", 128, 40 * 1024), ("k_d2_pairs_wILi1", 128, 40 * 1024),
+                                    ("k_d2_pairsILi2", 128, 53 * 1024 + 512), ("k_d2_pairsILi1", 128, 53 * 1024 + 512)):
         m = re.search(r"^(_ZN\S*%s\S*):[^\n]*\n(.*?)\n\s*\.amdhsa_kernel \1\n(.*?)\.end_amdhsa_kernel" % name, text, re.S | re.M)
         assert m, name + " not found in the generated code"
         meta = dict(re.findall(r"\.set \S*%s\S*\.(num_vgpr|private_seg_size), (\d+)" % name, text))
