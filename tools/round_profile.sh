@@ -14,7 +14,7 @@ GPURUN=/usr/local/graft/bin/gpurun
 case $mode in
 gpu)
     rm -rf gpurun_out/${tag} gpurun_out/${tag}_c3 gpurun_out/${tag}_c5 gpurun_out/${tag}_ops
-    $GPURUN --timeout 1200 -- "timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/${tag}_tests.txt 2>&1 && bash tools/pmc_profile.sh ${tag} && bash tools/pmc_profile.sh ${tag}_c5 --config 5 && bash tools/pmc_profile.sh ${tag}_c3 --config 3 && bash tools/ops_profile.sh ${tag}_ops; tail -1 gpurun_out/${tag}_tests.txt"
+    $GPURUN --timeout 1200 -- "timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/${tag}_tests.txt 2>&1 && bash tools/pmc_profile.sh ${tag} --no-graph && bash tools/pmc_profile.sh ${tag}_c5 --config 5 && bash tools/pmc_profile.sh ${tag}_c3 --config 3 && bash tools/ops_profile.sh ${tag}_ops; tail -1 gpurun_out/${tag}_tests.txt"
     python3 tools/summarize_profile.py gpurun_out/${tag} ${tag} gpurun_out/${tag}_c5 gpurun_out/${tag}_c3   # writes profiles/traffic.json (+ valu, lds) for this build BEFORE the bench lines
     $GPURUN --timeout 1200 -- "python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err && python bench.py --config 3 > gpurun_out/${tag}_bench_c3.json 2>> gpurun_out/${tag}_bench.err && python bench.py --config 5 > gpurun_out/${tag}_bench_c5.json 2>> gpurun_out/${tag}_bench.err && python bench.py --overlap > gpurun_out/${tag}_bench_ov.json 2>> gpurun_out/${tag}_bench.err && python tools/stress_parity.py --cases 2 > gpurun_out/${tag}_stress.txt 2>&1; tail -n 1 gpurun_out/${tag}_stress.txt"
     ;;
