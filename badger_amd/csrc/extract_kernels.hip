@@ -942,30 +942,38 @@ constexpr uint32_t R1_P0 = code_plane(0), R1_P1 = code_plane(1);
 __device__ __forceinline__ uint32_t myers_search(uint32_t (&w)[10], int n, uint32_t comp)
 {
     // Only bit 21 of the vectors is ever read and carries only move upwards, so bits 22..31 are left to hold anything.
+    // A column is 20 vector instructions (round 4; the compiler's form of the textbook statements was 29): the equality mask
+    // comes from the two bit planes of R1's codes and the base's code bits spread over the word, with "matches nothing" - an
+    // N, or a place behind the window's end, turned into 'N' once before the loop - told by ASCII bit 3 (set in 'N' alone
+    // among ACGTN) inside the same two three-input operations; every other line of the recurrence that joins three words is
+    // one v_bitop3 as well.
     uint32_t pv = 0x3FFFFFu, mv = 0u, score = R1_LEN, best = R1_LEN;
     const uint32_t flip = comp ? 0x04040404u : 0u;           // complement = 2-bit code ^ 2 = ASCII bit 2
+#pragma unroll
+    for (int d = 0; d < 10; ++d) {
+        const int left = n - 4 * d;                          // window bases in this word and behind it
+        const uint32_t keep = left >= 4 ? 0xFFFFFFFFu : (left <= 0 ? 0u : (1u << (8 * left)) - 1u);
+        w[d] = ((w[d] ^ flip) & keep) | (0x4E4E4E4Eu & ~keep);
+    }
 #pragma nounroll
     for (int d = 0; d < 10; ++d) {                           // rolled: keeps the kernel at 8 waves per SIMD, which the gathers need
-        const uint32_t raw = w[0], cur = raw ^ flip;
+        const uint32_t cur = w[0];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int j = d * 4 + b;
-            // equality mask of the base against R1 from the two bit planes of R1's codes: bit i set iff both code bits agree
             const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)cur, 8 * b + 1, 1);      // 0 or ~0
             const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)cur, 8 * b + 2, 1);
-            uint32_t eq = ~((R1_P1 ^ m1) | (R1_P0 ^ m0));
-            const bool use = j < n && ((raw >> (8 * b)) & 0xFFu) != (uint32_t)'N';
-            eq = use ? eq : 0u;
+            const uint32_t mn = (uint32_t)__builtin_amdgcn_sbfe((int)cur, 8 * b + 3, 1);
+            const uint32_t off = __builtin_amdgcn_bitop3_b32(m1, R1_P1, mn, 0xBE);            // (m1 ^ P1) | mn: where the base cannot match
+            const uint32_t eq = __builtin_amdgcn_bitop3_b32(m0, R1_P0, off, 0x41);            // ~((m0 ^ P0) | off)
             const uint32_t xv = eq | mv;
-            const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-            uint32_t ph = mv | ~(xh | pv);
-            uint32_t mh = pv & xh;
+            const uint32_t xh = __builtin_amdgcn_bitop3_b32((eq & pv) + pv, pv, eq, 0xBE);     // (((eq & pv) + pv) ^ pv) | eq
+            const uint32_t ph = __builtin_amdgcn_bitop3_b32(mv, xh, pv, 0xF1);                // mv | ~(xh | pv)
+            const uint32_t mh = pv & xh;
             score += (ph >> (R1_LEN - 1)) & 1u;
             score -= (mh >> (R1_LEN - 1)) & 1u;
-            ph <<= 1;                       // search: D[0][j] = 0
-            mh <<= 1;
-            pv = mh | ~(xv | ph);
-            mv = ph & xv;
+            const uint32_t ph1 = ph << 1, mh1 = mh << 1;                                       // search: D[0][j] = 0
+            pv = __builtin_amdgcn_bitop3_b32(mh1, xv, ph1, 0xF1);                             // mh1 | ~(xv | ph1)
+            mv = ph1 & xv;
             // columns past the window have eq = 0, where the score cannot go down: no need to exclude them here
             best = score < best ? score : best;
         }
