@@ -94,8 +94,8 @@ struct bdg_ctx {
     DevBuf g_sig;        // uint32 [n] letter-count signatures
     DevBuf g_tmp0, g_tmp1, g_cnt;
     DevBuf g_qj;         // q-gram join: sorted (six-mer, row) entries, inverse positions, bucket and slice starts
-    uint32_t g_d1_min_rows = 250000;    // thr 1: from this many rows on the one-deletion join runs instead of the neighbourhood probes (BADGER_AMD_D1_MIN_ROWS)
-    uint32_t g_d2_min_rows = 60000;     // thr 2: from this many rows on the deletion-variant join runs instead of the q-gram join (BADGER_AMD_D2_MIN_ROWS)
+    uint32_t g_d1_min_rows = 100000;    // thr 1: from this many rows on the one-deletion join runs instead of the neighbourhood probes (BADGER_AMD_D1_MIN_ROWS)
+    uint32_t g_d2_min_rows = 10000;     // thr 2: from this many rows on the deletion-variant join runs instead of the q-gram join (BADGER_AMD_D2_MIN_ROWS)
     int g_cus_distinct = 0;             // compute units (bdg_distinct_dev asks by itself when no graph call has)
     uint32_t* g_dj_geom = nullptr;      // deletion-variant joins: the device-side report of the last launch (bdg_graph_status)
     int g_cus = 0, g_qj_per_cu = 0, g_qjw_per_cu = 0, g_qjw_variant = 0;   // compute units and resident blocks per unit of the join kernels (asked once)

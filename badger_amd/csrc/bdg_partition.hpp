@@ -4,11 +4,10 @@
 // the distinct-barcode count needs them in ascending order; neither needs a full radix sort of the entries through HBM.
 //
 //   level 1  the producer runs twice over tiles of its input (a tile = what one block handles): the first run counts, per
-//            tile, how many entries go to each of NB1 coarse buckets (histogram in LDS, one row of `hist` per tile);
-//            k_part_colscan turns the columns of that matrix into every tile's write position inside each bucket,
-//            k_part_bases turns the column totals into the buckets' places (and picks NB2 from the total, on the
-//            device: the host never waits for a count); the second run writes each entry to its place (cursor per
-//            bucket in LDS).
+//            tile, how many entries go to each of NB1 coarse buckets (histogram in LDS, one column of a buckets x tiles
+//            matrix per tile); k_part_colscan turns the matrix's rows into every tile's write position inside each
+//            bucket, k_part_bases the row totals into the buckets' places (and picks NB2 from the sum, on the device:
+//            the host never waits for a count); the second run writes each entry to its place (cursor per bucket in LDS).
 //   level 2  k_part_split: one block per coarse bucket reads it twice (the second time out of L2), counts NB2 sub-buckets
 //            in LDS and writes the entries grouped by sub-bucket into a second buffer, with the start of every fine
 //            bucket in `fstart`.
@@ -46,25 +45,26 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
     return before + incl - v;
 }
 
-// hist[t][b] (counts of tile t for bucket b) -> the tile's offset inside column b, in place; tot[b] = the column's sum.
-// One block per column; a thread takes a run of consecutive tiles.
+// Where a tile's entries go inside a coarse bucket.  The counting run leaves the tiles' counts as a matrix with one ROW PER
+// BUCKET (hist[b * ntiles + t]: a block stores and later loads its column with scattered 4-byte words, a few microseconds'
+// worth), so that the scan below reads and writes whole rows: one block per bucket, a thread takes consecutive tiles.
+// (Two other forms were measured.  Tile-major rows with a scan that strides through them: 14 us for 256 buckets, 50 us
+// for 1,024 - as long as the kernels around it at config 3 and in the distinct count.  No matrix at all - the counting run
+// ending with one returning atomic add per tile and bucket on the bucket's total: invisible behind config 5's long counting
+// run, but 0.5 - 2 M adds on a few hundred addresses behind a short one cost 50 - 100 us.)
 static __global__ __launch_bounds__(256)
 void k_part_colscan(uint32_t* __restrict__ hist, uint32_t ntiles, uint32_t nb1, uint32_t* __restrict__ tot)
 {
     __shared__ uint32_t s_w[5];
-    const uint32_t b = blockIdx.x;
+    uint32_t* const row = hist + (size_t)blockIdx.x * ntiles;
     const uint32_t per = (ntiles + 255u) / 256u;
     const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
     uint32_t sum = 0;
-    for (uint32_t t = t0; t < t1; ++t) sum += hist[(size_t)t * nb1 + b];
+    for (uint32_t t = t0; t < t1; ++t) sum += row[t];
     uint32_t total;
     uint32_t run = block_excl_scan<256>(sum, s_w, total);
-    for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t c = hist[(size_t)t * nb1 + b];
-        hist[(size_t)t * nb1 + b] = run;
-        run += c;
-    }
-    if (threadIdx.x == 0) tot[b] = total;
+    for (uint32_t t = t0; t < t1; ++t) { const uint32_t c = row[t]; row[t] = run; run += c; }
+    if (threadIdx.x == 0) tot[blockIdx.x] = total;
 }
 
 // base[b] = where coarse bucket b starts (64-bit sums: the total is checked, not assumed), base[nb1] = m, the number of

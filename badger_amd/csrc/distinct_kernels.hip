@@ -26,15 +26,15 @@ constexpr int DS_THREADS = 256;
 template <bool EMIT>
 __global__ __launch_bounds__(256)
 void k_distinct_rows(const bdg_extract_rec* __restrict__ recs, uint32_t n, uint32_t per_tile, uint32_t l1,
-                     uint32_t* __restrict__ hist, const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
-                     unsigned long long* __restrict__ ent, uint32_t* __restrict__ out_n)
+                     uint32_t* __restrict__ hist, uint32_t* __restrict__ tot, const unsigned long long* __restrict__ base,
+                     const uint32_t* __restrict__ geom, unsigned long long* __restrict__ ent, uint32_t* __restrict__ out_n)
 {
     __shared__ uint32_t s_h[bdgpart::NB1_MAX];
     const uint32_t nb1 = 1u << l1, sh = 32u - l1;
     const uint32_t row0 = blockIdx.x * per_tile;
     const uint32_t row1 = n - row0 < per_tile ? n : row0 + per_tile;
     if (EMIT && (geom[bdgpart::G_FLAGS] & 1u)) return;
-    for (uint32_t i = threadIdx.x; i < nb1; i += 256u) s_h[i] = EMIT ? (uint32_t)base[i] + hist[(size_t)blockIdx.x * nb1 + i] : 0u;
+    for (uint32_t i = threadIdx.x; i < nb1; i += 256u) s_h[i] = EMIT ? (uint32_t)base[i] + hist[(size_t)i * gridDim.x + blockIdx.x] : 0u;
     __syncthreads();
     for (uint32_t i = row0 + threadIdx.x; i < row1; i += 256u) {
         const bdg_extract_rec r = recs[i];
@@ -46,7 +46,7 @@ void k_distinct_rows(const bdg_extract_rec* __restrict__ recs, uint32_t n, uint3
     }
     if (!EMIT) {
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nb1; i += 256u) hist[(size_t)blockIdx.x * nb1 + i] = s_h[i];
+        for (uint32_t i = threadIdx.x; i < nb1; i += 256u) hist[(size_t)i * gridDim.x + blockIdx.x] = s_h[i];      // (one row per bucket: k_part_colscan)
     }
 }
 
@@ -305,10 +305,10 @@ int bdg_distinct_launch(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t n,
     auto* t_first = t_count + n;
     {
         ScopedKernelTimer tm(ctx, "k_distinct_rows");
-        hipLaunchKernelGGL(k_distinct_rows<false>, dim3(ntiles), dim3(256), 0, st, d_recs, n, per_tile, l1, hist, base, geom, e_a, d_n);
+        hipLaunchKernelGGL(k_distinct_rows<false>, dim3(ntiles), dim3(256), 0, st, d_recs, n, per_tile, l1, hist, tot, base, geom, e_a, d_n);
         hipLaunchKernelGGL(bdgpart::k_part_colscan, dim3(nb1), dim3(256), 0, st, hist, ntiles, nb1, tot);
         hipLaunchKernelGGL(bdgpart::k_part_bases, dim3(1), dim3(1024), 0, st, tot, nb1, DS_CAP, l2_max, (unsigned long long)n, base, geom);
-        hipLaunchKernelGGL(k_distinct_rows<true>, dim3(ntiles), dim3(256), 0, st, d_recs, n, per_tile, l1, hist, base, geom, e_a, d_n);
+        hipLaunchKernelGGL(k_distinct_rows<true>, dim3(ntiles), dim3(256), 0, st, d_recs, n, per_tile, l1, hist, tot, base, geom, e_a, d_n);
         if (two_levels) hipLaunchKernelGGL(bdgpart::k_part_split<unsigned long long>, dim3(nb1), dim3(1024), 0, st, e_a, e_b, base, geom, nb1, 64u - l1, fstart);
     }
     {

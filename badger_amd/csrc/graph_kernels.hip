@@ -1036,7 +1036,8 @@ __device__ __forceinline__ int d1_reports(uint32_t a, uint32_t b, uint32_t k)
 template <bool EMIT, uint32_t NB1CAP>
 __global__ __launch_bounds__(256)
 void k_d2_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per_tile, uint32_t part, uint32_t nparts, uint32_t l1,
-               uint32_t* __restrict__ hist, const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
+               uint32_t* __restrict__ hist /* [tiles][nb1]: the tile's place inside each bucket */, uint32_t* __restrict__ tot,
+               const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
                uint32_t* __restrict__ ent, ulonglong2* __restrict__ kept /* per row: which of its 120 deletion pairs stay */)
 {
     __shared__ uint32_t s_tab[EMIT ? 1 : 4][D2_SLOTS];
@@ -1046,7 +1047,7 @@ void k_d2_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per
     const uint32_t row0 = blockIdx.x * rows_per_tile;
     const uint32_t row1 = n - row0 < rows_per_tile ? n : row0 + rows_per_tile;
     if (EMIT && (geom[bdgpart::G_FLAGS] & 1u)) return;                 // (more entries than the caller can index: it cuts smaller)
-    for (uint32_t i = threadIdx.x; i < nb1; i += 256u) s_h[i] = EMIT ? (uint32_t)base[i] + hist[(size_t)blockIdx.x * nb1 + i] : 0u;
+    for (uint32_t i = threadIdx.x; i < nb1; i += 256u) s_h[i] = EMIT ? (uint32_t)base[i] + hist[(size_t)i * gridDim.x + blockIdx.x] : 0u;
     __syncthreads();
     const uint32_t pq0 = d2_table.pq[lane], pq1 = d2_table.pq[lane < D2_NPAIR - 64 ? 64 + lane : 0];
     if (!EMIT) d2_tab_init(s_tab[wv], lane);
@@ -1085,7 +1086,7 @@ void k_d2_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per
     }
     if (!EMIT) {
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nb1; i += 256u) hist[(size_t)blockIdx.x * nb1 + i] = s_h[i];
+        for (uint32_t i = threadIdx.x; i < nb1; i += 256u) hist[(size_t)i * gridDim.x + blockIdx.x] = s_h[i];      // (one row per bucket: k_part_colscan)
     }
 }
 
@@ -1094,7 +1095,7 @@ void k_d2_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per
 template <bool EMIT, uint32_t NB1CAP>
 __global__ __launch_bounds__(256)
 void k_d1_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per_tile, uint32_t part, uint32_t nparts, uint32_t l1,
-               uint32_t* __restrict__ hist, const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
+               uint32_t* __restrict__ hist, uint32_t* __restrict__ tot, const unsigned long long* __restrict__ base, const uint32_t* __restrict__ geom,
                uint32_t* __restrict__ ent)
 {
     __shared__ uint32_t s_h[NB1CAP];
@@ -1102,7 +1103,7 @@ void k_d1_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per
     const uint32_t row0 = blockIdx.x * rows_per_tile;
     const uint32_t row1 = n - row0 < rows_per_tile ? n : row0 + rows_per_tile;
     if (EMIT && (geom[bdgpart::G_FLAGS] & 1u)) return;
-    for (uint32_t i = threadIdx.x; i < nb1; i += 256u) s_h[i] = EMIT ? (uint32_t)base[i] + hist[(size_t)blockIdx.x * nb1 + i] : 0u;
+    for (uint32_t i = threadIdx.x; i < nb1; i += 256u) s_h[i] = EMIT ? (uint32_t)base[i] + hist[(size_t)i * gridDim.x + blockIdx.x] : 0u;
     __syncthreads();
     for (uint32_t row = row0 + threadIdx.x; row < row1; row += 256u) {
         const uint32_t r = ranks[row];
@@ -1120,7 +1121,7 @@ void k_d1_rows(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per
     }
     if (!EMIT) {
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nb1; i += 256u) hist[(size_t)blockIdx.x * nb1 + i] = s_h[i];
+        for (uint32_t i = threadIdx.x; i < nb1; i += 256u) hist[(size_t)i * gridDim.x + blockIdx.x] = s_h[i];      // (one row per bucket: k_part_colscan)
     }
 }
 
@@ -1608,10 +1609,10 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
             {
                 ScopedKernelTimer tm(ctx, one_deletion ? "k_d1_count" : "k_d2_count");
 #define BDG_ROWS(EMIT) do { \
-                    if (one_deletion) { if (l1 <= 10u) hipLaunchKernelGGL((k_d1_rows<EMIT, 1024>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a); \
-                                        else hipLaunchKernelGGL((k_d1_rows<EMIT, 4096>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a); } \
-                    else { if (l1 <= 10u) hipLaunchKernelGGL((k_d2_rows<EMIT, 1024>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a, kept); \
-                           else hipLaunchKernelGGL((k_d2_rows<EMIT, 4096>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, base, geom, e_a, kept); } } while (0)
+                    if (one_deletion) { if (l1 <= 10u) hipLaunchKernelGGL((k_d1_rows<EMIT, 1024>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, tot, base, geom, e_a); \
+                                        else hipLaunchKernelGGL((k_d1_rows<EMIT, 4096>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, tot, base, geom, e_a); } \
+                    else { if (l1 <= 10u) hipLaunchKernelGGL((k_d2_rows<EMIT, 1024>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, tot, base, geom, e_a, kept); \
+                           else hipLaunchKernelGGL((k_d2_rows<EMIT, 4096>), dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, sub, nsub, l1, hist, tot, base, geom, e_a, kept); } } while (0)
                 BDG_ROWS(false);
             }
             {

@@ -323,8 +323,8 @@ int  bdg_graph_edges_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint
  * lists whose union is the full list. */
 int  bdg_graph_edges_rows_dev(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t row_begin, uint32_t row_end,
                               uint32_t thr, int32_t qgram_T, bdg_edge* d_out, uint64_t cap, uint64_t* d_n_edges);
-/* 0 automatic (thr 1: neighbourhood probes below 250,000 rows, the one-deletion join from there on; thr 2: deletion-variant
- * join; thr >= 3: q-gram join), 1 all-pairs scan,
+/* 0 automatic (thr 1: neighbourhood probes below 100,000 rows, the one-deletion join from there on; thr 2: deletion-variant
+ * join from 10,000 rows on, the q-gram join below; thr >= 3: q-gram join), 1 all-pairs scan,
  * 2 neighbourhood probes (thr = 1 only), 3 q-gram join (the device form of QGramIndex, index.py:29-35,77-93; any thr),
  * 4 the same with every candidate verified in closed form (the join's fallback for slices its table cannot take; for tests),
  * 5 deletion-variant join (thr <= 2: rows that share a 14-mer left by two deletions meet; same dmin and S tests; work linear

@@ -249,19 +249,20 @@ def test_mixed_keys_group_whole_variants_and_spread_them_evenly():
 
 
 def test_counting_pass_places_are_exact():
-    """bdg_partition.hpp in numpy: per-tile histograms -> column scan -> bases give every (tile, bucket) run its own place;
-    scattering with per-tile cursors fills [0, m) exactly once and every bucket's range holds exactly its entries."""
+    """bdg_partition.hpp in numpy: the tiles' counts as a buckets x tiles matrix -> a scan along every row gives each
+    (bucket, tile) run its own place, k_part_bases turns the row totals into the buckets' places; scattering with per-tile
+    cursors then fills [0, m) exactly once and every bucket's range holds exactly its entries."""
     rng = np.random.default_rng(5)
     ntiles, nb1 = 37, 256
     tiles = [rng.integers(0, 1 << 28, int(rng.integers(0, 900))).astype(np.uint64) for _ in range(ntiles)]
-    hist = np.stack([np.bincount((t >> np.uint64(20)).astype(np.int64), minlength=nb1) for t in tiles])
-    within = np.cumsum(hist, axis=0) - hist                               # k_part_colscan
-    tot = hist.sum(axis=0)
+    hist = np.stack([np.bincount((t >> np.uint64(20)).astype(np.int64), minlength=nb1) for t in tiles]).T      # [bucket][tile]
+    within = np.cumsum(hist, axis=1) - hist                               # k_part_colscan: one row per bucket
+    tot = hist.sum(axis=1)
     base = np.concatenate([[0], np.cumsum(tot)])                          # k_part_bases
     m = int(base[-1])
     out = np.full(m, -1, dtype=np.int64)
     for t, ent in enumerate(tiles):
-        cur = base[:-1] + within[t]                                       # the tile's cursors
+        cur = base[:-1] + within[:, t]                                    # the tile's cursors
         for e in ent:
             b = int(e >> np.uint64(20))
             assert out[cur[b]] == -1
