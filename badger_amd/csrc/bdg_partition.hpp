@@ -101,6 +101,48 @@ void k_part_bases(const uint32_t* __restrict__ tot, uint32_t nb1, uint32_t targe
     }
 }
 
+// Inclusive prefix sums of n 32-bit words in place (n up to 2^32; sums must fit 32 bits): 16,384 words per block - every
+// block scans its stretch and leaves its total, one block scans the totals, every block adds what lies in front of it.
+// (The directory of the whitelist's deletion variants, 2^25 words, once per whitelist: hipCUB's scan stood here.)
+constexpr uint32_t SCAN_SPAN = 16384;
+static __global__ __launch_bounds__(1024)
+void k_scan_blocks(uint32_t* __restrict__ a, unsigned long long n, uint32_t* __restrict__ sums)
+{
+    __shared__ uint32_t s_w[17];
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * SCAN_SPAN + threadIdx.x * 16ull;
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { v[j] = i0 + j < n ? a[i0 + j] : 0u; sum += v[j]; }
+    uint32_t total;
+    uint32_t run = block_excl_scan<1024>(sum, s_w, total);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { run += v[j]; if (i0 + j < n) a[i0 + j] = run; }
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+static __global__ __launch_bounds__(1024)
+void k_scan_sums(uint32_t* __restrict__ sums, uint32_t nblocks)       // exclusive, one block
+{
+    __shared__ uint32_t s_w[17];
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += 1024u) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t v = b < nblocks ? sums[b] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<1024>(v, s_w, total);
+        if (b < nblocks) sums[b] = carry + ex;
+        carry += total;
+    }
+}
+static __global__ __launch_bounds__(1024)
+void k_scan_add(uint32_t* __restrict__ a, unsigned long long n, const uint32_t* __restrict__ sums)
+{
+    const uint32_t add = sums[blockIdx.x];
+    if (add == 0u) return;
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * SCAN_SPAN + threadIdx.x * 16ull;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) if (i0 + j < n) a[i0 + j] += add;
+}
+
 // One block per coarse bucket: its entries grouped by sub-bucket (bits [sh_top - l2, sh_top) of an entry) into `out`,
 // the places of the fine buckets into fstart[b << l2 | j], fstart[nb1 << l2] = m.  Any bucket size: the bucket is streamed
 // twice, first for the sub-buckets' sizes, then in rounds of 64 KB that are grouped inside LDS before they leave, so that

@@ -23,8 +23,6 @@
 #include "bdg_partition.hpp"
 #include "dj_codec.hpp"
 
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 #include <cstdlib>
 
@@ -379,9 +377,9 @@ void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
 //
 // The reference keeps 4096 buckets {rank: count} and, for every barcode, sums the counts of all later
 // barcodes over its 11 six-mers: distances[j] = S(i, j); candidates are the j with S >= T.  Here:
-//   k_qj_emit    one entry (six-mer, row << 4 | position) per barcode and position: 11 n entries,
-//   hipCUB       stable radix sort on the 12 key bits: a bucket is a contiguous run, rows ascending inside it,
-//   k_qj_index   where each (row, position) landed (pos_of), where each bucket starts,
+//   k_qj_count / k_part_colscan / k_part_bases / k_qj_place   one entry row << 4 | position per barcode and position (11 n
+//                entries) in its six-mer's bucket, rows ascending inside it (a stable counting sort on the 12 key bits), where
+//                each (row, position) landed (pos_of), where each bucket starts,
 //   k_qj_split   for every bucket the first entry at or past each multiple of W rows (so that a row can take its
 //                candidates in slices of W rows without searching),
 //   k_graph_qjoin one block per row i: for each slice of later rows, every entry of the 11 bucket tails is one unit
@@ -396,28 +394,70 @@ void k_graph_probe(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
 constexpr int QJ_NQ = 11;                        // six-mers per 16-mer
 constexpr uint32_t QJ_W = 32768;                 // rows per slice = bytes of LDS counters per block
 
+// The index: every (row, position) entry in its six-mer's bucket, rows ascending inside a bucket - a stable counting sort on
+// the 12 key bits, in the two runs of csrc/bdg_partition.hpp (round 3 called hipCUB's radix sort here).
+// k_qj_count: a tile of rows per block, how many entries it has for each of the 4,096 six-mers (one column of the
+// buckets x tiles matrix; k_part_colscan / k_part_bases turn it into places: tiles ascend inside a bucket).
 __global__ __launch_bounds__(256)
-void k_qj_emit(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+void k_qj_count(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per_tile, uint32_t* __restrict__ hist)
 {
-    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (g >= (uint64_t)n * QJ_NQ) return;
-    const uint32_t row = (uint32_t)(g / QJ_NQ), p = (uint32_t)(g % QJ_NQ);
-    keys[g] = (ranks[row] >> (2u * p)) & 0xFFFu;            // barcode[p:p+6] (index.py:31-33), as the rank of the slice
-    vals[g] = (row << 4) | p;
+    __shared__ uint32_t s_h[4096];
+    for (uint32_t i = threadIdx.x; i < 4096u; i += 256u) s_h[i] = 0u;
+    __syncthreads();
+    const uint32_t row0 = blockIdx.x * rows_per_tile;
+    const uint32_t row1 = n - row0 < rows_per_tile ? n : row0 + rows_per_tile;
+    for (uint32_t row = row0 + threadIdx.x; row < row1; row += 256u) {
+        const uint32_t r = ranks[row];
+#pragma unroll
+        for (uint32_t p = 0; p < (uint32_t)QJ_NQ; ++p) atomicAdd(&s_h[(r >> (2u * p)) & 0xFFFu], 1u);     // barcode[p:p+6] (index.py:31-33)
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 4096u; i += 256u) hist[(size_t)i * gridDim.x + blockIdx.x] = s_h[i];
 }
 
-__global__ __launch_bounds__(256)
-void k_qj_index(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t m,
-                uint32_t* __restrict__ pos_of, uint32_t* __restrict__ bucket_off /* [4097] */)
+// k_qj_place: one WAVE per tile walks the tile's entries in (row, position) order, 64 at a time, and gives every entry the
+// next place of its bucket: inside a group of 64 the entries of one six-mer are told apart by twelve ballots (one per key
+// bit: the lanes that agree with this one on every bit), an entry's place is the bucket's cursor plus the number of such
+// lanes below it, and the last of them moves the cursor on.  Rows therefore ascend inside every bucket, positions inside
+// a row.  vals[place] = row << 4 | position, pos_of[row * 11 + position] = place, bucket_off[q] = where bucket q starts.
+__global__ __launch_bounds__(64)
+void k_qj_place(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t rows_per_tile, const uint32_t* __restrict__ hist,
+                const unsigned long long* __restrict__ base, uint32_t* __restrict__ vals, uint32_t* __restrict__ pos_of,
+                uint32_t* __restrict__ bucket_off /* [4097] */)
 {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k >= m) return;
-    const uint32_t v = vals[k];
-    pos_of[(v >> 4) * QJ_NQ + (v & 15u)] = k;
-    const uint32_t key = keys[k];
-    const uint32_t first = k ? keys[k - 1] + 1u : 0u;       // buckets (prev key, key] start here (empty ones included)
-    for (uint32_t q = first; q <= key; ++q) bucket_off[q] = k;
-    if (k == m - 1) for (uint32_t q = key + 1u; q <= 4096u; ++q) bucket_off[q] = m;
+    __shared__ uint32_t s_cur[4096];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 4096u; i += 64u) {
+        const uint32_t b = (uint32_t)base[i];
+        s_cur[i] = b + hist[(size_t)i * gridDim.x + blockIdx.x];
+        if (blockIdx.x == 0) bucket_off[i] = b;
+    }
+    if (blockIdx.x == 0 && lane == 0) bucket_off[4096] = (uint32_t)base[4096];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t row0 = blockIdx.x * rows_per_tile;
+    const uint32_t row1 = n - row0 < rows_per_tile ? n : row0 + rows_per_tile;
+    const unsigned long long g0 = (unsigned long long)row0 * QJ_NQ, g1 = (unsigned long long)row1 * QJ_NQ;
+    for (unsigned long long gb = g0; gb < g1; gb += 64ull) {
+        const unsigned long long g = gb + lane;
+        const bool on = g < g1;
+        const uint32_t row = on ? (uint32_t)(g / QJ_NQ) : 0u, p = on ? (uint32_t)(g % QJ_NQ) : 0u;
+        const uint32_t key = on ? (ranks[row] >> (2u * p)) & 0xFFFu : 0u;
+        unsigned long long peers = __ballot(on);
+#pragma unroll
+        for (uint32_t bit = 0; bit < 12u; ++bit) {
+            const unsigned long long m = __ballot((key >> bit) & 1u);
+            peers &= ((key >> bit) & 1u) ? m : ~m;
+        }
+        if (on) {
+            const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+            const uint32_t at = s_cur[key] + below;
+            vals[at] = (row << 4) | p;
+            pos_of[g] = at;
+        }
+        __builtin_amdgcn_wave_barrier();                              // (every lane has read its cursor)
+        if (on && (peers >> lane) == 1ull) s_cur[key] += (uint32_t)__popcll(peers);      // the group's highest lane
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // split[q * (G + 1) + g] = first entry of bucket q whose row is >= g * W
@@ -1662,24 +1702,27 @@ int bdg_graph_launch(bdg_ctx* ctx, const uint32_t* d_ranks, uint32_t n, uint32_t
         const uint32_t W = QJ_W;
         const uint32_t G = (n + W - 1) / W;
         const bool closed_form = ctx->graph_algo == 4;
-        size_t t_sort = 0;
-        uint32_t* nul = nullptr;
-        BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, nul, nul, nul, nul, (int)m, 0, 12, st));
-        const size_t words = 5 * m + 4097 + 4096ull * (G + 1) + 64;
-        if ((rc = bdg_reserve(ctx, ctx->g_qj, sizeof(uint32_t) * words + t_sort + 256))) return rc;
-        auto* k_in = static_cast<uint32_t*>(ctx->g_qj.p);
-        auto* k_out = k_in + m;
-        auto* v_in = k_out + m;
-        auto* v_out = v_in + m;
+        // tiles of rows for the two runs of the counting sort: at most ~512 of them (the place run gives a tile to one wave)
+        uint32_t rows_per_tile = ((n + 511u) / 512u + 63u) & ~63u;
+        if (rows_per_tile < 64u) rows_per_tile = 64u;
+        const uint32_t ntiles = (n + rows_per_tile - 1u) / rows_per_tile;
+        // workspace: base u64 [4097] | v_out [m] | pos_of [m] | bucket_off [4097] | split | hist [4096][ntiles] | tot [4096] | geom
+        const size_t words = 2 * m + 4097 + 4096ull * (G + 1) + 4096ull * ntiles + 4096 + bdgpart::G_WORDS + 64;
+        if ((rc = bdg_reserve(ctx, ctx->g_qj, 8ull * 4098 + sizeof(uint32_t) * words + 256))) return rc;
+        auto* base = static_cast<unsigned long long*>(ctx->g_qj.p);
+        auto* v_out = reinterpret_cast<uint32_t*>(base + 4098);
         auto* pos_of = v_out + m;
         auto* bucket_off = pos_of + m;
         auto* split = bucket_off + 4097;
-        void* temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(split + 4096ull * (G + 1)) + 255) & ~uintptr_t(255));
+        auto* hist = split + 4096ull * (G + 1);
+        auto* tot = hist + 4096ull * ntiles;
+        auto* geom = tot + 4096;
         {
             ScopedKernelTimer tm(ctx, "k_qj_build");
-            hipLaunchKernelGGL(k_qj_emit, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, d_ranks, n, k_in, v_in);
-            BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(temp, t_sort, k_in, k_out, v_in, v_out, (int)m, 0, 12, st));
-            hipLaunchKernelGGL(k_qj_index, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, k_out, v_out, (uint32_t)m, pos_of, bucket_off);
+            hipLaunchKernelGGL(k_qj_count, dim3(ntiles), dim3(256), 0, st, d_ranks, n, rows_per_tile, hist);
+            hipLaunchKernelGGL(bdgpart::k_part_colscan, dim3(4096), dim3(256), 0, st, hist, ntiles, 4096u, tot);
+            hipLaunchKernelGGL(bdgpart::k_part_bases, dim3(1), dim3(1024), 0, st, tot, 4096u, 1u, 0u, (unsigned long long)m, base, geom);
+            hipLaunchKernelGGL(k_qj_place, dim3(ntiles), dim3(64), 0, st, d_ranks, n, rows_per_tile, hist, base, v_out, pos_of, bucket_off);
             if (closed_form) hipLaunchKernelGGL(k_qj_split, dim3((4096u * (G + 1) + 255) / 256), dim3(256), 0, st, v_out, bucket_off, G, W, split);
         }
         if ((rc = graph_props(ctx))) return rc;

@@ -14,8 +14,7 @@
 //          a 2^30-bit map of the whitelist's variants, then the owners of a variant that is present (pass 2).  Details
 //          at PairTables / delmap_index below.
 #include "bdg_common.hpp"
-
-#include <hipcub/hipcub.hpp>
+#include "bdg_partition.hpp"
 
 #include <algorithm>
 #include <numeric>
@@ -271,9 +270,16 @@ __device__ __forceinline__ uint32_t delmap_index(uint32_t d, int g)
 }
 constexpr uint32_t DELMAP_WORDS = 1u << 25;              // 2^30 bits per copy
 
+// PLACE = false: the map bits and how many variants fall into each directory bucket (dir[bucket + 2]: an inclusive scan
+// then leaves every bucket's start at dir[bucket + 1] and its end at dir[bucket + 2]).  PLACE = true: every variant's entry
+// {variant, rank, caller index, 0} at the next free place of its bucket (an atomic add on dir[bucket + 1], which thereby
+// moves on to the bucket's end = the next bucket's start: afterwards dir[b] is where bucket b starts and dir[b + 1] where
+// it ends, the form the look-ups read).  A counting sort on the directory key: inside a bucket - 0.35 entries on average -
+// the look-up compares every entry anyway, so no order is needed there (round 3 radix-sorted the pairs with hipCUB).
+template <bool PLACE>
 __global__ __launch_bounds__(256)
-void k_build_delmap(const uint32_t* __restrict__ wl, uint32_t nw, uint32_t* __restrict__ delmap,
-                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ dir)
+void k_build_delmap(const uint32_t* __restrict__ wl, const uint32_t* __restrict__ orig, uint32_t nw, uint32_t* __restrict__ delmap,
+                    uint32_t* __restrict__ dir, uint4* __restrict__ ent)
 {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t w = g >> 4; const int i = (int)(g & 15u);
@@ -282,24 +288,14 @@ void k_build_delmap(const uint32_t* __restrict__ wl, uint32_t nw, uint32_t* __re
     const uint32_t lm = low_mask(i);
     const uint32_t d = ((r & lm) | ((r >> 2) & ~lm)) & 0x3FFFFFFFu;
     const bool dup = i > 0 && (((r >> (2 * i)) ^ (r >> (2 * i - 2))) & 3u) == 0u;
-    keys[g] = dup ? 0xFFFFFFFFu : d;
-    vals[g] = w;                                          // position in the sorted whitelist
-    if (!dup) {
+    if (dup) return;
+    if (PLACE) {
+        ent[atomicAdd(&dir[(d >> DV_DIR_SHIFT) + 1], 1u)] = make_uint4(d, r, orig[w], 0u);
+    } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { const uint32_t x = delmap_index(d, c); atomicOr(&delmap[c * DELMAP_WORDS + (x >> 5)], 1u << (x & 31u)); }
-        atomicAdd(&dir[(d >> DV_DIR_SHIFT) + 1], 1u);     // histogram; an inclusive scan turns it into bucket starts
+        atomicAdd(&dir[(d >> DV_DIR_SHIFT) + 2], 1u);
     }
-}
-
-// (variant, entry) pairs after the sort, with what a hit needs from the entry beside them: {variant, rank, caller index, 0}
-__global__ __launch_bounds__(256)
-void k_pack_variants(const uint32_t* __restrict__ dv_var, const uint32_t* __restrict__ dv_pos, uint32_t n,
-                     const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ orig, uint4* __restrict__ out)
-{
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t v = dv_var[k], p = dv_pos[k];
-    out[k] = v == 0xFFFFFFFFu ? make_uint4(v, 0u, 0u, 0u) : make_uint4(v, sorted[p], orig[p], 0u);
 }
 
 __global__ __launch_bounds__(256)
@@ -535,35 +531,25 @@ static int build_delins_index(bdg_ctx* ctx)
     if ((rc = bdg_reserve(ctx, ctx->w_delmap, size_t(4) << 27))) return rc;          // four copies of 2^30 bits
     BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->w_delmap.p, 0, size_t(4) << 27, ctx->stream));
     {
-        // deletion variants: map bits + (variant, entry) pairs sorted by variant on the device + directory
+        // deletion variants: map bits, the directory (how many variants per bucket -> where each bucket starts), the entries
         const size_t npairs = 16ull * nw;
         if (npairs >= (size_t(1) << 31)) return bdg_fail(ctx, BDG_E_ARG, "whitelist too large");
-        if ((rc = bdg_reserve(ctx, ctx->w_dv, sizeof(uint32_t) * (4 * npairs + DV_DIR_N + 2)))) return rc;
+        const size_t ndir = (size_t)DV_DIR_N + 3;
+        const uint32_t nscan = (uint32_t)((ndir + bdgpart::SCAN_SPAN - 1) / bdgpart::SCAN_SPAN);
+        if ((rc = bdg_reserve(ctx, ctx->w_dv, sizeof(uint32_t) * (4 * npairs + ndir + nscan + 8)))) return rc;
         auto* dv_ent = static_cast<uint4*>(ctx->w_dv.p);
         auto* dv_dir = static_cast<uint32_t*>(ctx->w_dv.p) + 4 * npairs;
-        uint32_t *k_in = nullptr, *v_in = nullptr, *dv_var = nullptr, *dv_pos = nullptr; void* temp = nullptr;
-        size_t t_sort = 0, t_scan = 0;
-        BDG_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, k_in, dv_var, v_in, dv_pos, (int)npairs, 0, 32, ctx->stream));
-        BDG_HIP_TRY(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, t_scan, dv_dir, dv_dir, (int)(DV_DIR_N + 1), ctx->stream));
-        BDG_HIP_TRY(ctx, hipMalloc(&k_in, sizeof(uint32_t) * npairs));
-        hipError_t e = hipMalloc(&v_in, sizeof(uint32_t) * npairs);
-        if (e == hipSuccess) e = hipMalloc(&dv_var, sizeof(uint32_t) * npairs);
-        if (e == hipSuccess) e = hipMalloc(&dv_pos, sizeof(uint32_t) * npairs);
-        if (e == hipSuccess) e = hipMalloc(&temp, std::max(t_sort, t_scan));
-        if (e == hipSuccess) e = hipMemsetAsync(dv_dir, 0, sizeof(uint32_t) * (DV_DIR_N + 2), ctx->stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_build_delmap, dim3((uint32_t)((npairs + 255) / 256)), dim3(256), 0, ctx->stream,
-                               static_cast<const uint32_t*>(ctx->w_sorted.p), nw, static_cast<uint32_t*>(ctx->w_delmap.p),
-                               k_in, v_in, dv_dir);
-            e = hipcub::DeviceRadixSort::SortPairs(temp, t_sort, k_in, dv_var, v_in, dv_pos, (int)npairs, 0, 32, ctx->stream);
-            if (e == hipSuccess)
-                hipLaunchKernelGGL(k_pack_variants, dim3((uint32_t)((npairs + 255) / 256)), dim3(256), 0, ctx->stream, dv_var, dv_pos,
-                                   (uint32_t)npairs, static_cast<const uint32_t*>(ctx->w_sorted.p), static_cast<const uint32_t*>(ctx->w_orig.p), dv_ent);
-        }
-        if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(temp, t_scan, dv_dir, dv_dir, (int)(DV_DIR_N + 1), ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(k_in); (void)hipFree(v_in); (void)hipFree(dv_var); (void)hipFree(dv_pos); (void)hipFree(temp);
-        BDG_HIP_TRY(ctx, e);
+        auto* sums = dv_dir + ndir;
+        const auto* srt = static_cast<const uint32_t*>(ctx->w_sorted.p);
+        const auto* org = static_cast<const uint32_t*>(ctx->w_orig.p);
+        const dim3 grid((uint32_t)((npairs + 255) / 256));
+        BDG_HIP_TRY(ctx, hipMemsetAsync(dv_dir, 0, sizeof(uint32_t) * ndir, ctx->stream));
+        hipLaunchKernelGGL(k_build_delmap<false>, grid, dim3(256), 0, ctx->stream, srt, org, nw, static_cast<uint32_t*>(ctx->w_delmap.p), dv_dir, dv_ent);
+        hipLaunchKernelGGL(bdgpart::k_scan_blocks, dim3(nscan), dim3(1024), 0, ctx->stream, dv_dir, (unsigned long long)ndir, sums);
+        hipLaunchKernelGGL(bdgpart::k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, sums, nscan);
+        hipLaunchKernelGGL(bdgpart::k_scan_add, dim3(nscan), dim3(1024), 0, ctx->stream, dv_dir, (unsigned long long)ndir, sums);
+        hipLaunchKernelGGL(k_build_delmap<true>, grid, dim3(256), 0, ctx->stream, srt, org, nw, static_cast<uint32_t*>(ctx->w_delmap.p), dv_dir, dv_ent);
+        BDG_HIP_TRY(ctx, hipGetLastError());
     }
     BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->w_delins_ready = true;
