@@ -56,3 +56,18 @@ def test_product_path_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 # no import, include, link or dlopen of anything under oracle/ (comments may cite it)
                 assert not re.search(r"^\s*(from|import)\s+oracle|pyoracle|#include.*oracle|libbadger_oracle", src, re.M), f
+
+
+def test_no_sort_or_scan_library_in_the_product():
+    """Every kernel of the library is the repo's own: no source under csrc/ includes hipCUB / rocPRIM / thrust, and the built
+    library holds no rocprim symbol (round 3's radix sorts, run-length encode and scans are the bucket partition of
+    csrc/bdg_partition.hpp now)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "badger_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".hpp")):
+            src = open(os.path.join(csrc, f)).read()
+            assert not re.search(r"#include\s*<(hipcub|rocprim|thrust)/", src), f
+    so = os.path.join(ROOT, "badger_amd", "libbadger_hip.so")
+    names = subprocess.run(["nm", "-C", so], capture_output=True, text=True, check=True).stdout
+    assert "rocprim" not in names and "hipcub" not in names
