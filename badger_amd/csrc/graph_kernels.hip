@@ -18,7 +18,9 @@
 // that can have dmin <= 1 with it and looks them up in the sorted array (membership bitmap,
 // then a prefix directory); see graph_probe_candidate() below.
 //
-// k_graph_qjoin (thr >= 2): the device form of the reference's QGramIndex, see further down.
+// k_graph_qjoin_w (thr >= 3, cross-check at thr 2): the device form of the reference's QGramIndex, see further down.
+// k_d1_rows / k_d2_rows + k_part_* + k_d2_pairs_w (thr 1 from 100 K rows, thr 2 from 10 K): the deletion-variant joins, see
+// "Deletion-variant join" below.  No sort or scan library anywhere: every grouping is csrc/bdg_partition.hpp.
 #include "bdg_common.hpp"
 #include "bdg_partition.hpp"
 #include "dj_codec.hpp"
@@ -866,8 +868,9 @@ void k_graph_qjoin_w(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t ro
 // The edge set itself does not need that walk:  dmin(a,b) <= 2  implies that a and b share a 14-mer that is left when two
 // letters are deleted from each (two substitutions: delete the two positions; one insertion + one deletion: delete the
 // odd letter of each, then any common letter; the forms through a[:-1] / b[:-1] delete the last letter and one or two
-// more - a[:-1] minus one letter is a minus two).  So: every row emits its <= 120 distinct two-deletion 14-mers as
-// (14-mer, row), the entries are sorted by 14-mer, and only rows that meet in a group are
+// more - a[:-1] minus one letter is a minus two).  So: every row emits its <= 120 distinct two-deletion 14-mers as 32-bit
+// entries (dj_codec.hpp), the entries are GROUPED by 14-mer - two bucket levels through HBM, the rest in LDS
+// (bdg_partition.hpp, k_d2_pairs_w; round 3 sorted them) - and only rows that meet in a group are
 // verified - by the same dmin and the same S (in closed form) as everywhere else, so the filter stays the reference's.
 // A pair shares several 14-mers; it is reported from exactly one group, named by a rule that looks at the two barcodes only
 // (k_d2_pairs).  A row's entries are made distinct when they are emitted (of equal 14-mers the first deletion pair stays),
@@ -1050,9 +1053,6 @@ __device__ __forceinline__ int d2_reports(uint32_t a, uint32_t b, uint32_t k)
     return 0;                                                          // none of the relations holds: dmin(a, b) > 2, no edge
 }
 
-// One wave per 64 consecutive sorted entries.  Lane l's entry meets the L_l entries behind it in its group (same 14-mer);
-// the wave walks the sum of those meetings 64 at a time, whatever the group sizes are (a meeting's owner is found in the
-// running sums), so the verification always runs with full lanes.
 // thr 1: dmin(a, b) <= 1 means one substituted letter, or a without letter i == b without letter j (which covers the forms
 // through a[:-1] / b[:-1]); either way the two share the 15-mer that is left, and the narrowest (i, j) names one of them
 // (for a substitution at s: i = j = s).  1: k is that 15-mer; 0: it is not, or the pair is no edge at all.
