@@ -831,12 +831,25 @@ __device__ __forceinline__ uint32_t sw_block(uint32_t (&w)[NW], int ndw, int n, 
 
 // ---------------------------------------------------------------------------
 // Packed form of sw_block for the forward pass: TWO clusters per lane, one per 16-bit half, so that
-// the half-rate integer max/add run as v_pk_max_u16 / v_pk_add_u16 on two cells at once.
-// Cells hold G = (H + 1) << 11 as unsigned 16-bit: H - 1 is never negative in that form
-// (G - 2048 >= 0), nothing exceeds 25 << 11 < 65536, and the SSW key  G | (63-col) << 5 | (31-row)
-// needs no shift.  A key k of this form is the sw_block key plus 2048 (k = 0: no cell seen).
+// add / subtract / max run as packed 16-bit instructions on two cells at once.
+// Cells hold G = (H + 1) << 10 as unsigned 16-bit: H - 1 is never negative in that form (G - 1024 >= 0) and nothing
+// exceeds 25 << 10 = 0x6400.  Below 0x7C00 an unsigned 16-bit pattern is also a finite non-negative half float whose
+// order is the order of the integers, so the three-way maximum of a cell is ONE v_pk_maximum3_f16 (gfx950; kernels run
+// with 16-bit denormals kept, and every cell is a multiple of 0x0400, the smallest normal number, anyway) where integer
+// instructions need two v_pk_max_u16.  The SSW key  G << 11 | (63-col) << 5 | (31-row)  is put together per COLUMN: the
+// rows contribute G << 10 | (31-row) to a column maximum (again one three-way maximum per two rows), the column adds
+// its number and moves G up one bit.  A key k of this form is the sw_block key plus 2048 (k = 0: no cell seen).
+// Eight instructions per pair of cells in round 3's form, 6.5 here.
 // ---------------------------------------------------------------------------
+constexpr uint32_t code_plane(int bit)
+{
+    uint32_t m = 0;
+    for (int i = 0; i < R1_LEN; ++i) if ((icode(R1[i]) >> bit) & 1u) m |= 1u << i;
+    return m;
+}
+constexpr uint32_t R1_P0 = code_plane(0), R1_P1 = code_plane(1);
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)); }
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)); }
 __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b)      // v_pk_sub_u16 clamp: max(a - b, 0) per half
@@ -847,14 +860,39 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
+__device__ __forceinline__ uint32_t pk_max3_below_7c00(uint32_t a, uint32_t b, uint32_t c)      // v_pk_maximum3_f16; every half < 0x7C00
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(
+        __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)), __builtin_bit_cast(f16x2, c)));
+}
 
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+
+// The window of one cluster, made ready for sw_block2: the strand's complement folded into the bytes (ASCII bit 2 = bit 1
+// of the 2-bit code) and every place behind the window's end turned into 'N', which matches nothing.
+template <int NW>
+__device__ __forceinline__ void sw_window(uint32_t (&w)[NW], int n, uint32_t comp)
+{
+    const uint32_t flip = comp ? 0x04040404u : 0u;
+#pragma unroll
+    for (int d = 0; d < NW; ++d) {
+        const int left = n - 4 * d;
+        const uint32_t keep = left >= 4 ? 0xFFFFFFFFu : (left <= 0 ? 0u : (1u << (8 * left)) - 1u);
+        w[d] = ((w[d] ^ flip) & keep) | (0x4E4E4E4Eu & ~keep);
+    }
+}
+
+// win: the two windows (sw_window) of this lane in LDS, dword d of cluster A at win[d * 64], of cluster B at
+// win[(NW + d) * 64] (the loop takes one dword of each per four columns; held in registers the 2 x NW words had to be
+// moved down one place per round).  n1 / n2: the two window lengths whose running key is wanted, both clusters packed.
 template <int NW, bool WITH_N>
-__device__ __forceinline__ uint32_t sw_block2(uint32_t (&wa)[NW], uint32_t (&wb)[NW], int ndw,
-                                              int nA, int nB, uint32_t compA, uint32_t compB,
-                                              int n1A, int n2A, int n1B, int n2B,
+__device__ __forceinline__ uint32_t sw_block2(const uint32_t* win, int ndw, uint32_t n1, uint32_t n2,
                                               uint32_t& snap1, uint32_t& snap2)
 {
-    constexpr uint32_t ONE2 = 0x08000800u;       // 1 << 11 in both halves
+    constexpr uint32_t ONE2 = 0x04000400u;       // 1 << 10 in both halves
     // Cells are kept as G - 1 = H in offset form, floored at 0 by the saturating subtract: every consumer of a cell (the
     // cell to its right, below it, and diagonally below) needs exactly that, so one v_pk_sub_u16 clamp per cell replaces
     // two subtractions and the max with 0.  (An unfloored cell only ever reaches the running key with score <= 0, where
@@ -863,48 +901,60 @@ __device__ __forceinline__ uint32_t sw_block2(uint32_t (&wa)[NW], uint32_t (&wb)
 #pragma unroll
     for (int i = 0; i < R1_LEN; ++i) hm[i] = 0u;             // H = 0
     uint32_t acc = 0, s1 = 0, s2 = 0;
+    uint32_t curA = win[0], curB = win[NW * 64];
 #pragma nounroll
     for (int d = 0; d < ndw; ++d) {
-        const uint32_t curA = wa[0], curB = wb[0];
+        const int dn = d + 1 < NW ? d + 1 : d;
+        const uint32_t nextA = win[dn * 64], nextB = win[(NW + dn) * 64];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int j = d * 4 + b;
-            const uint32_t cA = (curA >> (8 * b)) & 0xFFu, cB = (curB >> (8 * b)) & 0xFFu;
-            const uint32_t kA = ((cA >> 1) & 3u) ^ (compA << 1), kB = ((cB >> 1) & 3u) ^ (compB << 1);
-            uint32_t eA = (kA & 2u) ? ((kA & 1u) ? EQ3 : EQ2) : ((kA & 1u) ? EQ1 : EQ0);
-            uint32_t eB = (kB & 2u) ? ((kB & 1u) ? EQ3 : EQ2) : ((kB & 1u) ? EQ1 : EQ0);
-            const bool liveA = j < nA, liveB = j < nB;
-            const bool isNA = WITH_N && cA == (uint32_t)'N', isNB = WITH_N && cB == (uint32_t)'N';
-            eA = (liveA && !isNA) ? eA : 0u;
-            eB = (liveB && !isNB) ? eB : 0u;
-            const uint32_t M0 = (eA & 0xFFFFu) | (eB << 16);                 // rows 0..15 of both
-            const uint32_t M1 = (eA >> 16) | ((eB >> 16) << 16);             // rows 16..21
-            const uint32_t dN = WITH_N ? (((isNA && liveA) ? 0x0800u : 0u) | ((isNB && liveB) ? 0x08000000u : 0u)) : 0u;
-            const uint32_t cj = (uint32_t)((63 - j) << 5) * 0x00010001u;
+            // Equality words (row i = bit i; bits 22.. hold anything, no row reads them) from the two bit planes of R1's codes
+            // and the base's code bits spread over the word; ASCII bit 3 = 'N' or behind the window: matches nothing.
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_sbfe((int)curA, 8 * b + 1, 1), a1 = (uint32_t)__builtin_amdgcn_sbfe((int)curA, 8 * b + 2, 1);
+            const uint32_t an = (uint32_t)__builtin_amdgcn_sbfe((int)curA, 8 * b + 3, 1);
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_sbfe((int)curB, 8 * b + 1, 1), b1 = (uint32_t)__builtin_amdgcn_sbfe((int)curB, 8 * b + 2, 1);
+            const uint32_t bn = (uint32_t)__builtin_amdgcn_sbfe((int)curB, 8 * b + 3, 1);
+            const uint32_t eA = __builtin_amdgcn_bitop3_b32(a0, R1_P0, __builtin_amdgcn_bitop3_b32(a1, R1_P1, an, 0xBE), 0x41);
+            const uint32_t eB = __builtin_amdgcn_bitop3_b32(b0, R1_P0, __builtin_amdgcn_bitop3_b32(b1, R1_P1, bn, 0xBE), 0x41);
+            const uint32_t M0 = __builtin_amdgcn_perm(eB, eA, 0x05040100u);  // rows 0..15 of both
+            const uint32_t M1 = __builtin_amdgcn_perm(eB, eA, 0x07060302u);  // rows 16..21 (and what lies above them)
+            // N scores 0.  Places behind a window's end are 'N' too: in the form without N they simply match nothing (-1, as
+            // before); here they score 0, which cannot lift a cell above the best one before them - and at equal score the
+            // earlier column wins.
+            const uint32_t dN = WITH_N ? ((an & 0x0400u) | (bn & 0x04000000u)) : 0u;
             uint32_t diag_t = 0u;        // (H(-1, j-1) - 1) in offset form
             uint32_t upm = 0u;           // (H(-1, j) - 1) likewise
+            uint32_t colkey = 0u, kprev = 0u;
 #pragma unroll
             for (int i = 0; i < R1_LEN; ++i) {
                 const uint32_t tl = hm[i];                                               // H(i, j-1) - 1
                 const uint32_t src = i < 16 ? M0 : M1;
                 const int bitpos = i < 16 ? i : i - 16;
-                const uint32_t X = (bitpos <= 12 ? (src << (12 - bitpos)) : (src >> (bitpos - 12))) & 0x10001000u;   // 2 if match
-                uint32_t dg = pk_add(diag_t, X);                                         // H(i-1,j-1) +/- 1
-                if (WITH_N) dg = pk_add(dg, dN);
-                const uint32_t g = pk_max(pk_max(dg, tl), upm);                          // max(diag, left-1, up-1); the floor comes next
+                const uint32_t sh = bitpos <= 11 ? (src << (11 - bitpos)) : (src >> (bitpos - 11));
+                const uint32_t X = WITH_N ? ((sh & 0x08000800u) | dN) : (sh & 0x08000800u);      // +2 on a match (one v_and_or with N)
+                const uint32_t dg = pk_add(diag_t, X);                                   // H(i-1,j-1) +/- 1
+                const uint32_t g = pk_max3_below_7c00(dg, tl, upm);                      // max(diag, left-1, up-1); the floor comes next
                 const uint32_t gm = pk_sub_sat(g, ONE2);                                 // max(H, 0) - 1 in offset form
                 diag_t = tl;
                 hm[i] = gm;
                 upm = gm;
-                acc = pk_max(acc, __builtin_amdgcn_bitop3_b32(g, cj, (uint32_t)(31 - i) * 0x00010001u, 0xFE));      // g | cj | row: one v_bitop3
+                const uint32_t k = g | ((uint32_t)(31 - i) * 0x00010001u);
+                if (i & 1) colkey = pk_max3_below_7c00(colkey, kprev, k);
+                else kprev = k;
             }
-            const uint32_t m1 = ((j + 1 == n1A) ? 0xFFFFu : 0u) | ((j + 1 == n1B) ? 0xFFFF0000u : 0u);
-            const uint32_t m2 = ((j + 1 == n2A) ? 0xFFFFu : 0u) | ((j + 1 == n2B) ? 0xFFFF0000u : 0u);
+            // the column's best cell as an SSW key: G up one bit, the column number in between
+            const uint32_t cj = (uint32_t)((63 - j) << 5) * 0x00010001u;
+            const uint32_t key = ((colkey & 0x7C007C00u) << 1) | (colkey & 0x001F001Fu) | cj;
+            acc = pk_max(acc, key);
+            // the running key after column n1 - 1 / n2 - 1: all ones in the half whose length is j + 1
+            const uint32_t jj = (uint32_t)(j + 1) * 0x00010001u;
+            const uint32_t m1 = pk_sub(pk_min(n1 ^ jj, 0x00010001u), 0x00010001u);
+            const uint32_t m2 = pk_sub(pk_min(n2 ^ jj, 0x00010001u), 0x00010001u);
             s1 = (acc & m1) | (s1 & ~m1);
             s2 = (acc & m2) | (s2 & ~m2);
         }
-#pragma unroll
-        for (int i = 0; i < NW - 1; ++i) { wa[i] = wa[i + 1]; wb[i] = wb[i + 1]; }
+        curA = nextA; curB = nextB;
     }
     snap1 = s1; snap2 = s2;
     return acc;
@@ -931,13 +981,6 @@ __device__ __forceinline__ uint64_t make_key(uint32_t acc, uint32_t pos)
 // occurs in the window with semi-global edit distance <= 5.  Myers' 22-bit search decides that
 // at about a tenth of the cost of the alignment; only surviving hits join queue A.
 // ---------------------------------------------------------------------------
-constexpr uint32_t code_plane(int bit)
-{
-    uint32_t m = 0;
-    for (int i = 0; i < R1_LEN; ++i) if ((icode(R1[i]) >> bit) & 1u) m |= 1u << i;
-    return m;
-}
-constexpr uint32_t R1_P0 = code_plane(0), R1_P1 = code_plane(1);
 
 __device__ __forceinline__ uint32_t myers_search(uint32_t (&w)[10], int n, uint32_t comp)
 {
@@ -1131,6 +1174,7 @@ void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                    unsigned long long* __restrict__ keys)
 {
     __shared__ uint2 s_out[4][REQ_CAP];
+    __shared__ uint32_t s_win[4][2 * CW][64];    // the two windows of every lane (sw_block2)
     __shared__ uint32_t s_cnt[NSH];
     const uint64_t nq = queue_counts(counters, kind, 0, seg, s_cnt);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1146,9 +1190,17 @@ void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         load_block<CW>(bases, total_rounded, jb.rs, jb.L, (int)jb.strand, jb.ws, +1, wb);
         const bool anyN = __ballot((ja.active && block_has_N<CW>(wa)) || (jb.active && block_has_N<CW>(wb))) != 0;
         const int ndw = (wave_max(ja.n_u > jb.n_u ? ja.n_u : jb.n_u) + 3) >> 2;
+        sw_window<CW>(wa, ja.n_u, ja.strand);
+        sw_window<CW>(wb, jb.n_u, jb.strand);
+        uint32_t* const win = &s_win[wv][0][lane];
+#pragma unroll
+        for (int d = 0; d < CW; ++d) { win[d * 64] = wa[d]; win[(CW + d) * 64] = wb[d]; }
+        __builtin_amdgcn_wave_barrier();
         uint32_t sn_s = 0, sn_r = 0;
-        const uint32_t acc = anyN ? sw_block2<CW, true>(wa, wb, ndw, ja.n_u, jb.n_u, ja.strand, jb.strand, ja.n_s, ja.n_r, jb.n_s, jb.n_r, sn_s, sn_r)
-                                  : sw_block2<CW, false>(wa, wb, ndw, ja.n_u, jb.n_u, ja.strand, jb.strand, ja.n_s, ja.n_r, jb.n_s, jb.n_r, sn_s, sn_r);
+        const uint32_t n_s2 = (uint32_t)ja.n_s | ((uint32_t)jb.n_s << 16), n_r2 = (uint32_t)ja.n_r | ((uint32_t)jb.n_r << 16);
+        const uint32_t acc = anyN ? sw_block2<CW, true>(win, ndw, n_s2, n_r2, sn_s, sn_r)
+                                  : sw_block2<CW, false>(win, ndw, n_s2, n_r2, sn_s, sn_r);
+        __builtin_amdgcn_wave_barrier();
         nwin += (ja.active ? 1u : 0u) + (jb.active ? 1u : 0u);
         uint32_t rest_a = finish_job(ja, unpk(sn_s, 0), unpk(sn_r, 0), unpk(acc, 0), n_reads, keys);
         uint32_t rest_b = finish_job(jb, unpk(sn_s, 1), unpk(sn_r, 1), unpk(acc, 1), n_reads, keys);
