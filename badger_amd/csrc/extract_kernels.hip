@@ -866,6 +866,12 @@ __device__ __forceinline__ uint32_t pk_max3_below_7c00(uint32_t a, uint32_t b, u
         __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)), __builtin_bit_cast(f16x2, c)));
 }
 
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)      // a * b + c per half, b the same in every lane
+{
+    uint32_t r;             // (written out: the compiler turns a multiplication by a power of two into a shift and an addition)
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
@@ -919,6 +925,7 @@ __device__ __forceinline__ uint32_t sw_block2(const uint32_t* win, int ndw, uint
             const uint32_t eB = __builtin_amdgcn_bitop3_b32(b0, R1_P0, __builtin_amdgcn_bitop3_b32(b1, R1_P1, bn, 0xBE), 0x41);
             const uint32_t M0 = __builtin_amdgcn_perm(eB, eA, 0x05040100u);  // rows 0..15 of both
             const uint32_t M1 = __builtin_amdgcn_perm(eB, eA, 0x07060302u);  // rows 16..21 (and what lies above them)
+            const uint32_t M2 = M0 >> 4;                                     // rows 12..15 at bits 8..11 of both halves
             // N scores 0.  Places behind a window's end are 'N' too: in the form without N they simply match nothing (-1, as
             // before); here they score 0, which cannot lift a cell above the best one before them - and at equal score the
             // earlier column wins.
@@ -929,11 +936,12 @@ __device__ __forceinline__ uint32_t sw_block2(const uint32_t* win, int ndw, uint
 #pragma unroll
             for (int i = 0; i < R1_LEN; ++i) {
                 const uint32_t tl = hm[i];                                               // H(i, j-1) - 1
-                const uint32_t src = i < 16 ? M0 : M1;
-                const int bitpos = i < 16 ? i : i - 16;
-                const uint32_t sh = bitpos <= 11 ? (src << (11 - bitpos)) : (src >> (bitpos - 11));
-                const uint32_t X = WITH_N ? ((sh & 0x08000800u) | dN) : (sh & 0x08000800u);      // +2 on a match (one v_and_or with N)
-                const uint32_t dg = pk_add(diag_t, X);                                   // H(i-1,j-1) +/- 1
+                // The row's match bit stays where it is in its word (bit p <= 11 of both halves) and is scaled to +2 by
+                // the multiplier of a packed multiply-add: one AND and one v_pk_mad_u16 where shift, AND and add were three.
+                const uint32_t src = i < 12 ? M0 : (i < 16 ? M2 : M1);
+                const int p = i < 12 ? i : (i < 16 ? i - 4 : i - 16);
+                uint32_t dg = pk_mad(src & (0x00010001u << p), 0x00010001u << (11 - p), diag_t);      // H(i-1,j-1) +/- 1
+                if (WITH_N) dg = pk_add(dg, dN);
                 const uint32_t g = pk_max3_below_7c00(dg, tl, upm);                      // max(diag, left-1, up-1); the floor comes next
                 const uint32_t gm = pk_sub_sat(g, ONE2);                                 // max(H, 0) - 1 in offset form
                 diag_t = tl;
