@@ -83,8 +83,33 @@ void bdg_timer_end(bdg_ctx* ctx, int id)
     ctx->timers[id].launches++;
 }
 
+int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, int, uint32_t, uint32_t, uint32_t*, uint8_t*, uint16_t*);
+
+int bdg_launch_deferred_match(bdg_ctx* ctx, bool behind_scan)
+{
+    if (!ctx->deferred.pending) return BDG_OK;
+    const bdg_ctx::DeferredMatch d = ctx->deferred;
+    ctx->deferred.pending = false;
+    // behind the extraction that wrote the records (ev_main, recorded when the match was asked for) and, when the next
+    // extraction has begun, behind its scan
+    BDG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_main, 0));
+    if (behind_scan) {
+        BDG_HIP_TRY(ctx, hipEventRecord(ctx->ev_scan, ctx->stream));
+        BDG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_scan, 0));
+    }
+    ctx->launch_stream = ctx->aux_stream;
+    ctx->aux_pending = true;
+    const int rc = bdg_nearest16_launch(ctx, d.q, 8u, 1, d.n, d.max_ed, d.idx, d.ed, d.ties);
+    ctx->launch_stream = nullptr;
+    BDG_HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[ctx->aux_count & 1], ctx->aux_stream));
+    ctx->aux_count++;
+    return rc;
+}
+
 static int sync_all(bdg_ctx* ctx)
 {
+    const int rcd = bdg_launch_deferred_match(ctx, false);
+    if (rcd) return rcd;
     BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->aux_pending) { BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream)); ctx->aux_pending = false; }
     return BDG_OK;
@@ -229,6 +254,7 @@ void bdg_free(bdg_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
+    if (ctx->ev_scan) (void)hipEventDestroy(ctx->ev_scan);
     for (hipEvent_t e : ctx->ev_aux) if (e) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &ctx->x_lut, &ctx->x_polyt, &ctx->x_keys, &ctx->x_hits, &ctx->x_counters, &ctx->s_in0,
                        &ctx->s_in1, &ctx->s_out0, &ctx->w_sorted, &ctx->w_orig, &ctx->w_prefix, &ctx->w_bitmap, &ctx->w_pent, &ctx->w_delmap, &ctx->w_dv,
@@ -271,8 +297,10 @@ int bdg_set_overlap(bdg_ctx* ctx, int on)
     if (rc) return rc;
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (on && !ctx->aux_stream) {
+        // (same priority as the main stream: measured against the lowest and the highest one, tools/ov_prio_probe.sh)
         BDG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
         BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_scan, hipEventDisableTiming));
         BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[0], hipEventDisableTiming));
         BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[1], hipEventDisableTiming));
     }
@@ -323,7 +351,9 @@ int bdg_extract_batch_dev(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* 
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // overlap mode: the caller alternates between two record buffers, so this extraction may overwrite what the match before
     // the last one read: stay at most one match ahead
-    if (ctx->overlap && ctx->aux_count >= 2) BDG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[ctx->aux_count & 1], 0));
+    // (the match of the batch before this one is still waiting - it goes behind this extraction's scan; the one before it is
+    // the last one queued)
+    if (ctx->overlap && ctx->aux_count >= 1) BDG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[(ctx->aux_count - 1) & 1], 0));
     return bdg_extract_launch(ctx, d_bases, d_off, n, total_bytes, umi_len, d_out);
 }
 
@@ -608,19 +638,18 @@ int bdg_nearest16_recs_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t
                   "record layout the strided query reads");
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->overlap) {
-        // behind everything queued on the main stream so far (the extraction that wrote d_recs), beside whatever comes next
+        // not queued yet: it goes behind the next extraction's scan (or behind everything queued so far, at the next
+        // synchronisation, whitelist change or match)
+        int rc = bdg_launch_deferred_match(ctx, false);
+        if (rc) return rc;
+        if (ctx->w_n == 0) return bdg_fail(ctx, BDG_E_ARG, "no whitelist loaded (bdg_whitelist_load)");
         BDG_HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
-        BDG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_main, 0));
-        ctx->launch_stream = ctx->aux_stream;
-        ctx->aux_pending = true;
+        ctx->deferred.pending = true;
+        ctx->deferred.q = reinterpret_cast<const uint32_t*>(d_recs) + 5; ctx->deferred.n = n; ctx->deferred.max_ed = max_ed;
+        ctx->deferred.idx = d_best_idx; ctx->deferred.ed = d_best_ed; ctx->deferred.ties = d_n_ties;
+        return BDG_OK;
     }
-    const int rc = bdg_nearest16_launch(ctx, reinterpret_cast<const uint32_t*>(d_recs) + 5, 8u, 1, n, max_ed, d_best_idx, d_best_ed, d_n_ties);
-    ctx->launch_stream = nullptr;
-    if (ctx->overlap) {
-        BDG_HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[ctx->aux_count & 1], ctx->aux_stream));
-        ctx->aux_count++;
-    }
-    return rc;
+    return bdg_nearest16_launch(ctx, reinterpret_cast<const uint32_t*>(d_recs) + 5, 8u, 1, n, max_ed, d_best_idx, d_best_ed, d_n_ties);
 }
 
 int bdg_nearest16(bdg_ctx* ctx, const uint32_t* q, uint32_t nq, const uint32_t* wl, uint32_t nw,

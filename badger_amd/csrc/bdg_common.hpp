@@ -35,6 +35,12 @@ struct bdg_ctx {
     hipEvent_t ev_main = nullptr, ev_aux[2] = { nullptr, nullptr };
     uint64_t aux_count = 0;                 // matches queued on aux_stream so far
     bool overlap = false, aux_pending = false;
+    // The match is not queued when it is asked for but behind the NEXT extraction's scan (bdg_launch_deferred_match): beside
+    // the scan (which streams the reads at the memory's rate) its gathers cost more than they hide, beside the alignment
+    // kernels that follow (integer issue, almost no memory traffic) they are nearly free.
+    struct DeferredMatch { bool pending = false; const uint32_t* q = nullptr; uint32_t n = 0, max_ed = 0;
+                           uint32_t* idx = nullptr; uint8_t* ed = nullptr; uint16_t* ties = nullptr; } deferred;
+    hipEvent_t ev_scan = nullptr;
     hipStream_t launch_stream = nullptr;    // where kernels (and their timing events) currently go: stream, or aux_stream
     std::string err;
     bool profiling = false;
@@ -112,6 +118,7 @@ struct bdg_ctx {
 
 // Grow-only device buffer.
 int bdg_reserve(bdg_ctx* ctx, DevBuf& b, size_t bytes);
+int bdg_launch_deferred_match(bdg_ctx* ctx, bool behind_scan);   // overlap mode: queue the waiting whitelist match now (bdg_abi.cpp)
 
 // Event-bracketed launch bookkeeping.
 int  bdg_timer_id(bdg_ctx* ctx, const char* name);

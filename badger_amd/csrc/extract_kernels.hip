@@ -1491,6 +1491,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
                            static_cast<const uint8_t*>(ctx->x_lut.p), static_cast<int32_t*>(ctx->x_polyt.p),
                            qa, qb, qcap, counters, keys);
     }
+    if (ctx->deferred.pending && (rc = bdg_launch_deferred_match(ctx, true))) return rc;      // overlap mode: the match of the batch before
     {
         ScopedKernelTimer tm(ctx, "k_sw_clusters");
         hipLaunchKernelGGL(k_sw_clusters, dim3(256 * 8), dim3(256), 0, st, d_bases, total_rounded, d_off, n, pt,

@@ -441,6 +441,7 @@ int bdg_whitelist_load_impl(bdg_ctx* ctx, const uint32_t* wl, uint32_t nw)
         if (same) return BDG_OK;
     }
     // nothing is published until every table of the new list is complete: a failure below leaves "no whitelist loaded"
+    { const int rcd = bdg_launch_deferred_match(ctx, false); if (rcd) return rcd; }      // a match that waits meant the old list
     if (ctx->aux_pending) { BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream)); ctx->aux_pending = false; }
     ctx->w_n = 0; ctx->w_fp = 0; ctx->w_probe_ready = false; ctx->w_delins_ready = false;
     if (nw == 0) return BDG_OK;

@@ -63,12 +63,18 @@ def all_sum(value, device=None):
     return float(t[0])
 
 
-def timed(step, steps, device=None):
-    """K calls of step() bracketed by barrier + synchronize; returns max-over-ranks seconds."""
+def timed(step, steps, device=None, settle=None):
+    """K calls of step() bracketed by barrier + synchronize; returns max-over-ranks seconds.  settle: called before the
+    clock starts and again behind the last step, inside the timed region - for work a step may leave waiting (the
+    library's batch pipelining queues a batch's whitelist match only when the next batch begins)."""
+    if settle is not None:
+        settle()
     barrier(device)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if settle is not None:
+        settle()
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0

@@ -144,3 +144,15 @@ def test_hashed_group_shares_balance_the_deletion_variant_join():
         pairs = np.bincount(part.astype(np.int64), weights=size * (size - 1) / 2, minlength=world)
         assert entries.max() / entries.sum() * world < 1.03 and entries.min() / entries.sum() * world > 0.97
         assert pairs.max() / pairs.sum() * world < 1.03 and pairs.min() / pairs.sum() * world > 0.97
+
+
+def test_timed_settles_waiting_work_inside_the_clock():
+    """bench.py's batch pipelining leaves a step's whitelist match waiting until the next step begins: the clock must not
+    start with one waiting from the warm-up, and must not stop before the last step's has been queued and finished."""
+    from badger_amd import dist as bdist
+    log = []
+    t = bdist.timed(lambda: log.append("step"), 3, None, settle=lambda: log.append("settle"))
+    assert log == ["settle", "step", "step", "step", "settle"] and t >= 0.0
+    log.clear()
+    bdist.timed(lambda: log.append("step"), 2, None)
+    assert log == ["step", "step"]
