@@ -223,7 +223,8 @@ class Context:
         self._check(self.lib.bdg_synchronize(self.h))
 
     def set_overlap(self, on=True):
-        """nearest16_recs_dev on an auxiliary stream: the match of batch i overlaps the extraction of batch i + 1"""
+        """nearest16_recs_dev on an auxiliary stream: the match of batch i is queued behind the scan of batch i + 1 and runs
+        beside its alignment kernels; results are complete after synchronize() (which also queues a match still waiting)"""
         self._check(self.lib.bdg_set_overlap(self.h, 1 if on else 0))
 
     def profile(self, on=True):

@@ -30,7 +30,7 @@ struct bdg_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // bdg_set_overlap: the whitelist match of a batch's records runs on aux_stream, ordered behind the extraction that wrote
-    // them, so that it overlaps the extraction of the NEXT batch on `stream`
+    // them, so that it overlaps the extraction of the NEXT batch on `stream` (its alignment kernels: see DeferredMatch)
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_aux[2] = { nullptr, nullptr };
     uint64_t aux_count = 0;                 // matches queued on aux_stream so far

@@ -115,12 +115,14 @@ int  bdg_mem_from_host(bdg_ctx* ctx, void* d_dst, const void* src, uint64_t byte
  * Lets the caller order the library's kernels with its own work and time with its own events. */
 int  bdg_set_stream(bdg_ctx* ctx, void* hip_stream);
 int  bdg_synchronize(bdg_ctx* ctx);            /* waits for everything the context has queued (both streams, see below) */
-/* Batch pipelining.  With overlap on, bdg_nearest16_recs_dev runs on an auxiliary stream of the context: ordered behind
- * everything queued so far on the main stream (the extraction that wrote d_recs), but beside what is queued afterwards -
- * the whitelist match of batch i (latency-bound gathers) then overlaps the extraction of batch i + 1 (integer-issue bound).
- * The caller alternates between two record / result buffers (bdg_extract_batch_dev waits for the match before the last
- * one, so the extraction never runs more than one match ahead); results of a match are complete after
- * bdg_synchronize() (or a device-wide synchronisation), not merely in main-stream order. */
+/* Batch pipelining.  With overlap on, bdg_nearest16_recs_dev runs on an auxiliary stream of the context, ordered behind the
+ * extraction that wrote d_recs - and it is not queued at once: it waits for the NEXT bdg_extract_batch_dev, which queues it
+ * behind its own scan kernel, so that the whitelist match of batch i (gathers) runs beside the alignment kernels of batch
+ * i + 1 (integer issue, hardly any memory traffic) and not beside the scan, which streams the reads at the memory's rate
+ * and loses more to the gathers than they gain.  A match still waiting is queued by bdg_synchronize(), by the next match,
+ * and before the whitelist changes.  The caller alternates between two record / result buffers (an extraction waits for
+ * the match queued last, i.e. it never overwrites records a match has yet to read); results of a match are complete
+ * after bdg_synchronize() - not after a device-wide synchronisation alone, which does not know about a waiting match. */
 int  bdg_set_overlap(bdg_ctx* ctx, int on);
 int  bdg_profile_enable(bdg_ctx* ctx, int on);
 /* Time only the kernel of this name (NULL or "": every kernel again).  A pair of events around a kernel costs a few

@@ -25,11 +25,11 @@ def scan_isa(tmp_path_factory):
     m = re.search(r"^(_ZN\S*k_scan_reads\S*):[^\n]*\n(.*?)\n\s*\.amdhsa_kernel \1\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
     assert m, "k_scan_reads not found in the generated code"
     meta = dict(re.findall(r"\.set \S*k_scan_reads\S*\.(num_vgpr|private_seg_size|numbered_sgpr), (\d+)", text))
-    return m.group(2).split("\n"), m.group(3), meta
+    return m.group(2).split("\n"), m.group(3), meta, text
 
 
 def test_m0_is_written_only_for_the_lds_dma(scan_isa):
-    body, _, _ = scan_isa
+    body, _, _, _ = scan_isa
     code = [l.strip() for l in body if l.strip() and not l.strip().startswith(";")]
     uses = [i for i, l in enumerate(code) if re.search(r"\bm0\b", l)]
     dmas = [i for i, l in enumerate(code) if l.startswith("global_load_lds_dwordx4")]
@@ -43,11 +43,28 @@ def test_m0_is_written_only_for_the_lds_dma(scan_isa):
 
 
 def test_scan_kernel_budget(scan_isa):
-    _, desc, meta = scan_isa
+    _, desc, meta, _ = scan_isa
     assert int(meta["private_seg_size"]) == 0, "k_scan_reads spills"
     assert int(meta["num_vgpr"]) <= 128, "more than 128 registers: fewer than 4 waves per SIMD"
     lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", desc).group(1))
     assert 2 * lds <= 160 * 1024, "two blocks no longer fit a CU's LDS"
+
+
+def test_alignment_kernel_budget(scan_isa):
+    """k_sw_clusters (round 4): the three-way maximum of a cell is the packed half-float instruction, the match bonus a packed
+    multiply-add, the windows live in LDS - 96 registers where the integer form with the windows in registers took 240.
+    Four blocks of four waves per CU is what the launch assumes."""
+    text = scan_isa[3]
+    m = re.search(r"^(_ZN\S*k_sw_clusters\S*):[^\n]*\n(.*?)\n\s*\.amdhsa_kernel \1\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
+    assert m, "k_sw_clusters not found in the generated code"
+    body, desc = m.group(2), m.group(3)
+    meta = dict(re.findall(r"\.set \S*k_sw_clusters\S*\.(num_vgpr|private_seg_size), (\d+)", text))
+    assert int(meta["private_seg_size"]) == 0, "k_sw_clusters spills"
+    assert int(meta["num_vgpr"]) <= 128, "more than 128 registers: fewer than 4 waves per SIMD"
+    lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", desc).group(1))
+    assert 4 * lds <= 160 * 1024, "four blocks no longer fit a CU's LDS"
+    assert body.count("v_pk_maximum3_f16") >= 2 * 33 * 4, "the three-way maxima are not single instructions any more"
+    assert body.count("v_pk_mad_u16") >= 2 * 22 * 4, "the match bonus is not a multiply-add any more"
 
 
 def test_deletion_variant_join_kernels_budget(tmp_path):
