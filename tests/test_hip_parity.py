@@ -235,6 +235,37 @@ def test_overlap_mode_gives_the_same_calls(orc):
         assert (recs[k % 2][:n].cpu().numpy() == want[0]).all() and (bi[k % 2][:n].cpu().numpy() == want[1]).all()
         assert (be[k % 2][:n].cpu().numpy() == want[2]).all() and (bt[k % 2][:n].cpu().numpy() == want[3]).all()
     c.close()
+    # A match is only noted when it is asked for (it is queued behind the NEXT extraction's scan).  Whatever ends the wait
+    # must give the same answers: a synchronisation with no extraction behind the match, a second match on the other buffer
+    # (queues the first), and a whitelist change (the waiting match meant the OLD list and must run against it).
+    c = _native.Context(0)
+    c.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    c.whitelist_load(wl)
+    c.set_overlap(True)
+    (b0, o0, n0, t0), (b1, o1, n1, t1) = batches[0], batches[1]
+    c.extract_batch_dev(b0, o0, n0, t0, 12, recs[0])
+    c.nearest16_recs_dev(recs[0], n0, 2, bi[0], be[0], bt[0])
+    c.synchronize()                              # nothing behind the match
+    assert (bi[0][:n0].cpu().numpy() == results[False][0][1]).all() and (bt[0][:n0].cpu().numpy() == results[False][0][3]).all()
+    c.extract_batch_dev(b1, o1, n1, t1, 12, recs[1])
+    c.nearest16_recs_dev(recs[1], n1, 2, bi[1], be[1], bt[1])
+    bi[0].zero_(); be[0].zero_(); bt[0].zero_()
+    c.nearest16_recs_dev(recs[0], n0, 2, bi[0], be[0], bt[0])      # a second match: the first is queued now, this one waits
+    other = synth.make_whitelist(3000, seed=77)
+    c.whitelist_load(other)                      # ... until the list changes: it meant `wl`
+    c.synchronize()
+    for k in (0, 1):
+        n = batches[k][2]
+        assert (bi[k][:n].cpu().numpy() == results[False][k][1]).all() and (be[k][:n].cpu().numpy() == results[False][k][2]).all()
+        assert (bt[k][:n].cpu().numpy() == results[False][k][3]).all()
+    c.nearest16_recs_dev(recs[0], n0, 2, bi[0], be[0], bt[0])      # and the new list answers afterwards
+    c.synchronize()
+    got = bi[0][:n0].cpu().numpy().copy()
+    c.set_overlap(False)
+    c.nearest16_recs_dev(recs[0], n0, 2, bi[1], be[1], bt[1])
+    c.synchronize()
+    assert (got == bi[1][:n0].cpu().numpy()).all() and not (got == results[False][0][1]).all()
+    c.close()
 
 
 def test_extract_queue_overflow_is_contained_and_recovered(orc):
