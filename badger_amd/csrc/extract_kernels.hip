@@ -894,8 +894,12 @@ __device__ __forceinline__ void sw_window(uint32_t (&w)[NW], int n, uint32_t com
 // win: the two windows (sw_window) of this lane in LDS, dword d of cluster A at win[d * 64], of cluster B at
 // win[(NW + d) * 64] (the loop takes one dword of each per four columns; held in registers the 2 x NW words had to be
 // moved down one place per round).  n1 / n2: the two window lengths whose running key is wanted, both clusters packed.
-template <int NW, bool WITH_N>
+// SINGLE: one alignment a lane (the low halves; the high halves see a window of 'N').  P0 / P1: the bit planes of the rows'
+// codes (R1_P0 / R1_P1, or a lane's own: the reverse pass of k_finalize_reads aligns R1[end_read .. 0]), rowmask: the rows
+// that exist.
+template <int NW, bool WITH_N, bool SINGLE>
 __device__ __forceinline__ uint32_t sw_block2(const uint32_t* win, int ndw, uint32_t n1, uint32_t n2,
+                                              uint32_t P0, uint32_t P1, uint32_t rowmask,
                                               uint32_t& snap1, uint32_t& snap2)
 {
     constexpr uint32_t ONE2 = 0x04000400u;       // 1 << 10 in both halves
@@ -907,11 +911,11 @@ __device__ __forceinline__ uint32_t sw_block2(const uint32_t* win, int ndw, uint
 #pragma unroll
     for (int i = 0; i < R1_LEN; ++i) hm[i] = 0u;             // H = 0
     uint32_t acc = 0, s1 = 0, s2 = 0;
-    uint32_t curA = win[0], curB = win[NW * 64];
+    uint32_t curA = win[0], curB = SINGLE ? 0x4E4E4E4Eu : win[NW * 64];
 #pragma nounroll
     for (int d = 0; d < ndw; ++d) {
         const int dn = d + 1 < NW ? d + 1 : d;
-        const uint32_t nextA = win[dn * 64], nextB = win[(NW + dn) * 64];
+        const uint32_t nextA = win[dn * 64], nextB = SINGLE ? 0x4E4E4E4Eu : win[(NW + dn) * 64];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int j = d * 4 + b;
@@ -921,8 +925,8 @@ __device__ __forceinline__ uint32_t sw_block2(const uint32_t* win, int ndw, uint
             const uint32_t an = (uint32_t)__builtin_amdgcn_sbfe((int)curA, 8 * b + 3, 1);
             const uint32_t b0 = (uint32_t)__builtin_amdgcn_sbfe((int)curB, 8 * b + 1, 1), b1 = (uint32_t)__builtin_amdgcn_sbfe((int)curB, 8 * b + 2, 1);
             const uint32_t bn = (uint32_t)__builtin_amdgcn_sbfe((int)curB, 8 * b + 3, 1);
-            const uint32_t eA = __builtin_amdgcn_bitop3_b32(a0, R1_P0, __builtin_amdgcn_bitop3_b32(a1, R1_P1, an, 0xBE), 0x41);
-            const uint32_t eB = __builtin_amdgcn_bitop3_b32(b0, R1_P0, __builtin_amdgcn_bitop3_b32(b1, R1_P1, bn, 0xBE), 0x41);
+            const uint32_t eA = __builtin_amdgcn_bitop3_b32(a0, P0, __builtin_amdgcn_bitop3_b32(a1, P1, an, 0xBE), 0x41) & rowmask;
+            const uint32_t eB = SINGLE ? 0u : __builtin_amdgcn_bitop3_b32(b0, P0, __builtin_amdgcn_bitop3_b32(b1, P1, bn, 0xBE), 0x41);
             const uint32_t M0 = __builtin_amdgcn_perm(eB, eA, 0x05040100u);  // rows 0..15 of both
             const uint32_t M1 = __builtin_amdgcn_perm(eB, eA, 0x07060302u);  // rows 16..21 (and what lies above them)
             const uint32_t M2 = M0 >> 4;                                     // rows 12..15 at bits 8..11 of both halves
@@ -1206,8 +1210,8 @@ void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         __builtin_amdgcn_wave_barrier();
         uint32_t sn_s = 0, sn_r = 0;
         const uint32_t n_s2 = (uint32_t)ja.n_s | ((uint32_t)jb.n_s << 16), n_r2 = (uint32_t)ja.n_r | ((uint32_t)jb.n_r << 16);
-        const uint32_t acc = anyN ? sw_block2<CW, true>(win, ndw, n_s2, n_r2, sn_s, sn_r)
-                                  : sw_block2<CW, false>(win, ndw, n_s2, n_r2, sn_s, sn_r);
+        const uint32_t acc = anyN ? sw_block2<CW, true, false>(win, ndw, n_s2, n_r2, R1_P0, R1_P1, 0xFFFFFFFFu, sn_s, sn_r)
+                                  : sw_block2<CW, false, false>(win, ndw, n_s2, n_r2, R1_P0, R1_P1, 0xFFFFFFFFu, sn_s, sn_r);
         __builtin_amdgcn_wave_barrier();
         nwin += (ja.active ? 1u : 0u) + (jb.active ? 1u : 0u);
         uint32_t rest_a = finish_job(ja, unpk(sn_s, 0), unpk(sn_r, 0), unpk(acc, 0), n_reads, keys);
@@ -1268,9 +1272,9 @@ __device__ __forceinline__ uint32_t strand_byte(const uint8_t* __restrict__ rd, 
 
 struct StrandRes { int32_t valid, polyT, r1, score, bc_start, umi_start, umi_end; uint32_t bc[4]; /* 16 barcode characters, strand order, forward bytes */ };
 
-__device__ StrandRes finalize_strand(const uint8_t* __restrict__ bases, uint64_t total_rounded,
+__device__ __forceinline__ StrandRes finalize_strand(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                                      uint64_t rs, int64_t L, int strand, int32_t pt,
-                                     uint64_t kr, uint64_t ks, int umi_len, bool active)
+                                     uint64_t kr, uint64_t ks, int umi_len, bool active, uint32_t* win /* LDS: this lane's window words, 64 apart */)
 {
     StrandRes res = { 0, pt, -1, 0, -1, -1, -1, { 0, 0, 0, 0 } };
     bool found = false;
@@ -1292,15 +1296,25 @@ __device__ StrandRes finalize_strand(const uint8_t* __restrict__ bases, uint64_t
         need_rev = (R1_LEN - end_read_s - 1) <= 1;             // common.py:110-111
     }
     if (__ballot(need_rev)) {
+        // SSW's reverse pass: R1[end_read .. 0] against the read walked backwards from the end cell - the packed kernel of
+        // k_sw_clusters with one alignment a lane, the rows' bit planes reversed and shifted per lane (row r = R1[end_read - r])
         uint32_t w[10];
         load_block<10>(bases, total_rounded, rs, L, strand, ws_s + end_ref_s, -1, w);
         const bool anyN = __ballot(need_rev && block_has_N<10>(w)) != 0;
         const int ncol = need_rev ? end_ref_s + 1 : 0;
+        sw_window<10>(w, ncol, (uint32_t)strand);
+#pragma unroll
+        for (int d = 0; d < 10; ++d) win[d * 64] = w[d];
+        __builtin_amdgcn_wave_barrier();
+        const int ndw = (wave_max(ncol) + 3) >> 2;
+        const uint32_t p0r = __brev(R1_P0) >> (31 - end_read_s), p1r = __brev(R1_P1) >> (31 - end_read_s);
+        const uint32_t rows = (2u << end_read_s) - 1u;
         uint32_t sn1, sn2;
-        const uint32_t acc = anyN ? sw_block<10, true, true>(w, 10, ncol, (uint32_t)strand, end_read_s, 0, 0, sn1, sn2)
-                                  : sw_block<10, false, true>(w, 10, ncol, (uint32_t)strand, end_read_s, 0, 0, sn1, sn2);
+        const uint32_t acc = anyN ? sw_block2<10, true, true>(win, ndw, 0u, 0u, p0r, p1r, rows, sn1, sn2)
+                                  : sw_block2<10, false, true>(win, ndw, 0u, 0u, p0r, p1r, rows, sn1, sn2);
+        __builtin_amdgcn_wave_barrier();
         if (need_rev) {
-            const int rr = 31 - (int)(acc & 31u);
+            const int rr = 31 - (int)(unpk(acc, 0) & 31u);             // (the pass always finds the forward score again: the key is never 0)
             const int read_begin = end_read_s - rr;
             if (read_begin <= 1) {                             // common.py:108-109
                 found = true;
@@ -1343,7 +1357,7 @@ __device__ StrandRes finalize_strand(const uint8_t* __restrict__ bases, uint64_t
 }
 
 __global__ __launch_bounds__(256)
-void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
+__attribute__((amdgpu_waves_per_eu(7, 7))) void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                       const uint64_t* __restrict__ off, uint32_t n,
                       const int32_t* __restrict__ polyt,
                       const unsigned long long* __restrict__ keys,
@@ -1356,6 +1370,7 @@ void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
     // then written as "not extracted, batch incomplete", so that whatever consumes the records next on the stream
     // (bdg_nearest16_recs_dev, bdg_distinct_dev) sees nothing usable; bdg_extract_status() reports BDG_E_CAPACITY.
     __shared__ uint32_t s_over;
+    __shared__ uint32_t s_rwin[4][10][64];           // the reverse pass's windows (finalize_strand)
     if (threadIdx.x == 0) s_over = 0u;
     __syncthreads();
     if (threadIdx.x < NSH) {
@@ -1382,8 +1397,9 @@ void k_finalize_reads(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         krF = keys[2 * r]; krR = keys[2 * r + 1];
         ksF = keys[2ull * n + 2 * r]; ksR = keys[2ull * n + 2 * r + 1];
     }
-    const StrandRes f = finalize_strand(bases, total_rounded, rs, L, 0, ptF, krF, ksF, (int)umi_len, active);
-    const StrandRes v = finalize_strand(bases, total_rounded, rs, L, 1, ptR, krR, ksR, (int)umi_len, active);
+    uint32_t* const win = &s_rwin[threadIdx.x >> 6][0][threadIdx.x & 63];
+    const StrandRes f = finalize_strand(bases, total_rounded, rs, L, 0, ptF, krF, ksF, (int)umi_len, active, win);
+    const StrandRes v = finalize_strand(bases, total_rounded, rs, L, 1, ptR, krR, ksR, (int)umi_len, active, win);
     if (!active) return;
     bool use_rev;
     if (strand_rule == BDG_STRAND_RULE_NO_POLYA) use_rev = !f.valid; // find_barcode_umi_no_polya, :234-247: forward if valid, else
