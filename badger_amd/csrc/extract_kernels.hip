@@ -39,13 +39,6 @@ constexpr int BC_LEN = 16;
 
 // internal base code = (ascii >> 1) & 3 : A0 C1 T2 G3 ; complement = code ^ 2
 constexpr uint32_t icode(char c) { return (uint32_t(c) >> 1) & 3u; }
-constexpr uint32_t eq_mask(uint32_t code)
-{
-    uint32_t m = 0;
-    for (int i = 0; i < R1_LEN; ++i) if (icode(R1[i]) == code) m |= 1u << i;
-    return m;
-}
-constexpr uint32_t EQ0 = eq_mask(0), EQ1 = eq_mask(1), EQ2 = eq_mask(2), EQ3 = eq_mask(3);
 
 constexpr int KEY_SHIFT = 11;                 // score | (63-col) << 5 | (31-row)
 constexpr int32_t ONE = 1 << KEY_SHIFT;
@@ -768,78 +761,22 @@ __device__ __forceinline__ int wave_max(int v)
 }
 
 // ---------------------------------------------------------------------------
-// Smith-Waterman of R1 (rows) against the first n characters of the block
-// (columns), +1/-1/-1 linear gaps, N scores 0.  Returns the maximum over all cells of
-//   (H << 11) | (63 - col) << 5 | (31 - row)
-// i.e. the best score, its first column, and the smallest row in that column --
-// the end cell SSW reports (see oracle/badger_oracle.c, sw_scan).  The running key
-// after column n1-1 / n2-1 is returned in snap1 / snap2: the result for the window
-// made of the first n1 / n2 columns.
-// REV: rows are pattern[end_read - r] (reverse pass of ssw_align).
-// ---------------------------------------------------------------------------
-template <int NW, bool WITH_N, bool REV>
-__device__ __forceinline__ uint32_t sw_block(uint32_t (&w)[NW], int ndw, int n, uint32_t comp, int end_read,
-                                             int n1, int n2, uint32_t& snap1, uint32_t& snap2)
-{
-    int32_t hs[R1_LEN];
-#pragma unroll
-    for (int i = 0; i < R1_LEN; ++i) hs[i] = 0;
-    int32_t acc = 0;
-    uint32_t s1 = 0, s2 = 0;
-#pragma nounroll
-    for (int d = 0; d < ndw; ++d) {
-        const uint32_t cur = w[0];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int j = d * 4 + b;
-            const uint32_t c = (cur >> (8 * b)) & 0xFFu;
-            const uint32_t code = ((c >> 1) & 3u) ^ (comp << 1);
-            uint32_t e = (code & 2u) ? ((code & 1u) ? EQ3 : EQ2) : ((code & 1u) ? EQ1 : EQ0);
-            const bool live = j < n;
-            const bool isN = WITH_N && (c == (uint32_t)'N');
-            e = (live && !isN) ? e : 0u;
-            if (REV) e = __brev(e) >> (31 - end_read);
-            const int32_t dN = (WITH_N && isN && live) ? ONE : 0;
-            const int32_t cj = (63 - j) << 5;
-            int32_t diag_t = -ONE;       // H(-1, j-1) - 1
-            int32_t up = 0;              // H(i-1, j)
-            int32_t keyprev = 0;
-#pragma unroll
-            for (int i = 0; i < R1_LEN; ++i) {
-                const int32_t tl = hs[i] - ONE;                                  // H(i, j-1) - 1
-                int32_t dg = (int32_t)(__builtin_amdgcn_ubfe(e, i, 1) << (KEY_SHIFT + 1)) + diag_t;   // H(i-1,j-1) +/- 1
-                if (WITH_N) dg += dN;
-                const int32_t tu = up - ONE;                                     // H(i-1, j) - 1
-                int32_t h = max(max(dg, tl), tu);
-                h = max(h, 0);
-                diag_t = tl;
-                hs[i] = h;
-                up = h;
-                const int32_t key = h | cj | (31 - i);
-                if (i & 1) acc = max(max(acc, keyprev), key);
-                else keyprev = key;
-            }
-            s1 = (j + 1 == n1) ? (uint32_t)acc : s1;
-            s2 = (j + 1 == n2) ? (uint32_t)acc : s2;
-        }
-#pragma unroll
-        for (int i = 0; i < NW - 1; ++i) w[i] = w[i + 1];
-    }
-    snap1 = s1; snap2 = s2;
-    return (uint32_t)acc;
-}
-
-// ---------------------------------------------------------------------------
-// Packed form of sw_block for the forward pass: TWO clusters per lane, one per 16-bit half, so that
-// add / subtract / max run as packed 16-bit instructions on two cells at once.
-// Cells hold G = (H + 1) << 10 as unsigned 16-bit: H - 1 is never negative in that form (G - 1024 >= 0) and nothing
+// Smith-Waterman of R1 (rows) against the first characters of a window (columns), +1/-1/-1 linear gaps, N scores 0.
+// The result is the maximum over all cells of the SSW key
+//   (H + 1) << 11 | (63 - col) << 5 | (31 - row)
+// i.e. the best score, its first column, and the smallest row in that column - the end cell SSW reports (see
+// oracle/badger_oracle.c, sw_scan); unpk() takes the 2048 off again (0: no cell with a positive score).  The running key after
+// column n1 - 1 / n2 - 1 is returned in snap1 / snap2: the result for the window made of the first n1 / n2 columns.
+//
+// TWO alignments per lane, one per 16-bit half, so that add / subtract / max run as packed 16-bit instructions on two cells
+// at once.  Cells hold G = (H + 1) << 10 as unsigned 16-bit: H - 1 is never negative in that form (G - 1024 >= 0) and nothing
 // exceeds 25 << 10 = 0x6400.  Below 0x7C00 an unsigned 16-bit pattern is also a finite non-negative half float whose
 // order is the order of the integers, so the three-way maximum of a cell is ONE v_pk_maximum3_f16 (gfx950; kernels run
 // with 16-bit denormals kept, and every cell is a multiple of 0x0400, the smallest normal number, anyway) where integer
-// instructions need two v_pk_max_u16.  The SSW key  G << 11 | (63-col) << 5 | (31-row)  is put together per COLUMN: the
-// rows contribute G << 10 | (31-row) to a column maximum (again one three-way maximum per two rows), the column adds
-// its number and moves G up one bit.  A key k of this form is the sw_block key plus 2048 (k = 0: no cell seen).
-// Eight instructions per pair of cells in round 3's form, 6.5 here.
+// instructions need two v_pk_max_u16.  The SSW key is put together per COLUMN: the rows contribute G << 10 | (31-row) to a
+// column maximum (again one three-way maximum per two rows), the column adds its number and moves G up one bit.
+// Eight instructions per pair of cells in round 3's form, 5.5 here.  (Rounds 1-3 also had a one-alignment 32-bit form for the
+// reverse pass of k_finalize_reads; that pass runs through this one now, SINGLE.)
 // ---------------------------------------------------------------------------
 constexpr uint32_t code_plane(int bit)
 {
