@@ -48,34 +48,36 @@ __device__ __forceinline__ uint32_t letter_sig(uint32_t r)
 }
 
 // One Myers pass, pattern a (rows), text b (columns) -> min of D[16][16], D[15][16], D[16][15].
+// The vectors are kept SPREAD: row i at bit 2i, where a's 2-bit codes put it.  The equality vector of a column then needs no
+// per-letter match vectors (16 x 4 compares to build them): it is two three-input operations on a's two bit planes and the
+// column's code bits spread over the word, as in k_strict_filter.  The one addition of the recurrence must carry from bit 2i
+// to bit 2i + 2: pv keeps every odd bit set (its update, mh | ~(xv | ph), sets them by itself since xv and ph have none), so
+// a carry passes through; xh and mh then hold carries in their odd bits, which nothing reads.  293 vector instructions where
+// the form with match vectors took 511 (round 4; checked against the edit distance on the host, tools/myers_spread_check.py).
 __device__ __forceinline__ uint32_t dmin3(uint32_t a, uint32_t b)
 {
-    uint32_t peq[4] = { 0, 0, 0, 0 };
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t c = (a >> (2 * i)) & 3u;
-        peq[0] |= (c == 0u ? 1u : 0u) << i; peq[1] |= (c == 1u ? 1u : 0u) << i;
-        peq[2] |= (c == 2u ? 1u : 0u) << i; peq[3] |= (c == 3u ? 1u : 0u) << i;
-    }
-    uint32_t pv = 0xFFFFu, mv = 0u, score = 16u, score15 = 0u;
+    constexpr uint32_t EVEN = 0x55555555u;
+    const uint32_t P0 = a & EVEN, P1 = (a >> 1) & EVEN;
+    uint32_t pv = 0xFFFFFFFFu, mv = 0u, score = 16u, score15 = 0u;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const uint32_t c = (b >> (2 * j)) & 3u;
-        const uint32_t eq = (c & 2u) ? ((c & 1u) ? peq[3] : peq[2]) : ((c & 1u) ? peq[1] : peq[0]);
+        const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 2 * j, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 2 * j + 1, 1);
+        const uint32_t t1 = __builtin_amdgcn_bitop3_b32(m0, P0, EVEN, 0x82);              // ~(m0 ^ P0) & EVEN
+        const uint32_t eq = __builtin_amdgcn_bitop3_b32(t1, m1, P1, 0x90);                // t1 & ~(m1 ^ P1)
         const uint32_t xv = eq | mv;
-        const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-        uint32_t ph = mv | ~(xh | pv);
+        const uint32_t xh = __builtin_amdgcn_bitop3_b32((eq & pv) + pv, pv, eq, 0xBE);     // (((eq & pv) + pv) ^ pv) | eq
+        uint32_t ph = __builtin_amdgcn_bitop3_b32(mv, xh, pv, 0xF1);                      // mv | ~(xh | pv)
         uint32_t mh = pv & xh;
-        score += (ph >> 15) & 1u;
-        score -= (mh >> 15) & 1u;
-        ph = (ph << 1) | 1u;
-        mh = mh << 1;
-        pv = mh | ~(xv | ph);
+        score += (ph >> 30) & 1u;
+        score -= (mh >> 30) & 1u;
+        ph = (ph << 2) | 1u;
+        mh = mh << 2;
+        pv = __builtin_amdgcn_bitop3_b32(mh, xv, ph, 0xF1);                               // mh | ~(xv | ph)
         mv = ph & xv;
         if (j == 14) score15 = score;              // D[16][15] = ed(a, b[:-1])
     }
     // D[15][16] = D[16][16] - (vertical delta of the last row in the last column)
-    const uint32_t d1516 = score - ((pv >> 15) & 1u) + ((mv >> 15) & 1u);   // ed(a[:-1], b)
+    const uint32_t d1516 = score - ((pv >> 30) & 1u) + ((mv >> 30) & 1u);   // ed(a[:-1], b)
     uint32_t d = score < score15 ? score : score15;
     return d < d1516 ? d : d1516;
 }

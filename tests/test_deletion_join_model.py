@@ -273,3 +273,15 @@ def test_counting_pass_places_are_exact():
         seg = out[base[b]:base[b + 1]]
         assert ((seg >> 20) == b).all()
     assert sorted(out.tolist()) == sorted(int(e) for t in tiles for e in t)
+
+
+def test_spread_form_of_the_verifying_myers_pass():
+    """dmin3 (graph_kernels.hip) keeps its bit vectors spread over the even bits and lets the addition carry through odd bits
+    that pv keeps set; tools/myers_spread_check.py restates exactly those statements on the host and compares 20,000 pairs with
+    the edit-distance recurrence."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "myers_spread_check.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
