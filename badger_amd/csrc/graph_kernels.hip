@@ -481,31 +481,6 @@ void k_qj_split(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ 
     split[t] = lo;
 }
 
-// Myers pass with the pattern's match vectors given (the pattern is the block's row: built once per row)
-__device__ __forceinline__ uint32_t dmin3_peq(const uint32_t (&peq)[4], uint32_t b)
-{
-    uint32_t pv = 0xFFFFu, mv = 0u, score = 16u, score15 = 0u;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t c = (b >> (2 * j)) & 3u;
-        const uint32_t eq = (c & 2u) ? ((c & 1u) ? peq[3] : peq[2]) : ((c & 1u) ? peq[1] : peq[0]);
-        const uint32_t xv = eq | mv;
-        const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-        uint32_t ph = mv | ~(xh | pv);
-        uint32_t mh = pv & xh;
-        score += (ph >> 15) & 1u;
-        score -= (mh >> 15) & 1u;
-        ph = (ph << 1) | 1u;
-        mh = mh << 1;
-        pv = mh | ~(xv | ph);
-        mv = ph & xv;
-        if (j == 14) score15 = score;
-    }
-    const uint32_t d1516 = score - ((pv >> 15) & 1u) + ((mv >> 15) & 1u);
-    uint32_t d = score < score15 ? score : score15;
-    return d < d1516 ? d : d1516;
-}
-
 // first matching six-mer position pair (p in a, p' in b), lexicographically: p * 16 + p'; 0xFFFFFFFF if none
 __device__ __forceinline__ uint32_t qgram_first_match(uint32_t a, uint32_t b)
 {
@@ -558,16 +533,9 @@ void k_graph_qjoin(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
 
     for (uint32_t i = row_begin + blockIdx.x; i < row_end; i += gridDim.x) {
         const uint32_t a = ranks[i];
-        uint32_t peq[4] = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const uint32_t c = (a >> (2 * u)) & 3u;
-            peq[0] |= (c == 0u ? 1u : 0u) << u; peq[1] |= (c == 1u ? 1u : 0u) << u;
-            peq[2] |= (c == 2u ? 1u : 0u) << u; peq[3] |= (c == 3u ? 1u : 0u) << u;
-        }
         auto verify = [&](bool on, uint32_t j) {
             uint32_t b = 0, d = 99u;
-            if (on) { b = ranks[j]; d = dmin3_peq(peq, b); }
+            if (on) { b = ranks[j]; d = dmin3(a, b); }
             edge_push(on && d <= thr, a, b, d, s_edges[wv], ne, lane, out, cap, n_edges);
         };
         // one Myers pass per listed row, full lanes (block-wide; the list is empty afterwards)
@@ -625,7 +593,7 @@ void k_graph_qjoin(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
                             if (j > i) {
                                 b = ranks[j];
                                 on = qgram_first_match(a, b) == sgi * 16u + (v & 15u) && qgram_S(a, b) >= Tc;
-                                if (on) d = dmin3_peq(peq, b);
+                                if (on) d = dmin3(a, b);
                             }
                         }
                         edge_push(on && d <= thr, a, b, d, s_edges[wv], ne, lane, out, cap, n_edges);
@@ -699,33 +667,6 @@ void k_graph_qjoin(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t row_
 constexpr uint32_t QW_HCAP = 128;                // listed rows per wave
 constexpr uint32_t QW_SENT = 0x0FFFFFFFu;        // "no entry": a row beyond every slice (rows are < 2^25)
 
-// dmin3 with the pattern's four match vectors in named registers (an array here ends up in scratch memory: the compiler
-// turns the letter select into an indexed load)
-__device__ __forceinline__ uint32_t dmin3_peq4(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t b)
-{
-    uint32_t pv = 0xFFFFu, mv = 0u, score = 16u, score15 = 0u;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t c = (b >> (2 * j)) & 3u;
-        const uint32_t lo = (c & 1u) ? p1 : p0, hi = (c & 1u) ? p3 : p2;
-        const uint32_t eq = (c & 2u) ? hi : lo;
-        const uint32_t xv = eq | mv;
-        const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-        uint32_t ph = mv | ~(xh | pv);
-        uint32_t mh = pv & xh;
-        score += (ph >> 15) & 1u;
-        score -= (mh >> 15) & 1u;
-        ph = (ph << 1) | 1u;
-        mh = mh << 1;
-        pv = mh | ~(xv | ph);
-        mv = ph & xv;
-        if (j == 14) score15 = score;
-    }
-    const uint32_t d1516 = score - ((pv >> 15) & 1u) + ((mv >> 15) & 1u);
-    uint32_t d = score < score15 ? score : score15;
-    return d < d1516 ? d : d1516;
-}
-
 // ROWS: rows per slice = bytes of LDS counters per wave; WAVES: waves per block (the block's static LDS stays below 64 KB);
 // T_GE2: T >= 2, which lets a spare word (always 0) stand in for "no entry" without a check
 template <uint32_t ROWS, int WAVES, bool T_GE2>
@@ -756,20 +697,13 @@ void k_graph_qjoin_w(const uint32_t* __restrict__ ranks, uint32_t n, uint32_t ro
 
     for (uint32_t i = row_begin + wave_id; i < row_end; i += nwaves) {
         const uint32_t a = __builtin_amdgcn_readfirstlane(ranks[i]);
-        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const uint32_t c = (a >> (2 * u)) & 3u;
-            p0 |= (c == 0u ? 1u : 0u) << u; p1 |= (c == 1u ? 1u : 0u) << u;
-            p2 |= (c == 2u ? 1u : 0u) << u; p3 |= (c == 3u ? 1u : 0u) << u;
-        }
         uint32_t nh = 0;
         auto flush_hits = [&]() {
             for (uint32_t h0 = 0; h0 < nh; h0 += 64u) {
                 const uint32_t h = h0 + (uint32_t)lane;
                 const bool on = h < nh;
                 const uint32_t b = ranks[on ? hits[h] : i];
-                const uint32_t d = on ? dmin3_peq4(p0, p1, p2, p3, b) : 99u;
+                const uint32_t d = on ? dmin3(a, b) : 99u;
                 edge_push(on && d <= thr, a, b, d, s_edges[wv], ne, lane, out, cap, n_edges);
             }
             nh = 0;

@@ -69,13 +69,11 @@ void k_nearest_scan(const uint32_t* __restrict__ q, uint32_t qstride, int recs,
     const uint32_t qi = active ? (qlist ? qlist[slot] : slot) : 0u;
     const uint32_t qq = active ? q[(size_t)qi * qstride] : 0u;
     const bool usable = !recs || !active || ((q[(size_t)qi * qstride + 1] >> 24) & BDG_FLAG_RANK_OK) != 0;
-    uint32_t peq[4] = { 0, 0, 0, 0 };
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t c = (qq >> (2 * i)) & 3u;
-        peq[0] |= (c == 0u ? 1u : 0u) << i; peq[1] |= (c == 1u ? 1u : 0u) << i;
-        peq[2] |= (c == 2u ? 1u : 0u) << i; peq[3] |= (c == 3u ? 1u : 0u) << i;
-    }
+    // The Myers vectors stay SPREAD - row i of the query at bit 2i, where its 2-bit codes are - and a column's equality vector
+    // is two three-input operations on the query's two bit planes and the entry's code bits (scalars: the entry is the same in
+    // every lane); the addition carries through odd bits that pv keeps set (graph_kernels.hip, dmin3: the same statements).
+    constexpr uint32_t EVEN = 0x55555555u;
+    const uint32_t P0 = qq & EVEN, P1 = (qq >> 1) & EVEN;
     uint32_t best = 255u, bidx = NONE_IDX, ties = 0u;
     for (uint32_t t0 = 0; t0 < nw; t0 += SCAN_TILE) {
         const uint32_t tn = nw - t0 < (uint32_t)SCAN_TILE ? nw - t0 : (uint32_t)SCAN_TILE;
@@ -85,20 +83,21 @@ void k_nearest_scan(const uint32_t* __restrict__ q, uint32_t qstride, int recs,
         for (uint32_t k = 0; k < tn; ++k) {
             const uint32_t t = __builtin_amdgcn_readfirstlane(s_rank[k]);
             const uint32_t o = __builtin_amdgcn_readfirstlane(s_orig[k]);
-            uint32_t pv = 0xFFFFu, mv = 0u, score = 16u;
+            uint32_t pv = 0xFFFFFFFFu, mv = 0u, score = 16u;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const uint32_t c = (t >> (2 * j)) & 3u;
-                const uint32_t eq = (c & 2u) ? ((c & 1u) ? peq[3] : peq[2]) : ((c & 1u) ? peq[1] : peq[0]);
+                const uint32_t m0 = (uint32_t)((int32_t)(t << (31 - 2 * j)) >> 31), m1 = (uint32_t)((int32_t)(t << (30 - 2 * j)) >> 31);
+                const uint32_t t1 = __builtin_amdgcn_bitop3_b32(P0, m0, EVEN, 0x82);             // ~(P0 ^ m0) & EVEN
+                const uint32_t eq = __builtin_amdgcn_bitop3_b32(t1, P1, m1, 0x90);               // t1 & ~(P1 ^ m1)
                 const uint32_t xv = eq | mv;
-                const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-                uint32_t ph = mv | ~(xh | pv);
+                const uint32_t xh = __builtin_amdgcn_bitop3_b32((eq & pv) + pv, pv, eq, 0xBE);    // (((eq & pv) + pv) ^ pv) | eq
+                uint32_t ph = __builtin_amdgcn_bitop3_b32(mv, xh, pv, 0xF1);                     // mv | ~(xh | pv)
                 uint32_t mh = pv & xh;
-                score += (ph >> 15) & 1u;
-                score -= (mh >> 15) & 1u;
-                ph = (ph << 1) | 1u;
-                mh = mh << 1;
-                pv = mh | ~(xv | ph);
+                score += (ph >> 30) & 1u;
+                score -= (mh >> 30) & 1u;
+                ph = (ph << 2) | 1u;
+                mh = mh << 2;
+                pv = __builtin_amdgcn_bitop3_b32(mh, xv, ph, 0xF1);                              // mh | ~(xv | ph)
                 mv = ph & xv;
             }
             const bool better = score < best, same = score == best;
