@@ -828,14 +828,16 @@ __device__ __forceinline__ void sw_window(uint32_t (&w)[NW], int n, uint32_t com
     }
 }
 
-// win: the two windows (sw_window) of this lane in LDS, dword d of cluster A at win[d * 64], of cluster B at
-// win[(NW + d) * 64] (the loop takes one dword of each per four columns; held in registers the 2 x NW words had to be
+// win: the two windows (sw_window) of this lane in LDS but for their first dwords (firstA / firstB): dword d >= 1 of cluster A
+// at win[(d - 1) * 64], of cluster B at win[(NW - 1 + d - 1) * 64] (13 + 13 words a lane: with the re-queue staging a block of
+// k_sw_clusters stays below 32 KB, five blocks a compute unit).  The loop takes one dword of each per four columns; held in
+// registers the 2 x NW words had to be
 // moved down one place per round).  n1 / n2: the two window lengths whose running key is wanted, both clusters packed.
 // SINGLE: one alignment a lane (the low halves; the high halves see a window of 'N').  P0 / P1: the bit planes of the rows'
 // codes (R1_P0 / R1_P1, or a lane's own: the reverse pass of k_finalize_reads aligns R1[end_read .. 0]), rowmask: the rows
 // that exist.
 template <int NW, bool WITH_N, bool SINGLE>
-__device__ __forceinline__ uint32_t sw_block2(const uint32_t* win, int ndw, uint32_t n1, uint32_t n2,
+__device__ __forceinline__ uint32_t sw_block2(const uint32_t* win, uint32_t firstA, uint32_t firstB, int ndw, uint32_t n1, uint32_t n2,
                                               uint32_t P0, uint32_t P1, uint32_t rowmask,
                                               uint32_t& snap1, uint32_t& snap2)
 {
@@ -848,11 +850,11 @@ __device__ __forceinline__ uint32_t sw_block2(const uint32_t* win, int ndw, uint
 #pragma unroll
     for (int i = 0; i < R1_LEN; ++i) hm[i] = 0u;             // H = 0
     uint32_t acc = 0, s1 = 0, s2 = 0;
-    uint32_t curA = win[0], curB = SINGLE ? 0x4E4E4E4Eu : win[NW * 64];
+    uint32_t curA = firstA, curB = SINGLE ? 0x4E4E4E4Eu : firstB;
 #pragma nounroll
     for (int d = 0; d < ndw; ++d) {
-        const int dn = d + 1 < NW ? d + 1 : d;
-        const uint32_t nextA = win[dn * 64], nextB = SINGLE ? 0x4E4E4E4Eu : win[(NW + dn) * 64];
+        const int dn = d + 1 < NW ? d + 1 : NW - 1;           // (NW >= 2)
+        const uint32_t nextA = win[(dn - 1) * 64], nextB = SINGLE ? 0x4E4E4E4Eu : win[(NW - 1 + dn - 1) * 64];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int j = d * 4 + b;
@@ -1111,10 +1113,10 @@ __device__ __forceinline__ uint32_t finish_job(const ClusterJob& jb, uint32_t ac
     return (jb.active && (acc_u >> KEY_SHIFT) > score_s) ? (jb.mask & ~1u) : 0u;
 }
 
-constexpr uint32_t REQ_CAP = 256;            // per-wave staging of re-queued hits
+constexpr uint32_t REQ_CAP = 128;            // per-wave staging of re-queued hits (2 % of the clusters re-queue any)
 
 __global__ __launch_bounds__(256)
-void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
+__attribute__((amdgpu_waves_per_eu(5, 5))) void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                    const uint64_t* __restrict__ off, uint32_t n_reads,
                    const int32_t* __restrict__ polyt,
                    const QEnt* __restrict__ q, int kind, uint64_t seg,
@@ -1123,7 +1125,7 @@ void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
                    unsigned long long* __restrict__ keys)
 {
     __shared__ uint2 s_out[4][REQ_CAP];
-    __shared__ uint32_t s_win[4][2 * CW][64];    // the two windows of every lane (sw_block2)
+    __shared__ uint32_t s_win[4][2 * (CW - 1)][64];    // the two windows of every lane but for their first words (sw_block2)
     __shared__ uint32_t s_cnt[NSH];
     const uint64_t nq = queue_counts(counters, kind, 0, seg, s_cnt);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1143,12 +1145,12 @@ void k_sw_clusters(const uint8_t* __restrict__ bases, uint64_t total_rounded,
         sw_window<CW>(wb, jb.n_u, jb.strand);
         uint32_t* const win = &s_win[wv][0][lane];
 #pragma unroll
-        for (int d = 0; d < CW; ++d) { win[d * 64] = wa[d]; win[(CW + d) * 64] = wb[d]; }
+        for (int d = 1; d < CW; ++d) { win[(d - 1) * 64] = wa[d]; win[(CW - 1 + d - 1) * 64] = wb[d]; }
         __builtin_amdgcn_wave_barrier();
         uint32_t sn_s = 0, sn_r = 0;
         const uint32_t n_s2 = (uint32_t)ja.n_s | ((uint32_t)jb.n_s << 16), n_r2 = (uint32_t)ja.n_r | ((uint32_t)jb.n_r << 16);
-        const uint32_t acc = anyN ? sw_block2<CW, true, false>(win, ndw, n_s2, n_r2, R1_P0, R1_P1, 0xFFFFFFFFu, sn_s, sn_r)
-                                  : sw_block2<CW, false, false>(win, ndw, n_s2, n_r2, R1_P0, R1_P1, 0xFFFFFFFFu, sn_s, sn_r);
+        const uint32_t acc = anyN ? sw_block2<CW, true, false>(win, wa[0], wb[0], ndw, n_s2, n_r2, R1_P0, R1_P1, 0xFFFFFFFFu, sn_s, sn_r)
+                                  : sw_block2<CW, false, false>(win, wa[0], wb[0], ndw, n_s2, n_r2, R1_P0, R1_P1, 0xFFFFFFFFu, sn_s, sn_r);
         __builtin_amdgcn_wave_barrier();
         nwin += (ja.active ? 1u : 0u) + (jb.active ? 1u : 0u);
         uint32_t rest_a = finish_job(ja, unpk(sn_s, 0), unpk(sn_r, 0), unpk(acc, 0), n_reads, keys);
@@ -1241,14 +1243,14 @@ __device__ __forceinline__ StrandRes finalize_strand(const uint8_t* __restrict__
         const int ncol = need_rev ? end_ref_s + 1 : 0;
         sw_window<10>(w, ncol, (uint32_t)strand);
 #pragma unroll
-        for (int d = 0; d < 10; ++d) win[d * 64] = w[d];
+        for (int d = 1; d < 10; ++d) win[(d - 1) * 64] = w[d];
         __builtin_amdgcn_wave_barrier();
         const int ndw = (wave_max(ncol) + 3) >> 2;
         const uint32_t p0r = __brev(R1_P0) >> (31 - end_read_s), p1r = __brev(R1_P1) >> (31 - end_read_s);
         const uint32_t rows = (2u << end_read_s) - 1u;
         uint32_t sn1, sn2;
-        const uint32_t acc = anyN ? sw_block2<10, true, true>(win, ndw, 0u, 0u, p0r, p1r, rows, sn1, sn2)
-                                  : sw_block2<10, false, true>(win, ndw, 0u, 0u, p0r, p1r, rows, sn1, sn2);
+        const uint32_t acc = anyN ? sw_block2<10, true, true>(win, w[0], 0u, ndw, 0u, 0u, p0r, p1r, rows, sn1, sn2)
+                                  : sw_block2<10, false, true>(win, w[0], 0u, ndw, 0u, 0u, p0r, p1r, rows, sn1, sn2);
         __builtin_amdgcn_wave_barrier();
         if (need_rev) {
             const int rr = 31 - (int)(unpk(acc, 0) & 31u);             // (the pass always finds the forward score again: the key is never 0)
@@ -1307,7 +1309,7 @@ __attribute__((amdgpu_waves_per_eu(7, 7))) void k_finalize_reads(const uint8_t* 
     // then written as "not extracted, batch incomplete", so that whatever consumes the records next on the stream
     // (bdg_nearest16_recs_dev, bdg_distinct_dev) sees nothing usable; bdg_extract_status() reports BDG_E_CAPACITY.
     __shared__ uint32_t s_over;
-    __shared__ uint32_t s_rwin[4][10][64];           // the reverse pass's windows (finalize_strand)
+    __shared__ uint32_t s_rwin[4][9][64];            // the reverse pass's windows but for their first words (finalize_strand)
     if (threadIdx.x == 0) s_over = 0u;
     __syncthreads();
     if (threadIdx.x < NSH) {

@@ -53,16 +53,16 @@ def test_scan_kernel_budget(scan_isa):
 def test_alignment_kernel_budget(scan_isa):
     """k_sw_clusters (round 4): the three-way maximum of a cell is the packed half-float instruction, the match bonus a packed
     multiply-add, the windows live in LDS - 96 registers where the integer form with the windows in registers took 240.
-    Four blocks of four waves per CU is what the launch assumes."""
+    Five blocks of four waves per CU (30 KB of LDS a block) is what the kernel is sized for."""
     text = scan_isa[3]
     m = re.search(r"^(_ZN\S*k_sw_clusters\S*):[^\n]*\n(.*?)\n\s*\.amdhsa_kernel \1\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
     assert m, "k_sw_clusters not found in the generated code"
     body, desc = m.group(2), m.group(3)
     meta = dict(re.findall(r"\.set \S*k_sw_clusters\S*\.(num_vgpr|private_seg_size), (\d+)", text))
     assert int(meta["private_seg_size"]) == 0, "k_sw_clusters spills"
-    assert int(meta["num_vgpr"]) <= 128, "more than 128 registers: fewer than 4 waves per SIMD"
+    assert int(meta["num_vgpr"]) <= 96, "more than 96 registers: fewer than 5 waves per SIMD"
     lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", desc).group(1))
-    assert 4 * lds <= 160 * 1024, "four blocks no longer fit a CU's LDS"
+    assert 5 * lds <= 160 * 1024, "five blocks no longer fit a CU's LDS"
     assert body.count("v_pk_maximum3_f16") >= 2 * 33 * 4, "the three-way maxima are not single instructions any more"
     assert body.count("v_pk_mad_u16") >= 2 * 22 * 4, "the match bonus is not a multiply-add any more"
 
