@@ -932,7 +932,9 @@ __device__ __forceinline__ uint32_t d1_key(uint32_t r, uint32_t p)
 }
 
 // x[:15] against y without its letter `del`, equal but for one substituted letter at place `sub` of x[:15]?  late: the
-// substitution lies at or behind the deleted letter's place (then y's letter is y[sub + 1]), else in front of it
+// substitution lies at or behind the deleted letter's place (then y's letter is y[sub + 1]), else in front of it.
+// Straight-line code (no branch: the reporting rule runs for every meeting, 64 different pairs a wave, and every branch it
+// had was taken by some lane - 22 of them cost more than the arithmetic); without a relation: del = 1, sub = 0, late = false.
 __device__ __forceinline__ bool d2_shifted(uint32_t x, uint32_t y, uint32_t& del, uint32_t& sub, bool& late)
 {
     const uint32_t u = x & 0x3FFFFFFFu;
@@ -941,13 +943,16 @@ __device__ __forceinline__ bool d2_shifted(uint32_t x, uint32_t y, uint32_t& del
     const uint32_t nz1 = (x1 | (x1 >> 1)) & 0x15555555u;               // place p: x[p] != y[p + 1]
     const uint32_t f0 = nz0 ? (uint32_t)__builtin_ctz(nz0) >> 1 : 15u;
     const uint32_t behind = nz1 & ~((1u << (2u * f0)) - 1u);
-    if (__popc(behind) == 1) { del = f0; sub = (uint32_t)__builtin_ctz(behind) >> 1; late = true; return true; }
-    if (nz0) {
-        const uint32_t rest = nz0 & (nz0 - 1u);
-        const uint32_t j = rest ? (uint32_t)__builtin_ctz(rest) >> 1 : 15u;
-        if ((nz1 & ~((1u << (2u * j)) - 1u)) == 0u) { del = j; sub = f0; late = false; return true; }
-    }
-    return false;
+    const bool ok_late = __popc(behind) == 1;
+    const uint32_t sub_late = behind ? (uint32_t)__builtin_ctz(behind) >> 1 : 0u;
+    const uint32_t rest = nz0 & (nz0 - 1u);
+    const uint32_t j = rest ? (uint32_t)__builtin_ctz(rest) >> 1 : 15u;
+    const bool ok_early = nz0 != 0u && (nz1 & ~((1u << (2u * j)) - 1u)) == 0u;
+    const bool ok = ok_late || ok_early;
+    late = ok_late;
+    del = ok_late ? f0 : (ok_early ? j : 1u);
+    sub = ok_late ? sub_late : (ok_early ? f0 : 0u);
+    return ok;
 }
 
 // Which of the 14-mers a pair shares reports it.  A function of the two barcodes alone (a = the lower row), so that every
@@ -966,27 +971,32 @@ __device__ __forceinline__ bool d2_shifted(uint32_t x, uint32_t y, uint32_t& del
 // edge and is not even verified.  Returns 1: k is that 14-mer; 0: it is not, or there is no such relation.
 __device__ __forceinline__ int d2_reports(uint32_t a, uint32_t b, uint32_t k)
 {
+    // every relation's 14-mer is computed, the first relation that holds (in the order above) names the reporter: no branch
     const uint32_t x = a ^ b;                                          // (a != b)
     const uint32_t nz = (x | (x >> 1)) & 0x55555555u;
     const uint32_t h = (uint32_t)__popc(nz);
     const uint32_t lcp = (uint32_t)__builtin_ctz(nz) >> 1, lcs = (uint32_t)__builtin_clz(nz) >> 1;
-    if (h <= 2u) {
-        const uint32_t s1 = lcp, s2 = h == 2u ? 15u - lcs : (s1 == 0u ? 1u : 0u);
-        const uint32_t p = s1 < s2 ? s1 : s2, q = s1 < s2 ? s2 : s1;
-        return d2_key(a, p, q) == k ? 1 : 0;
-    }
-    const uint32_t far = 15u - lcs;                                    // first position from which on the tails agree (lcs <= 13 here)
+    // 1. at most two differing letters
+    const bool c1 = h <= 2u;
+    const uint32_t s1 = lcp, s2 = h == 2u ? 15u - lcs : (s1 == 0u ? 1u : 0u);
+    const uint32_t k1 = d2_key(a, s1 < s2 ? s1 : s2, s1 < s2 ? s2 : s1);
+    // 2. one insertion + one deletion
+    const uint32_t far = 15u - lcs;                                    // first position from which on the tails agree
     const uint32_t near = lcp < far ? lcp : far;
     const uint32_t span = ((1u << (2u * far)) - 1u) & ~((1u << (2u * near)) - 1u);      // letters near .. far - 1
-    if ((((a >> 2) ^ b) & span) == 0u) return (d1_key(a, near) >> 2) == k ? 1 : 0;       // i = near <= j = far
-    if ((((b >> 2) ^ a) & span) == 0u) return (d1_key(a, far) >> 2) == k ? 1 : 0;        // j = near < i = far
+    const bool c2a = (((a >> 2) ^ b) & span) == 0u;                    // i = near <= j = far
+    const bool c2b = (((b >> 2) ^ a) & span) == 0u;                    // j = near < i = far
+    const uint32_t k2 = d1_key(a, c2a ? near : far) >> 2;
     // 3. the forms through a[:-1] / b[:-1] with one more edit: x[:15] equals y without one letter but for one substituted
     //    letter (the shift of the deleted letter sits either in front of the substitution or behind it): the 14-mer without
     //    the substituted letter and the dropped last one / the deleted one
-    uint32_t del, sub; bool late;
-    if (d2_shifted(a, b, del, sub, late)) return d2_key(a, sub, 15u) == k ? 1 : 0;
-    if (d2_shifted(b, a, del, sub, late)) return (late ? d2_key(a, del, sub + 1u) : d2_key(a, sub, del)) == k ? 1 : 0;
-    return 0;                                                          // none of the relations holds: dmin(a, b) > 2, no edge
+    uint32_t del_a, sub_a, del_b, sub_b; bool late_a, late_b;
+    const bool c3a = d2_shifted(a, b, del_a, sub_a, late_a);
+    const bool c3b = d2_shifted(b, a, del_b, sub_b, late_b);
+    const uint32_t p3 = c3a ? sub_a : (late_b ? del_b : sub_b), q3 = c3a ? 15u : (late_b ? sub_b + 1u : del_b);
+    const uint32_t k3 = d2_key(a, p3, q3);
+    const uint32_t want = c1 ? k1 : ((c2a || c2b) ? k2 : k3);
+    return (c1 || c2a || c2b || c3a || c3b) && want == k ? 1 : 0;     // none of the relations holds: dmin(a, b) > 2, no edge
 }
 
 // thr 1: dmin(a, b) <= 1 means one substituted letter, or a without letter i == b without letter j (which covers the forms

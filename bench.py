@@ -579,6 +579,9 @@ def bench_calls(args, rank, world, dev, local_dev):
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pc["traffic"], "traffic_source": pc["source"],
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": per_launch_ms[dom], "int_issue": int_issue},
+            # the whole step against the same roofline: the algorithmic bytes of K1 and K2 together / the step's time per GPU
+            "whole_step": {"algorithmic_bytes": k1_bytes + k2_bytes, "achieved": (k1_bytes + k2_bytes) / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                           "frac_of_hbm_peak": (k1_bytes + k2_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(table_ms.items())},
             "kernels_ms_per_step_source": "%d steps behind the timed region with every kernel timed; roofline.kernel_ms is the dominant "
                                           "kernel's mean over the timed region itself, where only it carries events%s" % (
