@@ -88,6 +88,7 @@ int bdg_nearest16_launch(bdg_ctx*, const uint32_t*, uint32_t, int, uint32_t, uin
 int bdg_launch_deferred_match(bdg_ctx* ctx, bool behind_scan)
 {
     if (!ctx->deferred.pending) return BDG_OK;
+    BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));          // (bdg_synchronize of one context among several devices' contexts)
     const bdg_ctx::DeferredMatch d = ctx->deferred;
     ctx->deferred.pending = false;
     // behind the extraction that wrote the records (ev_main, recorded when the match was asked for) and, when the next
