@@ -300,10 +300,12 @@ int bdg_set_overlap(bdg_ctx* ctx, int on)
     if (on && !ctx->aux_stream) {
         // (same priority as the main stream: measured against the lowest and the highest one, tools/ov_prio_probe.sh)
         BDG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
-        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_scan, hipEventDisableTiming));
-        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[0], hipEventDisableTiming));
-        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[1], hipEventDisableTiming));
+        // (device-scope release: these events order kernels of two streams of one device; the default, a release to the
+        // system, writes the caches back and kept the next kernel waiting 12 us behind the scan)
+        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming | hipEventReleaseToDevice));
+        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_scan, hipEventDisableTiming | hipEventReleaseToDevice));
+        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[0], hipEventDisableTiming | hipEventReleaseToDevice));
+        BDG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[1], hipEventDisableTiming | hipEventReleaseToDevice));
     }
     ctx->aux_count = 0;
     ctx->overlap = on != 0;
@@ -446,7 +448,7 @@ static int slot_enqueue(bdg_ctx* ctx, bdg_ctx::Slot& sl)
     sl.qcap = ctx->x_hits_cap_launched;
     hipStream_t st = ctx->stream;
     BDG_HIP_TRY(ctx, hipMemcpyAsync(sl.h_recs, sl.d_recs.p, sizeof(bdg_extract_rec) * (size_t)sl.n, hipMemcpyDeviceToHost, st));
-    BDG_HIP_TRY(ctx, hipMemcpyAsync(sl.h_counters, ctx->x_counters.p, bdg_extract_counter_bytes(), hipMemcpyDeviceToHost, st));
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(sl.h_counters, bdg_extract_counters_now(ctx), bdg_extract_counter_bytes(), hipMemcpyDeviceToHost, st));
     BDG_HIP_TRY(ctx, hipEventRecord(sl.done, st));
     return BDG_OK;
 }

@@ -53,7 +53,9 @@ struct bdg_ctx {
     DevBuf x_polyt;      // int32 [2n]
     DevBuf x_keys;       // uint64 [4n]  relaxed[2n] | strict[2n]
     DevBuf x_hits;       // uint64 [hits_cap]
-    DevBuf x_counters;   // uint64 [8]
+    DevBuf x_counters;   // two sets of the extraction's counters: a batch uses one and its last kernel clears the other for the next
+    uint32_t x_counter_set = 0;          // the set of the batch launched last
+    void* x_counters_cleared = nullptr;  // the allocation both sets of which have been cleared once
     uint64_t x_hits_cap = 0;
     uint64_t x_hits_cap_fixed = 0;     // bdg_extract_set_queue_capacity (0 = automatic)
     int x_strand_rule = 0;             // bdg_extract_set_strand_rule
@@ -118,6 +120,7 @@ struct bdg_ctx {
 
 // Grow-only device buffer.
 int bdg_reserve(bdg_ctx* ctx, DevBuf& b, size_t bytes);
+const void* bdg_extract_counters_now(const bdg_ctx* ctx);   // the counters of the extraction launched last (extract_kernels.hip)
 int bdg_launch_deferred_match(bdg_ctx* ctx, bool behind_scan);   // overlap mode: queue the waiting whitelist match now (bdg_abi.cpp)
 
 // Event-bracketed launch bookkeeping.

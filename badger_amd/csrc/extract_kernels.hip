@@ -1301,8 +1301,13 @@ __attribute__((amdgpu_waves_per_eu(7, 7))) void k_finalize_reads(const uint8_t* 
                       const int32_t* __restrict__ polyt,
                       const unsigned long long* __restrict__ keys,
                       const unsigned long long* __restrict__ counters, uint64_t qcap,
-                      uint32_t umi_len, int strand_rule, bdg_extract_rec* __restrict__ out)
+                      uint32_t umi_len, int strand_rule, bdg_extract_rec* __restrict__ out,
+                      unsigned long long* __restrict__ next_counters)
 {
+    // The NEXT batch's counters (the other of two sets) are cleared here, by the last kernel of this batch: a memset of its
+    // own between two batches cost the stream 20 us of switching from kernels to a fill and back (round 4, kernel trace).
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(COUNTER_BYTES / 8); i += 256u) next_counters[i] = 0ull;
     const uint64_t r = (uint64_t)blockIdx.x * 256ull + threadIdx.x;
     const bool active = r < n;
     // A queue that overflowed dropped alignment candidates: no record of this batch can be trusted.  Every record is
@@ -1416,7 +1421,7 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
     }
     if ((rc = bdg_reserve(ctx, ctx->x_polyt, sizeof(int32_t) * 2ull * n))) return rc;
     if ((rc = bdg_reserve(ctx, ctx->x_keys, sizeof(uint64_t) * 4ull * n))) return rc;
-    if ((rc = bdg_reserve(ctx, ctx->x_counters, COUNTER_BYTES))) return rc;
+    if ((rc = bdg_reserve(ctx, ctx->x_counters, 2 * COUNTER_BYTES))) return rc;
     // three cluster queues (A: aligned, B: filtered first, C: re-queued hits of a cluster; D, the filter's survivors, reuses A),
     // 16 B per entry, each made of NSH segments of x_hits_cap entries
     uint64_t want = (total_bytes / 48 + 4096 + NSH - 1) / NSH;
@@ -1432,10 +1437,15 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
 
     hipStream_t st = ctx->stream;
     const uint64_t total_rounded = (total_bytes + 15ull) & ~15ull;
-    auto* counters = static_cast<unsigned long long*>(ctx->x_counters.p);
+    if (ctx->x_counters_cleared != ctx->x_counters.p) {          // a fresh allocation: both sets once, here
+        BDG_HIP_TRY(ctx, hipMemsetAsync(ctx->x_counters.p, 0, 2 * COUNTER_BYTES, st));
+        ctx->x_counters_cleared = ctx->x_counters.p;
+    }
+    ctx->x_counter_set ^= 1u;                                     // this batch's set was cleared by the batch before (k_finalize_reads)
+    auto* counters = static_cast<unsigned long long*>(ctx->x_counters.p) + (size_t)ctx->x_counter_set * (COUNTER_BYTES / 8);
+    auto* next_counters = static_cast<unsigned long long*>(ctx->x_counters.p) + (size_t)(ctx->x_counter_set ^ 1u) * (COUNTER_BYTES / 8);
     auto* keys = static_cast<unsigned long long*>(ctx->x_keys.p);
     const auto* pt = static_cast<const int32_t*>(ctx->x_polyt.p);
-    BDG_HIP_TRY(ctx, hipMemsetAsync(counters, 0, COUNTER_BYTES, st));
     {
         ScopedKernelTimer tm(ctx, "k_scan_reads");
         const uint32_t ntasks = (n + TASK_READS - 1) / TASK_READS;
@@ -1470,7 +1480,8 @@ int bdg_extract_launch(bdg_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_o
         ScopedKernelTimer tm(ctx, "k_finalize_reads");
         hipLaunchKernelGGL(k_finalize_reads, dim3((n + 255) / 256), dim3(256), 0, st, d_bases, total_rounded, d_off, n,
                            static_cast<const int32_t*>(ctx->x_polyt.p),
-                           static_cast<const unsigned long long*>(ctx->x_keys.p), counters, qcap, umi_len, ctx->x_strand_rule, d_out);
+                           static_cast<const unsigned long long*>(ctx->x_keys.p), counters, qcap, umi_len, ctx->x_strand_rule, d_out,
+                           next_counters);
     }
     BDG_HIP_TRY(ctx, hipGetLastError());
     return BDG_OK;
@@ -1496,7 +1507,7 @@ void sum_counters(const uint64_t* c, CounterSums& cs)
 int read_counters(bdg_ctx* ctx, CounterSums& cs)
 {
     std::vector<uint64_t> c(COUNTER_BYTES / 8);
-    BDG_HIP_TRY(ctx, hipMemcpyAsync(c.data(), ctx->x_counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    BDG_HIP_TRY(ctx, hipMemcpyAsync(c.data(), bdg_extract_counters_now(ctx), COUNTER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     BDG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     sum_counters(c.data(), cs);
     return BDG_OK;
@@ -1525,6 +1536,11 @@ int judge_counters(bdg_ctx* ctx, const CounterSums& cs, uint64_t qcap, uint64_t*
 }  // namespace
 
 size_t bdg_extract_counter_bytes() { return COUNTER_BYTES; }
+// the counters of the batch launched last (one of the two sets)
+const void* bdg_extract_counters_now(const bdg_ctx* ctx)
+{
+    return static_cast<const char*>(ctx->x_counters.p) + (size_t)ctx->x_counter_set * COUNTER_BYTES;
+}
 
 // the same verdict from a host copy of the counters taken right behind a batch (bdg_extract_submit / collect)
 int bdg_extract_judge_host(bdg_ctx* ctx, const void* host_counters, uint64_t qcap, uint64_t* bad_read, uint64_t* n_windows)
