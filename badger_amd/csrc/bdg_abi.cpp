@@ -91,13 +91,13 @@ int bdg_launch_deferred_match(bdg_ctx* ctx, bool behind_scan)
     BDG_HIP_TRY(ctx, hipSetDevice(ctx->device));          // (bdg_synchronize of one context among several devices' contexts)
     const bdg_ctx::DeferredMatch d = ctx->deferred;
     ctx->deferred.pending = false;
-    // behind the extraction that wrote the records (ev_main, recorded when the match was asked for) and, when the next
-    // extraction has begun, behind its scan
-    BDG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_main, 0));
-    if (behind_scan) {
-        BDG_HIP_TRY(ctx, hipEventRecord(ctx->ev_scan, ctx->stream));
-        BDG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_scan, 0));
-    }
+    // behind the extraction that wrote the records: one event on the main stream, recorded NOW - behind the next extraction's
+    // scan when that has just been queued (which is behind the records' extraction in stream order), else behind whatever
+    // the main stream holds so far.  (Recording one when the match was asked for as well put a second marker between two
+    // batches: 6 us a step.)
+    hipEvent_t after = behind_scan ? ctx->ev_scan : ctx->ev_main;
+    BDG_HIP_TRY(ctx, hipEventRecord(after, ctx->stream));
+    BDG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, after, 0));
     ctx->launch_stream = ctx->aux_stream;
     ctx->aux_pending = true;
     const int rc = bdg_nearest16_launch(ctx, d.q, 8u, 1, d.n, d.max_ed, d.idx, d.ed, d.ties);
@@ -646,7 +646,6 @@ int bdg_nearest16_recs_dev(bdg_ctx* ctx, const bdg_extract_rec* d_recs, uint32_t
         int rc = bdg_launch_deferred_match(ctx, false);
         if (rc) return rc;
         if (ctx->w_n == 0) return bdg_fail(ctx, BDG_E_ARG, "no whitelist loaded (bdg_whitelist_load)");
-        BDG_HIP_TRY(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
         ctx->deferred.pending = true;
         ctx->deferred.q = reinterpret_cast<const uint32_t*>(d_recs) + 5; ctx->deferred.n = n; ctx->deferred.max_ed = max_ed;
         ctx->deferred.idx = d_best_idx; ctx->deferred.ed = d_best_ed; ctx->deferred.ties = d_n_ties;
